@@ -1,0 +1,180 @@
+/*
+ * racecar_hip.h - C ABI of libracecar_hip.so: the MI355X (gfx950) batched F1TENTH racing
+ * environment.  Plain C, plain pointers and sizes; no torch / C++ types cross this boundary.
+ *
+ * What this replaces in the reference (CPS-TUWien/racing_dreamer).  The reference has no
+ * native code; its "FFI" for this path is the Python call into the external simulator
+ * `racecar_gym` (PyBullet).  Each entry point below cites the reference call site whose
+ * role it takes over:
+ *
+ *   rc_create / rc_load_track ... MultiAgentScenario.from_spec + MultiAgentRaceEnv(scenario)
+ *                                 dreamer/wrappers.py:14-15;  SingleAgentScenario.from_spec +
+ *                                 ChangingTrackSingleAgentRaceEnv(...)
+ *                                 baselines/racing/experiments/sb3/sb_experiment.py:61-63
+ *   rc_reset .................... env.reset(mode='grid'|'random'|'random_ball')
+ *                                 dreamer/wrappers.py:72,91-92; baselines/racing/environment/common.py:28-29
+ *   rc_step ..................... env.step({'A': {'motor', 'steering'}})   dreamer/wrappers.py:62-64
+ *                                 with ActionRepeat (wrappers.py:107-116), ReduceActionSpace
+ *                                 (wrappers.py:128-134) and TimeLimit (wrappers.py:147-154) folded in
+ *   rc_get / rc_copy_out ........ the obs / reward / done / info dicts returned by step()
+ *                                 dreamer/wrappers.py:64-69,210-226
+ *   RC_F_OCCUPANCY .............. OccupancyMapObs.step                     dreamer/wrappers.py:390-408
+ *   rc_trajectory_slab .......... the per-step transition Collect.step records
+ *                                 dreamer/wrappers.py:213-219 (+ dreamer/callbacks.py:41-53)
+ *
+ * Conventions
+ *   - every function returns RC_OK (0) or a negative rc_status; the message of the last
+ *     failure on the calling thread is rc_last_error().  No exception crosses the ABI.
+ *   - one rc_env = one GPU + one HIP stream.  Calls on one handle must be serialised by the
+ *     caller (the reference callers are single threaded); different handles are independent.
+ *   - the library owns all device buffers for the handle's lifetime unless the caller passes
+ *     `external_arena`; rc_get() returns borrowed device pointers.
+ *   - all work is stream-ordered on the handle's stream; rc_sync() waits for it.
+ *   - car index c = env * cars_per_env + agent.  Arrays are SoA, one section per field.
+ */
+#ifndef RACECAR_HIP_H
+#define RACECAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_ABI_VERSION 1
+#define RC_N_BEAMS 1080
+#define RC_PATCH 64
+#define RC_MAX_CARS 4
+
+typedef struct rc_env rc_env;
+
+typedef enum rc_status {
+    RC_OK = 0,
+    RC_ERR_INVALID = -1,      /* bad argument / call order            */
+    RC_ERR_HIP = -2,          /* a HIP runtime call failed            */
+    RC_ERR_NO_TRACK = -3,     /* rc_load_track has not been called    */
+    RC_ERR_NEEDS_RESET = -4,  /* step before reset ("Must reset environment.", wrappers.py:148) */
+    RC_ERR_NOMEM = -5
+} rc_status;
+
+enum { RC_TASK_MAX_PROGRESS = 0, RC_TASK_MAX_SPEED = 1 };           /* scenario yml task_name; tasks.py:4-22 */
+enum { RC_RESET_GRID = 0, RC_RESET_RANDOM = 1, RC_RESET_RANDOM_BALL = 2 };  /* dream.py:105-108,120 */
+enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1 };              /* dream.py obs_type */
+
+/* Output / state fields, for rc_get() and rc_copy_out().  n = num_envs * cars_per_env. */
+typedef enum rc_field {
+    /* --- trajectory record, contiguous in this order (rc_trajectory_slab) --- */
+    RC_F_LIDAR = 0,          /* float32 [n, 1080]  ranges [m], beam 0 at +135 deg, clockwise  */
+    RC_F_POSE = 1,           /* float32 [n, 6]     x, y, 0, 0, 0, yaw                          */
+    RC_F_VELOCITY = 2,       /* float32 [n, 6]     v, 0, 0, 0, 0, yaw rate                     */
+    RC_F_SPEED = 3,          /* float32 [n]        |v|   (RaceCarWrapper.step, wrappers.py:66) */
+    RC_F_ACTION = 4,         /* float32 [n, 2]     the action passed to rc_step                */
+    RC_F_REWARD = 5,         /* float32 [n]        summed over the repeated sub-steps          */
+    RC_F_DISCOUNT = 6,       /* float32 [n]        1 - done               (wrappers.py:217)    */
+    RC_F_PROGRESS_TOTAL = 7, /* float32 [n]        lap + progress - 1     (wrappers.py:218)    */
+    RC_F_TIME = 8,           /* float32 [n]        simulated seconds      (wrappers.py:219)    */
+    RC_F_OCCUPANCY = 9,      /* uint8   [n, 64, 64] lidar_occupancy, 1 = drivable (only if enabled) */
+    /* --- info / flags --- */
+    RC_F_PROGRESS = 10,      /* float32 [n]  norm. distance from start in [0, 1]               */
+    RC_F_LAP = 11,           /* int32   [n]  first lap is 1                                    */
+    RC_F_CHECKPOINT = 12,    /* int32   [n]                                                    */
+    RC_F_DONE = 13,          /* uint8   [n]                                                    */
+    RC_F_TRUNCATED = 14,     /* uint8   [n]  done because of time_limit_steps                  */
+    RC_F_WALL_COLLISION = 15,     /* uint8 [n]                                                 */
+    RC_F_OPPONENT_COLLISION = 16, /* uint8 [n]                                                 */
+    RC_F_WRONG_WAY = 17,     /* uint8   [n]                                                    */
+    RC_F_FRESH = 18,         /* uint8   [n]  1 if the observation is the first of a new episode */
+    RC_F_ACCELERATION = 19,  /* float32 [n]  longitudinal acceleration                          */
+    RC_F_STEERING_ANGLE = 20,/* float32 [n]  front wheel angle [rad]                            */
+    RC_F_ACTION_IN = 21,     /* float32 [n, 2] device-side action input buffer (writable)       */
+    RC_F_COUNT = 22
+} rc_field;
+
+/* Kernels, for rc_kernel_time(). */
+enum { RC_K_DYNAMICS = 0, RC_K_RAYCAST = 1, RC_K_PATCH = 2, RC_K_RESET = 3, RC_K_ACTIONS = 4, RC_K_COUNT = 5 };
+
+typedef struct rc_config {
+    uint32_t struct_size;          /* = sizeof(rc_config), for ABI evolution                   */
+    int32_t  device;               /* HIP device ordinal                                       */
+    int32_t  num_envs;             /* envs held by this handle (this GPU's shard)              */
+    int32_t  cars_per_env;         /* 1..RC_MAX_CARS                                           */
+    int64_t  first_env;            /* global index of env 0: RNG streams are keyed by the global
+                                      env id, so results do not depend on the sharding         */
+    int32_t  obs_type;             /* RC_OBS_LIDAR | RC_OBS_LIDAR_OCCUPANCY                    */
+    int32_t  task;                 /* RC_TASK_*                                                */
+    int32_t  laps;                 /* scenario params, dreamer/scenarios/max_progress/columbia.yml:10 */
+    float    time_limit;           /*   seconds of simulated time                              */
+    int32_t  terminate_on_collision;
+    float    collision_reward;
+    int32_t  remap_actions;        /* 1: a' = (a + 1) / 2 * (high - low) + low (wrappers.py:128-130) */
+    float    action_low[2];        /*   (motor, steering), dream.py:138                        */
+    float    action_high[2];
+    int32_t  time_limit_steps;     /* TimeLimit duration in rc_step calls; 0 = off (wrappers.py:137-158) */
+    int32_t  auto_reset;           /* 1: finished envs are reset inside rc_step (batched rollouts) */
+    void    *external_arena;       /* optional caller-owned device memory for the output arena */
+    size_t   external_arena_bytes; /*   must be >= rc_arena_bytes(cfg)                         */
+    void    *stream;               /* optional hipStream_t to run on; NULL = library creates one */
+} rc_config;
+
+/* Fill `cfg` with the defaults of the reference's max_progress scenario. */
+void rc_default_config(rc_config *cfg);
+
+/* Bytes of device memory the output arena needs for this configuration. */
+size_t rc_arena_bytes(const rc_config *cfg);
+
+int rc_create(const rc_config *cfg, rc_env **out);
+void rc_destroy(rc_env *env);
+
+/*
+ * Upload one compiled track (host pointers).  Bitmaps are uint32 [h][pitch], bit i of word j =
+ * cell ix = 32*j + i, row iy = 0 is the southern-most.  progress is float32 [h][w]
+ * (norm_distance_from_start, generate-costmap.py:220-222; < 0 outside the drivable area),
+ * centerline float32 [n][4] = x, y, heading, progress (spawn table for rc_reset).
+ */
+int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivable_words,
+                  const float *progress, int32_t h, int32_t w, int32_t pitch,
+                  float resolution, float origin_x, float origin_y,
+                  const float *centerline, int32_t n_centerline);
+
+/* Reset the envs selected by the host mask (uint8 [num_envs], NULL = all) and produce their
+ * first observation. */
+int rc_reset(rc_env *env, const uint8_t *mask_or_null, int32_t mode, uint64_t seed);
+
+/* One agent step = up to `repeat` simulator sub-steps of dt = 0.01 s, then the observation.
+ * `actions_dev` is device memory float32 [n, 2] = (motor, steering); NULL = use the buffer
+ * behind RC_F_ACTION_IN (e.g. after rc_fill_random_actions). */
+int rc_step(rc_env *env, const float *actions_dev, int32_t repeat);
+/* Same, actions in host memory (copied with the stream). */
+int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat);
+
+/* Fill RC_F_ACTION_IN with U(-1,1)^2 from Philox4x32-10 keyed by (seed, step, global car id). */
+int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step);
+
+int rc_get(rc_env *env, int32_t field, void **dev_ptr, size_t *bytes);
+int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes);
+/* The trajectory record of the last step as one contiguous device slab (fields LIDAR..TIME,
+ * plus OCCUPANCY when enabled): the source buffer of the multi-GPU all-gather. */
+int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes);
+
+int rc_sync(rc_env *env);
+void *rc_stream(rc_env *env);      /* the hipStream_t the handle launches on */
+
+/* Per-kernel timing with HIP events recorded on the handle's stream. */
+int rc_set_profiling(rc_env *env, int32_t enabled);
+int rc_kernel_time(rc_env *env, int32_t kernel, double *total_ms, uint64_t *launches);
+int rc_reset_kernel_times(rc_env *env);
+
+/* Raycast implementation selector (all variants return identical results). */
+int rc_set_raycast_variant(rc_env *env, int32_t variant);
+
+/* Host-only: the beam (cos, sin) and footprint tables the kernels use (float32 [1080][2], [34][2]). */
+void rc_spec_tables(float *beams_1080x2, float *footprint_34x2);
+
+const char *rc_last_error(void);
+int rc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RACECAR_HIP_H */

@@ -1,0 +1,551 @@
+"""CPU oracle of the batched racecar environment - TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+file.  The product path (racing_dreamer_amd/) never does: it fails loudly when the HIP
+library is missing.
+
+PARITY UNPINNED for the simulator core.  The reference's env.step() arithmetic (vehicle
+integrator, LiDAR, progress reward, collision) lives in the un-vendored third-party
+packages racecar_gym (pinned @icra22 / @gym-api / e117432572bb / a9e6f5f440f3:
+dreamer/requirements.txt:6, baselines/requirements.txt:13,
+baselines/docker/requirements_sb3.txt:88, requirements_acme.txt:100) and pybullet
+3.2.1 / 3.0.8 (requirements_sb3.txt:76, requirements_acme.txt:85); neither is present
+under /root/reference nor installable here, and the reference holds no tests or golden
+vectors for this path.  This file therefore restates the build's own
+env spec whose *interface* is pinned by the reference's call sites:
+
+* step()/reset() contract, info keys ............ dreamer/wrappers.py:62-77,210-236
+* action dict {'motor','steering'} .............. dreamer/wrappers.py:63
+* 1080 beams, 270 deg clockwise from +135 deg ... dreamer/tools.py:84-86, dream.py:66
+* 15 m max range ................................ dreamer/tools.py:274
+* vehicle limits ................................ ros_agent/models/dreamer/racing_dreamer.py:14-16
+* wheelbase ..................................... ros_agent/agents/follow_the_gap/src/agent.py:78
+* task params (laps, 180 s, collision -1) ....... dreamer/scenarios/max_progress/columbia.yml:10
+* max_speed reward .............................. baselines/racing/environment/tasks.py:6-15
+* progress grid ................................. docs/maps/costmaps/generate-costmap.py:196-222
+* lidar_occupancy patch geometry ................ dreamer/wrappers.py:390-408
+* action remap .................................. dreamer/wrappers.py:128-130
+
+What IS pinned against the reference: the wrapper-layer semantics and the patch
+geometry, through tests/golden/*.npz captured from the importable reference wrappers
+(tests/golden/make_golden.py), and the Philox4x32-10 generator through the published
+Random123 known-answer vectors.
+
+Numerics contract: every float operation below is a single correctly-rounded IEEE
+binary32 operation (+, -, *, /, compare, floor, rint) applied in the written order - no
+fused multiply-add, no libm.  The HIP kernels are compiled with -ffp-contract=off and
+follow the same order, so device results are expected to be bit-identical.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+f32 = np.float32
+i32 = np.int32
+u32 = np.uint32
+u64 = np.uint64
+
+# ----------------------------------------------------------------------------- constants
+DT = f32(0.01)
+N_BEAMS = 1080
+FOV_DEG = 270.0
+MAX_RANGE = f32(15.0)
+LIDAR_X = f32(0.25)
+WHEELBASE = f32(0.3302)
+MAX_STEER = f32(0.42)
+MAX_VEL = f32(5.0)
+ACCEL_MAX = f32(4.0)             # max_force 0.5 * 8.0
+STEER_STEP = f32(0.032)          # 3.2 rad/s * dt
+INV_DT = f32(100.0)
+X_REAR, X_FRONT, HALF_W = -0.10, 0.45, 0.15
+BOX_CX = f32(0.175)              # (X_FRONT + X_REAR) / 2
+BOX_HL = f32(0.275)              # (X_FRONT - X_REAR) / 2
+BOX_HW = f32(0.15)
+N_CHECKPOINTS = 20
+PROGRESS_REWARD = f32(100.0)
+PATCH = 64
+PATCH_PX = f32(0.15625)          # 200 cells * 0.05 m / 64
+PATCH_TAPS = 2
+BALL_GAP_BINS = 12
+PI = f32(3.14159274101257324)
+TWO_PI = f32(6.28318548202514648)
+INF = f32(np.inf)
+
+TASK_MAX_PROGRESS, TASK_MAX_SPEED = 0, 1
+RESET_GRID, RESET_RANDOM, RESET_RANDOM_BALL = 0, 1, 2
+
+
+def beam_table():
+    half = math.radians(FOV_DEG) / 2.0
+    ang = half - np.arange(N_BEAMS, dtype=np.float64) * (2.0 * half / (N_BEAMS - 1))
+    return np.cos(ang).astype(f32), np.sin(ang).astype(f32)
+
+
+def footprint_table():
+    xs = np.linspace(X_REAR, X_FRONT, 12)
+    ys = np.linspace(-HALF_W, HALF_W, 7)[1:-1]
+    pts = [(x, -HALF_W) for x in xs] + [(x, HALF_W) for x in xs]
+    pts += [(X_REAR, y) for y in ys] + [(X_FRONT, y) for y in ys]
+    return np.asarray(pts, np.float64).astype(f32)
+
+
+# ----------------------------------------------------------------------------- fp32 math
+_TWO_OVER_PI = f32(0.636619772367581343)
+_PIO2_1 = f32(1.5703125)
+_PIO2_2 = f32(4.837512969970703125e-4)
+_PIO2_3 = f32(7.54978995489188216e-8)
+_S1, _S2, _S3 = f32(-1.6666654611e-1), f32(8.3321608736e-3), f32(-1.9515295891e-4)
+_C1, _C2, _C3 = f32(4.166664568298827e-2), f32(-1.388731625493765e-3), f32(2.443315711809948e-5)
+
+
+def clamp32(d, lo, hi):
+    """lo if d < lo, hi if d > hi, else d - spelled with selects so signed zeros are defined."""
+    return np.where(d < lo, lo, np.where(d > hi, hi, d)).astype(f32)
+
+
+def sincos32(a):
+    """(sin, cos) of float32 angles |a| <= ~2*pi, mul/add only (Cody-Waite + cephes sinf/cosf)."""
+    a = np.asarray(a, f32)
+    kf = np.rint(a * _TWO_OVER_PI)
+    r = ((a - kf * _PIO2_1) - kf * _PIO2_2) - kf * _PIO2_3
+    q = kf.astype(i32) & 3
+    z = r * r
+    s = r + (r * z) * (_S1 + z * (_S2 + z * _S3))
+    c = (f32(1.0) - f32(0.5) * z) + (z * z) * (_C1 + z * (_C2 + z * _C3))
+    sin = np.where(q == 0, s, np.where(q == 1, c, np.where(q == 2, -s, -c)))
+    cos = np.where(q == 0, c, np.where(q == 1, -s, np.where(q == 2, -c, s)))
+    return sin.astype(f32), cos.astype(f32)
+
+
+_LOG2E = f32(1.44269504088896341)
+_LN2_1 = f32(0.693359375)
+_LN2_2 = f32(-2.12194440e-4)
+_E = [f32(1.9875691500e-4), f32(1.3981999507e-3), f32(8.3334519073e-3),
+      f32(4.1665795894e-2), f32(1.6666665459e-1), f32(5.0000001201e-1)]
+
+
+def exp32(x):
+    """float32 exp, mul/add only (cephes expf), argument clamped to [-80, 80]."""
+    x = clamp32(np.asarray(x, f32), f32(-80.0), f32(80.0))
+    kf = np.rint(x * _LOG2E)
+    r = (x - kf * _LN2_1) - kf * _LN2_2
+    z = r * r
+    p = _E[0]
+    for c in _E[1:]:
+        p = p * r + c
+    y = (p * z + r) + f32(1.0)
+    scale = ((kf.astype(i32) + 127) << 23).astype(i32).view(f32)
+    return (y * scale).astype(f32)
+
+
+# ----------------------------------------------------------------------------- Philox4x32-10
+_PM0, _PM1 = u64(0xD2511F53), u64(0xCD9E8D57)
+_PW0, _PW1 = 0x9E3779B9, 0xBB67AE85
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123).  All inputs broadcastable uint32."""
+    c0, c1, c2, c3 = (np.asarray(c, u32).astype(u64) for c in np.broadcast_arrays(c0, c1, c2, c3))
+    k0 = int(k0) & 0xFFFFFFFF
+    k1 = int(k1) & 0xFFFFFFFF
+    m32 = u64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = _PM0 * c0
+        p1 = _PM1 * c2
+        hi0, lo0 = p0 >> u64(32), p0 & m32
+        hi1, lo1 = p1 >> u64(32), p1 & m32
+        c0, c1, c2, c3 = hi1 ^ c1 ^ u64(k0), lo1, hi0 ^ c3 ^ u64(k1), lo0
+        k0 = (k0 + _PW0) & 0xFFFFFFFF
+        k1 = (k1 + _PW1) & 0xFFFFFFFF
+    return c0.astype(u32), c1.astype(u32), c2.astype(u32), c3.astype(u32)
+
+
+def random_actions(seed, step, n_cars, first_car=0):
+    """U(-1,1)^2 actions keyed by (seed, step, global car id): float32 [n_cars, 2]."""
+    car = np.arange(first_car, first_car + n_cars, dtype=np.uint64).astype(u32)
+    r0, r1, _, _ = philox4x32(car, u32(step), u32(1), u32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = np.stack([(r >> u32(8)).astype(f32) * f32(2.0 ** -24) for r in (r0, r1)], axis=1)
+    return (u * f32(2.0) - f32(1.0)).astype(f32)
+
+
+# ----------------------------------------------------------------------------- the env
+class OracleConfig:
+    def __init__(self, num_envs=1, cars_per_env=1, laps=10, time_limit=180.0,
+                 terminate_on_collision=True, collision_reward=-1.0, task=TASK_MAX_PROGRESS,
+                 remap_actions=False, action_low=(0.005, -1.0), action_high=(1.0, 1.0),
+                 time_limit_steps=0, auto_reset=False, first_env=0, render_occupancy=False):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+class OracleRaceEnv:
+    """Vectorised NumPy restatement of the env spec.  One track per instance."""
+
+    def __init__(self, occ, drivable, progress, centerline, origin, resolution, cfg: OracleConfig):
+        self.cfg = cfg
+        self.occ = np.asarray(occ, bool).copy()
+        # sentinel ring: the outermost cells of the grid end every ray with "no return" and count
+        # as wall for the footprint test, so the traversal needs no per-step bounds check
+        self.ring = np.zeros_like(self.occ)
+        self.ring[0, :] = self.ring[-1, :] = self.ring[:, 0] = self.ring[:, -1] = True
+        self.occ |= self.ring
+        self.drv = np.asarray(drivable, bool)
+        self.progress_grid = np.asarray(progress, f32)
+        self.centerline = np.asarray(centerline, f32)
+        self.H, self.W = self.occ.shape
+        self.org_x, self.org_y = f32(origin[0]), f32(origin[1])
+        self.res = f32(resolution)
+        self.inv_res = f32(1.0 / resolution)
+        self.tmax = MAX_RANGE * self.inv_res
+        self.B, self.A = cfg.num_envs, cfg.cars_per_env
+        n = self.NC = self.B * self.A
+        self.cb, self.sb = beam_table()
+        self.fp = footprint_table()
+        z = lambda dt: np.zeros(n, dt)
+        self.x, self.y, self.theta, self.ct, self.st = z(f32), z(f32), z(f32), z(f32), z(f32)
+        self.v, self.delta, self.omega, self.accel = z(f32), z(f32), z(f32), z(f32)
+        self.progress, self.lap, self.cp = z(f32), z(i32), z(i32)
+        self.wall, self.opp, self.wrong_way = z(np.uint8), z(np.uint8), z(np.uint8)
+        self.done, self.truncated, self.fresh = z(np.uint8), z(np.uint8), z(np.uint8)
+        self.reward = z(f32)
+        self.action = np.zeros((n, 2), f32)
+        self.steps = np.zeros(self.B, i32)         # sub-steps since reset
+        self.agent_steps = np.zeros(self.B, i32)   # step() calls since reset
+        self.episode = np.zeros(self.B, u32)       # resets so far (Philox counter word 1)
+        self.needs_reset = np.ones(self.B, bool)
+        self.lidar = np.zeros((n, N_BEAMS), f32)
+        self.patch = np.zeros((n, PATCH, PATCH), np.uint8)
+        self.seed = 0
+        self.mode = RESET_GRID
+
+    # ------------------------------------------------------------------ helpers
+    def _cell(self, wx, wy):
+        gx = (wx - self.org_x) * self.inv_res
+        gy = (wy - self.org_y) * self.inv_res
+        return np.floor(gx).astype(i32), np.floor(gy).astype(i32)
+
+    def _lookup(self, grid, ix, iy, oob):
+        inb = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
+        out = np.full(ix.shape, oob, grid.dtype)
+        out[inb] = grid[iy[inb], ix[inb]]
+        return out
+
+    # ------------------------------------------------------------------ reset (H6)
+    def reset(self, mask=None, mode=RESET_GRID, seed=0):
+        self.seed, self.mode = int(seed), int(mode)
+        envs = np.arange(self.B) if mask is None else np.nonzero(np.asarray(mask).astype(bool))[0]
+        self._reset_envs(envs)
+        self._observe()
+        return self.outputs()
+
+    def _reset_envs(self, envs):
+        if envs.size == 0:
+            return
+        cfg, n_cl = self.cfg, len(self.centerline)
+        g = (envs + cfg.first_env).astype(np.uint64).astype(u32)
+        r0, _, _, _ = philox4x32(g, self.episode[envs], u32(0), u32(0),
+                                 self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+        self.episode[envs] += u32(1)
+        if self.mode == RESET_GRID:
+            idx0 = np.zeros(envs.size, np.int64)
+        else:
+            idx0 = ((r0.astype(u64) * u64(n_cl)) >> u64(32)).astype(np.int64)
+        for a in range(self.A):
+            cars = envs * self.A + a
+            idx = (idx0 - a * BALL_GAP_BINS) % n_cl
+            self.x[cars] = self.centerline[idx, 0]
+            self.y[cars] = self.centerline[idx, 1]
+            self.theta[cars] = self.centerline[idx, 2]
+            self.st[cars], self.ct[cars] = sincos32(self.theta[cars])
+            ix, iy = self._cell(self.x[cars], self.y[cars])
+            p = self._lookup(self.progress_grid, ix, iy, f32(-1.0))
+            p = np.where(p < f32(0.0), f32(0.0), p)
+            self.progress[cars] = p
+            self.cp[cars] = np.minimum((p * f32(N_CHECKPOINTS)).astype(i32), N_CHECKPOINTS - 1)
+            for arr in (self.v, self.delta, self.omega, self.accel, self.reward):
+                arr[cars] = f32(0.0)
+            for arr in (self.wall, self.opp, self.wrong_way, self.done, self.truncated):
+                arr[cars] = 0
+            self.lap[cars] = 1
+            self.fresh[cars] = 1
+            self.action[cars] = f32(0.0)
+        self.steps[envs] = 0
+        self.agent_steps[envs] = 0
+        self.needs_reset[envs] = False
+
+    # ------------------------------------------------------------------ dynamics (H2)
+    def _substep(self, envs, motor, steer):
+        """One dt for every car of `envs`.  motor/steer: float32 [len(envs), A]."""
+        A = self.A
+        for a in range(A):
+            c = envs * A + a
+            m, s = motor[:, a], steer[:, a]
+            v, delta, theta = self.v[c], self.delta[c], self.theta[c]
+            v_t = np.where(m >= f32(0.0), MAX_VEL, f32(0.0))
+            dv_max = (np.abs(m) * ACCEL_MAX) * DT
+            dv = clamp32(v_t - v, -dv_max, dv_max)
+            v = v + dv
+            dd = clamp32(s * MAX_STEER - delta, -STEER_STEP, STEER_STEP)
+            delta = delta + dd
+            sd, cd = sincos32(delta)
+            omega = (v / WHEELBASE) * (sd / cd)
+            self.x[c] = self.x[c] + (v * self.ct[c]) * DT
+            self.y[c] = self.y[c] + (v * self.st[c]) * DT
+            theta = theta + omega * DT
+            theta = np.where(theta > PI, theta - TWO_PI, theta)
+            theta = np.where(theta < -PI, theta + TWO_PI, theta)
+            self.theta[c] = theta
+            self.st[c], self.ct[c] = sincos32(theta)
+            self.v[c], self.delta[c], self.omega[c] = v, delta, omega
+            self.accel[c] = dv * INV_DT
+        self.steps[envs] += 1
+        # --- collisions (H5)
+        for a in range(A):
+            c = envs * A + a
+            hit = np.zeros(envs.size, bool)
+            x, y, ct, st = self.x[c], self.y[c], self.ct[c], self.st[c]
+            for fx, fy in self.fp:
+                wx = x + (fx * ct - fy * st)
+                wy = y + (fx * st + fy * ct)
+                ix, iy = self._cell(wx, wy)
+                hit |= self._lookup(self.occ, ix, iy, True)
+            self.wall[c] = hit
+            self.opp[c] = 0
+        for a in range(A):
+            for b in range(a + 1, A):
+                ca, cb_ = envs * A + a, envs * A + b
+                o = self._obb_overlap(ca, cb_)
+                self.opp[ca] |= o
+                self.opp[cb_] |= o
+        # --- progress / reward / done (H4, H15)
+        cfg = self.cfg
+        tlim = f32(cfg.time_limit)
+        time = self.steps[envs].astype(f32) * DT
+        for a in range(A):
+            c = envs * A + a
+            ix, iy = self._cell(self.x[c], self.y[c])
+            p_new = self._lookup(self.progress_grid, ix, iy, f32(-1.0))
+            p_old, lap_old, cp_old = self.progress[c], self.lap[c], self.cp[c]
+            valid = p_new >= f32(0.0)
+            p_new = np.where(valid, p_new, p_old)
+            cp_new = np.minimum((p_new * f32(N_CHECKPOINTS)).astype(i32), N_CHECKPOINTS - 1)
+            d = np.mod(cp_new - cp_old, N_CHECKPOINTS)
+            fwd = (d > 0) & (d <= N_CHECKPOINTS // 2)
+            bwd = d > N_CHECKPOINTS // 2
+            lap = lap_old + np.where(fwd & (cp_new < cp_old), 1, 0) - np.where(bwd & (cp_new > cp_old), 1, 0)
+            lap = lap.astype(i32)
+            self.wrong_way[c] = np.where(fwd, 0, np.where(bwd, 1, self.wrong_way[c]))
+            self.cp[c] = np.where(fwd | bwd, cp_new, cp_old)
+            self.lap[c], self.progress[c] = lap, p_new
+            collided = (self.wall[c] | self.opp[c]).astype(bool)
+            if cfg.task == TASK_MAX_PROGRESS:
+                delta = (lap - lap_old).astype(f32) + (p_new - p_old)
+                r = delta * PROGRESS_REWARD + np.where(collided, f32(cfg.collision_reward), f32(0.0))
+                done = (collided & bool(cfg.terminate_on_collision)) | (lap > cfg.laps) | (time > tlim)
+            else:  # baselines/racing/environment/tasks.py:6-18
+                r = np.where(self.wall[c].astype(bool), f32(-1.0), -exp32(np.abs(steer[:, a]) - self.v[c]))
+                done = np.zeros(envs.size, bool)
+            self.reward[c] = self.reward[c] + r.astype(f32)
+            self.done[c] = done
+
+    def _obb_overlap(self, ca, cb_):
+        cta, sta, ctb, stb = self.ct[ca], self.st[ca], self.ct[cb_], self.st[cb_]
+        ax = self.x[ca] + BOX_CX * cta
+        ay = self.y[ca] + BOX_CX * sta
+        bx = self.x[cb_] + BOX_CX * ctb
+        by = self.y[cb_] + BOX_CX * stb
+        dx, dy = bx - ax, by - ay
+        c = np.abs(cta * ctb + sta * stb)
+        s = np.abs(sta * ctb - cta * stb)
+        ra = BOX_HL + (BOX_HL * c + BOX_HW * s)      # projections on A's long axis (and B's)
+        rb = BOX_HW + (BOX_HL * s + BOX_HW * c)      # on the short axes
+        sep = np.abs(dx * cta + dy * sta) > ra
+        sep |= np.abs(dy * cta - dx * sta) > rb
+        sep |= np.abs(dx * ctb + dy * stb) > ra
+        sep |= np.abs(dy * ctb - dx * stb) > rb
+        return (~sep).astype(np.uint8)
+
+    # ------------------------------------------------------------------ step (H7-H10)
+    def step(self, actions, repeat=1):
+        cfg, A = self.cfg, self.A
+        actions = np.asarray(actions, f32).reshape(self.B, A, 2)
+        assert not self.needs_reset.any(), "Must reset environment."   # dreamer/wrappers.py:148
+        env_done = self.done.reshape(self.B, A).any(axis=1)
+        live = np.nonzero(~env_done)[0]
+        self.fresh[:] = 0
+        self.reward[:] = f32(0.0)
+        self.action[:] = actions.reshape(-1, 2)
+        a = actions[live]
+        if cfg.remap_actions:                                          # dreamer/wrappers.py:128-130
+            lo, hi = np.asarray(cfg.action_low, f32), np.asarray(cfg.action_high, f32)
+            a = ((a + f32(1.0)) * f32(0.5)) * (hi - lo) + lo
+        a = clamp32(a, f32(-1.0), f32(1.0))
+        motor, steer = a[..., 0], a[..., 1]
+        active = np.ones(live.size, bool)
+        for _ in range(repeat):                                        # dreamer/wrappers.py:107-116
+            if not active.any():
+                break
+            self._substep(live[active], motor[active], steer[active])
+            active &= ~self.done.reshape(self.B, A)[live].any(axis=1)
+        self.agent_steps[live] += 1
+        if cfg.time_limit_steps > 0:                                   # dreamer/wrappers.py:147-154
+            over = live[self.agent_steps[live] >= cfg.time_limit_steps]
+            oc = (over[:, None] * A + np.arange(A)[None, :]).ravel()
+            self.done[oc] = 1
+            self.truncated[oc] = 1
+        out = self._scalar_outputs()
+        if cfg.auto_reset:
+            self._reset_envs(np.nonzero(self.done.reshape(self.B, A).any(axis=1))[0])
+        self._observe()
+        out.update(self._obs_outputs())
+        return out
+
+    # ------------------------------------------------------------------ observations
+    def _observe(self):
+        self.lidar = self.raycast()
+        if self.cfg.render_occupancy:
+            self.patch = self.render_patch()
+
+    def raycast(self, chunk_cars=2048):
+        out = np.empty((self.NC, N_BEAMS), f32)
+        for c0 in range(0, self.NC, chunk_cars):
+            out[c0:c0 + chunk_cars] = self._raycast_cars(np.arange(c0, min(c0 + chunk_cars, self.NC)))
+        return out
+
+    def _raycast_cars(self, cars):
+        """LiDAR scan (H3): exact grid traversal, boundaries from integer cell indices."""
+        A, n = self.A, cars.size
+        ct, st = self.ct[cars][:, None], self.st[cars][:, None]
+        lx = self.x[cars][:, None] + LIDAR_X * ct
+        ly = self.y[cars][:, None] + LIDAR_X * st
+        dx = np.broadcast_to(ct * self.cb[None, :] - st * self.sb[None, :], (n, N_BEAMS)).ravel()
+        dy = np.broadcast_to(st * self.cb[None, :] + ct * self.sb[None, :], (n, N_BEAMS)).ravel()
+        gx = np.broadcast_to((lx - self.org_x) * self.inv_res, (n, N_BEAMS)).ravel()
+        gy = np.broadcast_to((ly - self.org_y) * self.inv_res, (n, N_BEAMS)).ravel()
+        ix, iy = np.floor(gx).astype(i32), np.floor(gy).astype(i32)
+        rng = np.full(n * N_BEAMS, MAX_RANGE, f32)
+        inb = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
+        start_hit = ~inb
+        start_hit[inb] = self.occ[iy[inb], ix[inb]]    # includes the sentinel ring
+        rng[start_hit] = f32(0.0)
+        with np.errstate(divide="ignore"):
+            idx = np.where(dx != 0, f32(1.0) / dx, f32(0.0)).astype(f32)
+            idy = np.where(dy != 0, f32(1.0) / dy, f32(0.0)).astype(f32)
+        sx = np.where(dx > 0, 1, -1).astype(i32)
+        sy = np.where(dy > 0, 1, -1).astype(i32)
+        bx = (ix + (dx > 0)).astype(f32)
+        by = (iy + (dy > 0)).astype(f32)
+        tx = np.where(dx != 0, (bx - gx) * idx, INF).astype(f32)
+        ty = np.where(dy != 0, (by - gy) * idy, INF).astype(f32)
+        act = np.nonzero(~start_hit)[0]
+        while act.size:
+            txa, tya = tx[act], ty[act]
+            stepx = txa < tya
+            t = np.where(stepx, txa, tya)
+            over = t >= self.tmax                      # no return within 15 m
+            keep = ~over
+            act, stepx, t = act[keep], stepx[keep], t[keep]
+            ax, ay = act[stepx], act[~stepx]
+            ix[ax] += sx[ax]
+            bx[ax] += sx[ax].astype(f32)
+            tx[ax] = (bx[ax] - gx[ax]) * idx[ax]
+            iy[ay] += sy[ay]
+            by[ay] += sy[ay].astype(f32)
+            ty[ay] = (by[ay] - gy[ay]) * idy[ay]
+            cx, cy = ix[act], iy[act]
+            stop = self.occ[cy, cx]                    # wall or sentinel ring (never out of bounds)
+            hit = stop & ~self.ring[cy, cx]            # the ring itself gives no return
+            rng[act[hit]] = t[hit] * self.res
+            act = act[~stop]
+        rng = rng.reshape(n, N_BEAMS)
+        if A > 1:                                      # inter-car returns (H18)
+            env = cars // A
+            for other in range(A):
+                oc = env * A + other
+                tcar = self._ray_vs_car(lx, ly, dx.reshape(n, N_BEAMS), dy.reshape(n, N_BEAMS), oc)
+                tcar = np.where((oc != cars)[:, None], tcar, INF)
+                rng = np.where(tcar < rng, tcar, rng)
+        return rng.astype(f32)
+
+    def _ray_vs_car(self, lx, ly, dx, dy, oc):
+        """Distance [m] along each ray to car `oc`'s rectangle (slab test in its body frame)."""
+        ct2, st2 = self.ct[oc][:, None], self.st[oc][:, None]
+        cx = self.x[oc][:, None] + BOX_CX * ct2
+        cy = self.y[oc][:, None] + BOX_CX * st2
+        rx, ry = lx - cx, ly - cy
+        px = rx * ct2 + ry * st2
+        py = ry * ct2 - rx * st2
+        ex = dx * ct2 + dy * st2
+        ey = dy * ct2 - dx * st2
+        tn = np.full(dx.shape, -INF, f32)
+        tf = np.full(dx.shape, INF, f32)
+        miss = np.zeros(dx.shape, bool)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            for p, e, h in ((px, ex, BOX_HL), (py, ey, BOX_HW)):
+                p = np.broadcast_to(p, dx.shape)
+                par = e == 0
+                inv = np.where(par, f32(0.0), f32(1.0) / np.where(par, f32(1.0), e)).astype(f32)
+                t1 = (-h - p) * inv
+                t2 = (h - p) * inv
+                lo, hi = np.where(t1 < t2, t1, t2), np.where(t1 < t2, t2, t1)
+                tn = np.where(par, tn, np.where(lo > tn, lo, tn))
+                tf = np.where(par, tf, np.where(hi < tf, hi, tf))
+                miss |= par & (np.abs(p) > h)
+        hit = ~miss & (tn <= tf) & (tf >= f32(0.0))
+        t = np.where(tn > f32(0.0), tn, f32(0.0))
+        return np.where(hit & (t < MAX_RANGE), t, INF).astype(f32)
+
+    def render_patch(self, cars=None):
+        """lidar_occupancy (H11): ego-aligned 64x64, heading = +col, 1 = drivable."""
+        cars = np.arange(self.NC) if cars is None else cars
+        S = PATCH_TAPS
+        sub = ((np.arange(PATCH * S, dtype=np.float64) + 0.5) / S - PATCH / 2).astype(f32)
+        xb = (sub * PATCH_PX)[None, None, :]                  # forward  -> columns
+        yb = (-(sub * PATCH_PX))[None, :, None]               # left     -> rows (row 0 = left-most)
+        out = np.zeros((cars.size, PATCH, PATCH), np.uint8)
+        for k0 in range(0, cars.size, 256):
+            c = cars[k0:k0 + 256]
+            ct, st = self.ct[c][:, None, None], self.st[c][:, None, None]
+            wx = self.x[c][:, None, None] + (xb * ct - yb * st)
+            wy = self.y[c][:, None, None] + (xb * st + yb * ct)
+            ix, iy = self._cell(wx, wy)
+            v = self._lookup(self.drv, ix, iy, False)
+            cnt = v.reshape(c.size, PATCH, S, PATCH, S).sum(axis=(2, 4))
+            img = (cnt * 2 >= S * S).astype(np.uint8)
+            img[self.fresh[c].astype(bool)] = 0               # dreamer/wrappers.py:413
+            out[k0:k0 + 256] = img
+        return out
+
+    # ------------------------------------------------------------------ outputs
+    def _scalar_outputs(self):
+        """Per-step results of the step that just ran (terminal values if the env finished)."""
+        env_of = np.arange(self.NC) // self.A
+        return dict(
+            action=self.action.copy(), reward=self.reward.copy(),
+            discount=(f32(1.0) - self.done.astype(f32)),
+            progress_total=((self.lap - 1).astype(f32) + self.progress),
+            time=self.steps[env_of].astype(f32) * DT,
+            progress=self.progress.copy(), lap=self.lap.copy(), checkpoint=self.cp.copy(),
+            done=self.done.copy(), truncated=self.truncated.copy(), wall_collision=self.wall.copy(),
+            opponent_collision=self.opp.copy(), wrong_way=self.wrong_way.copy(),
+        )
+
+    def _obs_outputs(self):
+        """Observation of the current state (after the auto-reset, if one happened)."""
+        n = self.NC
+        pose = np.zeros((n, 6), f32)
+        vel = np.zeros((n, 6), f32)
+        pose[:, 0], pose[:, 1], pose[:, 5] = self.x, self.y, self.theta
+        vel[:, 0], vel[:, 5] = self.v, self.omega
+        d = dict(lidar=self.lidar.copy(), pose=pose, velocity=vel, speed=np.abs(self.v),
+                 acceleration=self.accel.copy(), steering_angle=self.delta.copy(), fresh=self.fresh.copy())
+        if self.cfg.render_occupancy:
+            d["lidar_occupancy"] = self.patch.copy()
+        return d
+
+    def outputs(self):
+        out = self._scalar_outputs()
+        out.update(self._obs_outputs())
+        return out

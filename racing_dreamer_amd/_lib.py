@@ -1,0 +1,98 @@
+"""ctypes binding of libracecar_hip.so (include/racecar_hip.h).
+
+There is no CPU fallback: if the library has not been built, importing the binding raises with
+the build command.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``python -m racing_dreamer_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LIB_DIR = os.path.join(os.path.dirname(__file__), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libracecar_hip.so")
+
+RC_N_BEAMS = 1080
+RC_PATCH = 64
+RC_MAX_CARS = 4
+
+# rc_field
+(F_LIDAR, F_POSE, F_VELOCITY, F_SPEED, F_ACTION, F_REWARD, F_DISCOUNT, F_PROGRESS_TOTAL, F_TIME, F_OCCUPANCY,
+ F_PROGRESS, F_LAP, F_CHECKPOINT, F_DONE, F_TRUNCATED, F_WALL_COLLISION, F_OPPONENT_COLLISION, F_WRONG_WAY,
+ F_FRESH, F_ACCELERATION, F_STEERING_ANGLE, F_ACTION_IN, F_COUNT) = range(23)
+
+K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_COUNT = range(6)
+KERNEL_NAMES = {K_DYNAMICS: "rc_dynamics_kernel", K_RAYCAST: "rc_raycast_kernel", K_PATCH: "rc_patch_kernel",
+                K_RESET: "rc_reset_kernel", K_ACTIONS: "rc_random_actions_kernel"}
+
+
+class RcConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("device", C.c_int32), ("num_envs", C.c_int32), ("cars_per_env", C.c_int32),
+        ("first_env", C.c_int64), ("obs_type", C.c_int32), ("task", C.c_int32), ("laps", C.c_int32),
+        ("time_limit", C.c_float), ("terminate_on_collision", C.c_int32), ("collision_reward", C.c_float),
+        ("remap_actions", C.c_int32), ("action_low", C.c_float * 2), ("action_high", C.c_float * 2),
+        ("time_limit_steps", C.c_int32), ("auto_reset", C.c_int32), ("external_arena", C.c_void_p),
+        ("external_arena_bytes", C.c_size_t), ("stream", C.c_void_p),
+    ]
+
+
+# every symbol include/racecar_hip.h declares: name -> (restype, argtypes)
+_P = C.POINTER
+SYMBOLS = {
+    "rc_default_config": (None, [_P(RcConfig)]),
+    "rc_arena_bytes": (C.c_size_t, [_P(RcConfig)]),
+    "rc_create": (C.c_int, [_P(RcConfig), _P(C.c_void_p)]),
+    "rc_destroy": (None, [C.c_void_p]),
+    "rc_load_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]),
+    "rc_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]),
+    "rc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "rc_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "rc_fill_random_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
+    "rc_get": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
+    "rc_copy_out": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "rc_trajectory_slab": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_size_t)]),
+    "rc_sync": (C.c_int, [C.c_void_p]),
+    "rc_stream": (C.c_void_p, [C.c_void_p]),
+    "rc_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rc_kernel_time": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_uint64)]),
+    "rc_reset_kernel_times": (C.c_int, [C.c_void_p]),
+    "rc_set_raycast_variant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rc_spec_tables": (None, [C.c_void_p, C.c_void_p]),
+    "rc_last_error": (C.c_char_p, []),
+    "rc_abi_version": (C.c_int, []),
+}
+
+
+class RacecarHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the HIP library and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RacecarHipError(
+            f"{path} not found: the HIP extension is not built. Run `python -m racing_dreamer_amd.build` "
+            "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.rc_abi_version() != 1:
+        raise RacecarHipError(f"ABI version mismatch: library reports {lib.rc_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        msg = load_library().rc_last_error()
+        raise RacecarHipError(f"libracecar_hip error {rc}: {msg.decode() if msg else '?'}")

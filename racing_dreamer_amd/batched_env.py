@@ -1,0 +1,203 @@
+"""BatchedRaceEnv: the Python host of the MI355X batched racing environment.
+
+Thin layer over the C-ABI (include/racecar_hip.h): torch allocates the output arena and the
+stream, the HIP library does all the work, and every output is a zero-copy torch view of the
+arena.  The surface mirrors what the reference's callers consume from racecar_gym
+(SURVEY.md §8b): ``reset(mode=...)`` / ``step(actions)`` returning ``lidar``, ``pose``,
+``velocity``, ``speed``, ``lidar_occupancy``, ``reward``, ``done`` and the info keys
+``progress``, ``lap``, ``time``, ``wrong_way``, ``wall_collision``
+(dreamer/wrappers.py:62-77,210-226; baselines/.../sb_experiment.py:82-88), batched over
+``num_envs x cars_per_env``.
+
+The returned tensors are views of buffers that the next step()/reset() overwrites; clone what
+must be kept.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Union
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import spec
+from .track_assets import Track, load_track
+
+_FIELD_VIEWS = {
+    # name: (field id, torch dtype, trailing shape)
+    "lidar": (L.F_LIDAR, torch.float32, (L.RC_N_BEAMS,)),
+    "pose": (L.F_POSE, torch.float32, (6,)),
+    "velocity": (L.F_VELOCITY, torch.float32, (6,)),
+    "speed": (L.F_SPEED, torch.float32, ()),
+    "action": (L.F_ACTION, torch.float32, (2,)),
+    "reward": (L.F_REWARD, torch.float32, ()),
+    "discount": (L.F_DISCOUNT, torch.float32, ()),
+    "progress_total": (L.F_PROGRESS_TOTAL, torch.float32, ()),
+    "time": (L.F_TIME, torch.float32, ()),
+    "lidar_occupancy": (L.F_OCCUPANCY, torch.uint8, (L.RC_PATCH, L.RC_PATCH, 1)),
+    "progress": (L.F_PROGRESS, torch.float32, ()),
+    "lap": (L.F_LAP, torch.int32, ()),
+    "checkpoint": (L.F_CHECKPOINT, torch.int32, ()),
+    "done": (L.F_DONE, torch.uint8, ()),
+    "truncated": (L.F_TRUNCATED, torch.uint8, ()),
+    "wall_collision": (L.F_WALL_COLLISION, torch.uint8, ()),
+    "opponent_collision": (L.F_OPPONENT_COLLISION, torch.uint8, ()),
+    "wrong_way": (L.F_WRONG_WAY, torch.uint8, ()),
+    "fresh": (L.F_FRESH, torch.uint8, ()),
+    "acceleration": (L.F_ACCELERATION, torch.float32, ()),
+    "steering_angle": (L.F_STEERING_ANGLE, torch.float32, ()),
+    "action_in": (L.F_ACTION_IN, torch.float32, (2,)),
+}
+
+OBS_TYPES = {"lidar": 0, "lidar_occupancy": 1}
+TASKS = {"maximize_progress": spec.TASK_MAX_PROGRESS, "max_progress": spec.TASK_MAX_PROGRESS,
+         "max_speed": spec.TASK_MAX_SPEED}
+
+
+class BatchedRaceEnv:
+    def __init__(self, track: Union[str, Track], num_envs: int, cars_per_env: int = 1, obs_type: str = "lidar",
+                 action_repeat: int = 1, seed: int = 0, device: int = 0, first_env: int = 0,
+                 task: str = "maximize_progress", laps: int = 10, time_limit: float = 180.0,
+                 terminate_on_collision: bool = True, collision_reward: float = -1.0,
+                 remap_actions: bool = False, action_low=spec.ACTION_LOW, action_high=spec.ACTION_HIGH,
+                 time_limit_steps: int = 0, auto_reset: bool = False, profiling: bool = False):
+        if obs_type not in OBS_TYPES:
+            raise ValueError(f"obs_type must be one of {sorted(OBS_TYPES)}, got {obs_type!r}")
+        if task not in TASKS:
+            raise ValueError(f"task must be one of {sorted(TASKS)}, got {task!r}")
+        self._lib = L.load_library()                     # raises if the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise L.RacecarHipError("no HIP device visible to torch; BatchedRaceEnv has no CPU fallback")
+        self.track = load_track(track) if isinstance(track, str) else track
+        self.num_envs, self.cars_per_env = int(num_envs), int(cars_per_env)
+        self.n_cars = self.num_envs * self.cars_per_env
+        self.obs_type, self.action_repeat, self.seed = obs_type, int(action_repeat), int(seed)
+        self.device = torch.device("cuda", device)
+        self.first_env = int(first_env)
+
+        cfg = L.RcConfig()
+        self._lib.rc_default_config(C.byref(cfg))
+        cfg.device, cfg.num_envs, cfg.cars_per_env, cfg.first_env = device, self.num_envs, self.cars_per_env, first_env
+        cfg.obs_type, cfg.task, cfg.laps, cfg.time_limit = OBS_TYPES[obs_type], TASKS[task], laps, time_limit
+        cfg.terminate_on_collision, cfg.collision_reward = int(terminate_on_collision), collision_reward
+        cfg.remap_actions = int(remap_actions)
+        cfg.action_low[:] = [float(v) for v in action_low]
+        cfg.action_high[:] = [float(v) for v in action_high]
+        cfg.time_limit_steps, cfg.auto_reset = int(time_limit_steps), int(auto_reset)
+        nbytes = self._lib.rc_arena_bytes(C.byref(cfg))
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
+            self.stream = torch.cuda.Stream(device=self.device)
+        pad = (-self.arena.data_ptr()) % 64
+        self._arena_view = self.arena[pad:pad + nbytes]
+        cfg.external_arena = self._arena_view.data_ptr()
+        cfg.external_arena_bytes = nbytes
+        cfg.stream = self.stream.cuda_stream
+        self._cfg = cfg
+        self._h = C.c_void_p()
+        L.check(self._lib.rc_create(C.byref(cfg), C.byref(self._h)))
+        self._load_track(self.track)
+        self.views: Dict[str, torch.Tensor] = {}
+        base = self._arena_view.data_ptr()
+        for name, (fid, dtype, tail) in _FIELD_VIEWS.items():
+            if fid == L.F_OCCUPANCY and obs_type != "lidar_occupancy":
+                continue
+            ptr, nb = C.c_void_p(), C.c_size_t()
+            L.check(self._lib.rc_get(self._h, fid, C.byref(ptr), C.byref(nb)))
+            off = ptr.value - base
+            t = self._arena_view[off:off + nb.value].view(dtype)
+            self.views[name] = t.view(self.num_envs, self.cars_per_env, *tail)
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.rc_trajectory_slab(self._h, C.byref(ptr), C.byref(nb)))
+        self.slab = self._arena_view[ptr.value - base:ptr.value - base + nb.value]
+        if profiling:
+            self.set_profiling(True)
+
+    # ------------------------------------------------------------------ plumbing
+    def _load_track(self, t: Track) -> None:
+        occ = np.ascontiguousarray(t.occ_words, np.uint32)
+        drv = np.ascontiguousarray(t.drv_words, np.uint32)
+        prog = np.ascontiguousarray(t.progress, np.float32)
+        cl = np.ascontiguousarray(t.centerline, np.float32)
+        L.check(self._lib.rc_load_track(
+            self._h, occ.ctypes.data, drv.ctypes.data, prog.ctypes.data, t.height, t.width, t.pitch,
+            np.float32(t.resolution), np.float32(t.origin[0]), np.float32(t.origin[1]), cl.ctypes.data, len(cl)))
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self) -> None:
+        L.check(self._lib.rc_sync(self._h))
+
+    def _enter(self) -> None:
+        # order the env's stream after whatever produced the actions on torch's current stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+
+    def _exit(self) -> None:
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    # ------------------------------------------------------------------ env API
+    def reset(self, mask: Optional[Union[np.ndarray, torch.Tensor]] = None, mode: str = "grid",
+              seed: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        if mode not in spec.RESET_MODES:
+            raise ValueError(f"reset mode must be one of {sorted(spec.RESET_MODES)}, got {mode!r}")
+        if seed is not None:
+            self.seed = int(seed)
+        mptr = None
+        if mask is not None:
+            m = np.ascontiguousarray(torch.as_tensor(mask).cpu().numpy().astype(np.uint8).reshape(self.num_envs))
+            mptr = m.ctypes.data
+        self._enter()
+        L.check(self._lib.rc_reset(self._h, mptr, spec.RESET_MODES[mode], C.c_uint64(self.seed)))
+        self._exit()
+        return self.views
+
+    def step(self, actions: Optional[torch.Tensor] = None, repeat: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """One agent step.  ``actions``: float32 [num_envs, cars_per_env, 2] = (motor, steering) on the
+        env's device, or None to use the device-side ``action_in`` buffer."""
+        repeat = self.action_repeat if repeat is None else int(repeat)
+        ptr = None
+        if actions is not None:
+            if actions.device != self.device:
+                actions = actions.to(self.device, non_blocking=True)
+            actions = actions.to(torch.float32).contiguous()
+            if actions.numel() != self.n_cars * 2:
+                raise ValueError(f"actions must hold {self.n_cars} x 2 values, got shape {tuple(actions.shape)}")
+            ptr = actions.data_ptr()
+        self._enter()
+        L.check(self._lib.rc_step(self._h, ptr, repeat))
+        self._exit()
+        return self.views
+
+    def fill_random_actions(self, seed: int, step: int) -> None:
+        L.check(self._lib.rc_fill_random_actions(self._h, C.c_uint64(seed), C.c_uint32(step)))
+
+    # ------------------------------------------------------------------ profiling
+    def set_profiling(self, on: bool) -> None:
+        L.check(self._lib.rc_set_profiling(self._h, int(on)))
+
+    def reset_kernel_times(self) -> None:
+        L.check(self._lib.rc_reset_kernel_times(self._h))
+
+    def kernel_times(self) -> Dict[str, Dict[str, float]]:
+        out = {}
+        for k, name in L.KERNEL_NAMES.items():
+            ms, n = C.c_double(), C.c_uint64()
+            L.check(self._lib.rc_kernel_time(self._h, k, C.byref(ms), C.byref(n)))
+            out[name] = {"total_ms": ms.value, "launches": int(n.value),
+                         "avg_ms": ms.value / n.value if n.value else 0.0}
+        return out
+
+    def host(self, name: str) -> np.ndarray:
+        """Synchronised host copy of one output field."""
+        self.sync()
+        return self.views[name].cpu().numpy()

@@ -1,0 +1,541 @@
+// C-ABI of libracecar_hip.so (declared in include/racecar_hip.h): handle, device buffers,
+// stream-ordered launches.  No exceptions cross the boundary; errors are codes + rc_last_error().
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/racecar_hip.h"
+#include "racecar_internal.h"
+#include "racecar_spec.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(RC_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct FieldInfo {
+    size_t elem_bytes;   // bytes per car
+};
+
+// bytes per car of every rc_field, in arena order
+const size_t kFieldBytes[RC_F_COUNT] = {
+    RC_N_BEAMS * 4, 24, 24, 4, 8, 4, 4, 4, 4, RC_PATCH * RC_PATCH,   // LIDAR .. OCCUPANCY
+    4, 4, 4, 1, 1, 1, 1, 1, 1, 4, 4, 8,                               // PROGRESS .. ACTION_IN
+};
+
+struct Layout {
+    size_t offset[RC_F_COUNT];
+    size_t bytes[RC_F_COUNT];
+    size_t slab_bytes;   // LIDAR..TIME (+OCCUPANCY when rendered)
+    size_t total;
+};
+
+Layout make_layout(int n_cars, bool occupancy) {
+    Layout l{};
+    size_t off = 0;
+    for (int f = 0; f < RC_F_COUNT; ++f) {
+        size_t b = kFieldBytes[f] * (size_t)n_cars;
+        if (f == RC_F_OCCUPANCY && !occupancy) b = 0;
+        l.offset[f] = off;
+        l.bytes[f] = b;
+        off = align_up(off + b, 64);
+        if (f == (occupancy ? RC_F_OCCUPANCY : RC_F_TIME)) l.slab_bytes = l.offset[f] + b;
+    }
+    l.total = off;
+    return l;
+}
+
+struct EventPair {
+    hipEvent_t a, b;
+    int kernel;
+};
+
+}  // namespace
+
+struct rc_env {
+    rc_config cfg{};
+    int n_cars = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device memory
+    void *arena = nullptr;
+    bool own_arena = false;
+    Layout layout{};
+    void *state_mem = nullptr;
+    void *track_mem = nullptr;
+    uint8_t *mask_dev = nullptr;
+    float *actions_in = nullptr;   // inside the arena (RC_F_ACTION_IN)
+    RcParams params{};
+    RcLaunchInfo launch{};
+    bool has_track = false;
+    bool was_reset = false;
+    // profiling
+    bool profiling = false;
+    std::vector<EventPair> pending;
+    std::vector<EventPair> free_events;
+    double k_ms[RC_K_COUNT] = {0};
+    uint64_t k_n[RC_K_COUNT] = {0};
+};
+
+namespace {
+
+int drain_events(rc_env *env) {
+    if (env->pending.empty()) return RC_OK;
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    for (EventPair &ep : env->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, ep.a, ep.b));
+        env->k_ms[ep.kernel] += ms;
+        env->k_n[ep.kernel] += 1;
+        env->free_events.push_back(ep);
+    }
+    env->pending.clear();
+    return RC_OK;
+}
+
+struct KernelTimer {
+    rc_env *env;
+    EventPair ep{};
+    bool on = false;
+    int begin(rc_env *e, int kernel) {
+        env = e;
+        if (!e->profiling) return RC_OK;
+        if (e->pending.size() >= 4096) {
+            int rc = drain_events(e);
+            if (rc) return rc;
+        }
+        if (!e->free_events.empty()) {
+            ep = e->free_events.back();
+            e->free_events.pop_back();
+        } else {
+            HIP_TRY(hipEventCreate(&ep.a));
+            HIP_TRY(hipEventCreate(&ep.b));
+        }
+        ep.kernel = kernel;
+        HIP_TRY(hipEventRecord(ep.a, e->stream));
+        on = true;
+        return RC_OK;
+    }
+    int end() {
+        if (!on) return RC_OK;
+        HIP_TRY(hipEventRecord(ep.b, env->stream));
+        env->pending.push_back(ep);
+        return RC_OK;
+    }
+};
+
+#define TIMED(env, kernel, launch_expr)                 \
+    do {                                                \
+        KernelTimer _t;                                 \
+        int _rc = _t.begin(env, kernel);                \
+        if (_rc) return _rc;                            \
+        HIP_TRY(launch_expr);                           \
+        _rc = _t.end();                                 \
+        if (_rc) return _rc;                            \
+    } while (0)
+
+int observe(rc_env *env) {
+    TIMED(env, RC_K_RAYCAST, rck_launch_raycast(env->params, env->launch, env->stream));
+    if (env->params.render_patch)
+        TIMED(env, RC_K_PATCH, rck_launch_patch(env->params, env->launch, env->stream));
+    return RC_OK;
+}
+
+int check_cfg(const rc_config *cfg) {
+    if (!cfg) return fail(RC_ERR_INVALID, "rc_config is NULL");
+    if (cfg->struct_size != sizeof(rc_config))
+        return fail(RC_ERR_INVALID, "rc_config.struct_size %u != %zu (ABI mismatch)", cfg->struct_size, sizeof(rc_config));
+    if (cfg->num_envs < 1) return fail(RC_ERR_INVALID, "num_envs must be >= 1 (got %d)", cfg->num_envs);
+    if (cfg->cars_per_env < 1 || cfg->cars_per_env > RC_MAX_CARS)
+        return fail(RC_ERR_INVALID, "cars_per_env must be in 1..%d (got %d)", RC_MAX_CARS, cfg->cars_per_env);
+    if ((int64_t)cfg->num_envs * cfg->cars_per_env * RC_N_BEAMS > 0x7fffffffLL)
+        return fail(RC_ERR_INVALID, "num_envs * cars_per_env * 1080 must fit int32");
+    if (cfg->obs_type != RC_OBS_LIDAR && cfg->obs_type != RC_OBS_LIDAR_OCCUPANCY)
+        return fail(RC_ERR_INVALID, "unknown obs_type %d", cfg->obs_type);
+    if (cfg->task != RC_TASK_MAX_PROGRESS && cfg->task != RC_TASK_MAX_SPEED)
+        return fail(RC_ERR_INVALID, "unknown task %d", cfg->task);
+    return RC_OK;
+}
+
+}  // namespace
+
+namespace {
+void make_tables(float *beams, float *foot) {
+    // evaluated in double and rounded once, as spec.beam_table()/footprint_table() and the oracle do
+    const double kPi = 3.14159265358979323846;
+    const double half = (270.0 * kPi / 180.0) / 2.0;
+    for (int i = 0; i < RC_N_BEAMS; ++i) {
+        const double ang = half - (double)i * (2.0 * half / (RC_N_BEAMS - 1));
+        beams[2 * i] = (float)std::cos(ang);
+        beams[2 * i + 1] = (float)std::sin(ang);
+    }
+    const double xr = -0.10, xf = 0.45, hw = 0.15;
+    int k = 0;
+    auto lin = [](double a, double b, int n, int i) {   // numpy.linspace
+        const double step = (b - a) / (n - 1);
+        return i == n - 1 ? b : a + i * step;
+    };
+    for (int i = 0; i < 12; ++i) { foot[2 * k] = (float)lin(xr, xf, 12, i); foot[2 * k + 1] = (float)-hw; ++k; }
+    for (int i = 0; i < 12; ++i) { foot[2 * k] = (float)lin(xr, xf, 12, i); foot[2 * k + 1] = (float)hw; ++k; }
+    for (int i = 1; i < 6; ++i) { foot[2 * k] = (float)xr; foot[2 * k + 1] = (float)lin(-hw, hw, 7, i); ++k; }
+    for (int i = 1; i < 6; ++i) { foot[2 * k] = (float)xf; foot[2 * k + 1] = (float)lin(-hw, hw, 7, i); ++k; }
+}
+}  // namespace
+
+extern "C" {
+
+void rc_spec_tables(float *beams_1080x2, float *footprint_34x2) {
+    if (beams_1080x2 && footprint_34x2) make_tables(beams_1080x2, footprint_34x2);
+}
+
+const char *rc_last_error(void) { return g_last_error.c_str(); }
+int rc_abi_version(void) { return RC_ABI_VERSION; }
+
+void rc_default_config(rc_config *cfg) {
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(rc_config);
+    cfg->num_envs = 1;
+    cfg->cars_per_env = 1;
+    cfg->obs_type = RC_OBS_LIDAR;
+    cfg->task = RC_TASK_MAX_PROGRESS;
+    cfg->laps = 10;                      // dreamer/scenarios/max_progress/columbia.yml:10
+    cfg->time_limit = 180.0f;
+    cfg->terminate_on_collision = 1;
+    cfg->collision_reward = -1.0f;
+    cfg->remap_actions = 0;
+    cfg->action_low[0] = 0.005f;         // dreamer/dream.py:138
+    cfg->action_low[1] = -1.0f;
+    cfg->action_high[0] = 1.0f;
+    cfg->action_high[1] = 1.0f;
+}
+
+size_t rc_arena_bytes(const rc_config *cfg) {
+    if (!cfg || cfg->num_envs < 1 || cfg->cars_per_env < 1) return 0;
+    return make_layout(cfg->num_envs * cfg->cars_per_env, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY).total;
+}
+
+int rc_create(const rc_config *cfg, rc_env **out) {
+    if (!out) return fail(RC_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(RC_ERR_INVALID, "device %d out of range (%d HIP devices visible)", cfg->device, ndev);
+    HIP_TRY(hipSetDevice(cfg->device));
+    rc_env *env = new (std::nothrow) rc_env();
+    if (!env) return fail(RC_ERR_NOMEM, "out of host memory");
+    env->cfg = *cfg;
+    const int n = env->n_cars = cfg->num_envs * cfg->cars_per_env;
+    const bool occ = cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY;
+    env->layout = make_layout(n, occ);
+#define FAIL_FREE(code_expr) do { int _c = (code_expr); rc_destroy(env); return _c; } while (0)
+#define HIP_TRY_FREE(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) FAIL_FREE(fail(RC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
+    if (cfg->stream) {
+        env->stream = (hipStream_t)cfg->stream;
+    } else {
+        HIP_TRY_FREE(hipStreamCreateWithFlags(&env->stream, hipStreamNonBlocking));
+        env->own_stream = true;
+    }
+    if (cfg->external_arena) {
+        if (cfg->external_arena_bytes < env->layout.total)
+            FAIL_FREE(fail(RC_ERR_INVALID, "external arena too small: %zu < %zu", cfg->external_arena_bytes, env->layout.total));
+        if ((uintptr_t)cfg->external_arena % 64)
+            FAIL_FREE(fail(RC_ERR_INVALID, "external arena must be 64-byte aligned"));
+        env->arena = cfg->external_arena;
+    } else {
+        HIP_TRY_FREE(hipMalloc(&env->arena, env->layout.total));
+        env->own_arena = true;
+    }
+    HIP_TRY_FREE(hipMemsetAsync(env->arena, 0, env->layout.total, env->stream));
+
+    // simulator state: 10 float + 2 int + 6 byte arrays per car, 2 int + 1 uint per env
+    const size_t nc = (size_t)align_up(n, 64), ne = (size_t)align_up(cfg->num_envs, 64);
+    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6) + ne * 12;
+    HIP_TRY_FREE(hipMalloc(&env->state_mem, state_bytes));
+    HIP_TRY_FREE(hipMemsetAsync(env->state_mem, 0, state_bytes, env->stream));
+    HIP_TRY_FREE(hipMalloc((void **)&env->mask_dev, ne));
+    {
+        char *m = (char *)env->state_mem;
+        RcStateDev &s = env->params.st;
+        float **fp[] = {&s.x, &s.y, &s.theta, &s.ct, &s.st, &s.v, &s.delta, &s.omega, &s.accel, &s.progress};
+        for (float **f : fp) { *f = (float *)m; m += nc * 4; }
+        s.lap = (int32_t *)m; m += nc * 4;
+        s.cp = (int32_t *)m; m += nc * 4;
+        s.steps = (int32_t *)m; m += ne * 4;
+        s.agent_steps = (int32_t *)m; m += ne * 4;
+        s.episode = (uint32_t *)m; m += ne * 4;
+        uint8_t **bp[] = {&s.wall, &s.opp, &s.wrong, &s.done, &s.trunc, &s.fresh};
+        for (uint8_t **b : bp) { *b = (uint8_t *)m; m += nc; }
+    }
+    {
+        char *a = (char *)env->arena;
+        const Layout &l = env->layout;
+        RcOutDev &o = env->params.out;
+        o.lidar = (float *)(a + l.offset[RC_F_LIDAR]);
+        o.pose = (float *)(a + l.offset[RC_F_POSE]);
+        o.velocity = (float *)(a + l.offset[RC_F_VELOCITY]);
+        o.speed = (float *)(a + l.offset[RC_F_SPEED]);
+        o.action = (float *)(a + l.offset[RC_F_ACTION]);
+        o.reward = (float *)(a + l.offset[RC_F_REWARD]);
+        o.discount = (float *)(a + l.offset[RC_F_DISCOUNT]);
+        o.progress_total = (float *)(a + l.offset[RC_F_PROGRESS_TOTAL]);
+        o.time = (float *)(a + l.offset[RC_F_TIME]);
+        o.patch = (uint8_t *)(a + l.offset[RC_F_OCCUPANCY]);
+        o.progress = (float *)(a + l.offset[RC_F_PROGRESS]);
+        o.lap = (int32_t *)(a + l.offset[RC_F_LAP]);
+        o.cp = (int32_t *)(a + l.offset[RC_F_CHECKPOINT]);
+        o.done = (uint8_t *)(a + l.offset[RC_F_DONE]);
+        o.trunc = (uint8_t *)(a + l.offset[RC_F_TRUNCATED]);
+        o.wall = (uint8_t *)(a + l.offset[RC_F_WALL_COLLISION]);
+        o.opp = (uint8_t *)(a + l.offset[RC_F_OPPONENT_COLLISION]);
+        o.wrong = (uint8_t *)(a + l.offset[RC_F_WRONG_WAY]);
+        o.fresh = (uint8_t *)(a + l.offset[RC_F_FRESH]);
+        o.accel = (float *)(a + l.offset[RC_F_ACCELERATION]);
+        o.steer = (float *)(a + l.offset[RC_F_STEERING_ANGLE]);
+        env->actions_in = (float *)(a + l.offset[RC_F_ACTION_IN]);
+    }
+    RcParams &p = env->params;
+    p.num_envs = cfg->num_envs;
+    p.cars_per_env = cfg->cars_per_env;
+    p.n_cars = n;
+    p.first_env = (uint32_t)(uint64_t)cfg->first_env;
+    p.task = cfg->task;
+    p.laps = cfg->laps;
+    p.terminate_on_collision = cfg->terminate_on_collision;
+    p.remap_actions = cfg->remap_actions;
+    p.time_limit_steps = cfg->time_limit_steps;
+    p.auto_reset = cfg->auto_reset;
+    p.render_patch = occ ? 1 : 0;
+    p.time_limit = cfg->time_limit;
+    p.collision_reward = cfg->collision_reward;
+    p.act_lo0 = cfg->action_low[0];
+    p.act_lo1 = cfg->action_low[1];
+    p.act_hi0 = cfg->action_high[0];
+    p.act_hi1 = cfg->action_high[1];
+    hipDeviceProp_t prop;
+    HIP_TRY_FREE(hipGetDeviceProperties(&prop, cfg->device));
+    env->launch.n_cu = prop.multiProcessorCount;
+    *out = env;
+    return RC_OK;
+}
+
+void rc_destroy(rc_env *env) {
+    if (!env) return;
+    if (env->stream) (void)hipStreamSynchronize(env->stream);
+    for (EventPair &ep : env->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    for (EventPair &ep : env->free_events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
+    if (env->own_arena && env->arena) (void)hipFree(env->arena);
+    if (env->state_mem) (void)hipFree(env->state_mem);
+    if (env->track_mem) (void)hipFree(env->track_mem);
+    if (env->mask_dev) (void)hipFree(env->mask_dev);
+    if (env->own_stream && env->stream) (void)hipStreamDestroy(env->stream);
+    delete env;
+}
+
+int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivable_words, const float *progress,
+                  int32_t h, int32_t w, int32_t pitch, float resolution, float origin_x, float origin_y,
+                  const float *centerline, int32_t n_centerline) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!occ_words || !drivable_words || !progress || !centerline) return fail(RC_ERR_INVALID, "NULL track array");
+    if (h < 3 || w < 3 || pitch * 32 < w) return fail(RC_ERR_INVALID, "bad track shape h=%d w=%d pitch=%d", h, w, pitch);
+    if (n_centerline < 1) return fail(RC_ERR_INVALID, "centerline table is empty");
+    if (!(resolution > 0.f)) return fail(RC_ERR_INVALID, "resolution must be > 0");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    const size_t nwords = (size_t)h * pitch;
+    const size_t bm_bytes = align_up(nwords * 4, 64);
+    if (bm_bytes > 160 * 1024)
+        return fail(RC_ERR_INVALID, "track bitmap %zu B does not fit the 160 KiB LDS", bm_bytes);
+    // occupancy with the sentinel ring set
+    std::vector<uint32_t> ray(bm_bytes / 4, 0u), drv(bm_bytes / 4, 0u);
+    std::memcpy(ray.data(), occ_words, nwords * 4);
+    std::memcpy(drv.data(), drivable_words, nwords * 4);
+    auto setbit = [&](int ix, int iy) { ray[(size_t)iy * pitch + (ix >> 5)] |= 1u << (ix & 31); };
+    for (int ix = 0; ix < w; ++ix) { setbit(ix, 0); setbit(ix, h - 1); }
+    for (int iy = 0; iy < h; ++iy) { setbit(0, iy); setbit(w - 1, iy); }
+    std::vector<float> beams(RC_N_BEAMS * 2), foot(RCS_N_FOOTPRINT * 2);
+    make_tables(beams.data(), foot.data());
+    const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
+    const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
+    const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
+    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes;
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    if (env->track_mem) { HIP_TRY(hipFree(env->track_mem)); env->track_mem = nullptr; }
+    HIP_TRY(hipMalloc(&env->track_mem, total));
+    char *m = (char *)env->track_mem;
+    RcTrackDev &t = env->params.trk;
+    HIP_TRY(hipMemcpy(m, ray.data(), bm_bytes, hipMemcpyHostToDevice)); t.ray_words = (const uint32_t *)m; m += bm_bytes;
+    HIP_TRY(hipMemcpy(m, drv.data(), bm_bytes, hipMemcpyHostToDevice)); t.drv_words = (const uint32_t *)m; m += bm_bytes;
+    HIP_TRY(hipMemcpy(m, progress, (size_t)h * w * 4, hipMemcpyHostToDevice)); t.progress = (const float *)m; m += prog_bytes;
+    HIP_TRY(hipMemcpy(m, centerline, (size_t)n_centerline * 16, hipMemcpyHostToDevice)); t.centerline = (const float *)m; m += cl_bytes;
+    HIP_TRY(hipMemcpy(m, beams.data(), beams.size() * 4, hipMemcpyHostToDevice)); t.beams = (const float *)m; m += beam_bytes;
+    HIP_TRY(hipMemcpy(m, foot.data(), foot.size() * 4, hipMemcpyHostToDevice)); t.footprint = (const float *)m; m += foot_bytes;
+    t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
+    t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
+    t.inv_res = 1.0f / resolution;
+    t.tmax = RCS_MAX_RANGE * t.inv_res;
+    // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
+    RcLaunchInfo &li = env->launch;
+    li.lds_bytes = bm_bytes;
+    li.ray_threads = 1024;
+    li.patch_threads = 1024;
+    int wg_per_cu = (int)((160 * 1024) / bm_bytes);
+    if (wg_per_cu > 2) wg_per_cu = 2;           // 2 x 1024 threads = 32 waves/CU, the hardware maximum
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    const long long rays = (long long)env->n_cars * RC_N_BEAMS;
+    const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 4);
+    const int max_blocks = li.n_cu * wg_per_cu;
+    li.ray_blocks = (int)std::min<long long>((rays + li.ray_threads - 1) / li.ray_threads, max_blocks);
+    li.patch_blocks = (int)std::min<long long>((quads + li.patch_threads - 1) / li.patch_threads, max_blocks);
+    HIP_TRY(rck_set_lds_limits(li.lds_bytes));
+    env->has_track = true;
+    env->was_reset = false;
+    return RC_OK;
+}
+
+int rc_reset(rc_env *env, const uint8_t *mask_or_null, int32_t mode, uint64_t seed) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_reset");
+    if (mode < RC_RESET_GRID || mode > RC_RESET_RANDOM_BALL) return fail(RC_ERR_INVALID, "unknown reset mode %d", mode);
+    if (mask_or_null && !env->was_reset) return fail(RC_ERR_INVALID, "the first rc_reset must reset every env (mask = NULL)");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    env->params.reset_mode = mode;
+    env->params.seed_lo = (uint32_t)(seed & 0xffffffffu);
+    env->params.seed_hi = (uint32_t)(seed >> 32);
+    const uint8_t *mask_dev = nullptr;
+    if (mask_or_null) {
+        HIP_TRY(hipMemcpyAsync(env->mask_dev, mask_or_null, (size_t)env->cfg.num_envs, hipMemcpyHostToDevice, env->stream));
+        // the host buffer may be pageable and reused by the caller right after we return
+        HIP_TRY(hipStreamSynchronize(env->stream));
+        mask_dev = env->mask_dev;
+    }
+    TIMED(env, RC_K_RESET, rck_launch_reset(env->params, mask_dev, env->stream));
+    env->was_reset = true;
+    return observe(env);
+}
+
+int rc_step(rc_env *env, const float *actions_dev, int32_t repeat) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_step");
+    if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+    if (repeat < 1) return fail(RC_ERR_INVALID, "repeat must be >= 1 (got %d)", repeat);
+    const float *act = actions_dev ? actions_dev : env->actions_in;
+    TIMED(env, RC_K_DYNAMICS, rck_launch_dynamics(env->params, act, repeat, env->stream));
+    return observe(env);
+}
+
+int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!actions_host) return fail(RC_ERR_INVALID, "actions_host is NULL");
+    HIP_TRY(hipMemcpyAsync(env->actions_in, actions_host, (size_t)env->n_cars * 8, hipMemcpyHostToDevice, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    return rc_step(env, nullptr, repeat);
+}
+
+int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    const uint32_t first_car = env->params.first_env * (uint32_t)env->cfg.cars_per_env;
+    TIMED(env, RC_K_ACTIONS, rck_launch_random_actions(env->actions_in, env->n_cars, first_car, (uint32_t)(seed & 0xffffffffu),
+                                                       (uint32_t)(seed >> 32), step, env->stream));
+    return RC_OK;
+}
+
+int rc_get(rc_env *env, int32_t field, void **dev_ptr, size_t *bytes) {
+    if (!env || !dev_ptr || !bytes) return fail(RC_ERR_INVALID, "NULL argument");
+    if (field < 0 || field >= RC_F_COUNT) return fail(RC_ERR_INVALID, "unknown field %d", field);
+    if (env->layout.bytes[field] == 0) return fail(RC_ERR_INVALID, "field %d is not enabled in this configuration", field);
+    *dev_ptr = (char *)env->arena + env->layout.offset[field];
+    *bytes = env->layout.bytes[field];
+    return RC_OK;
+}
+
+int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes) {
+    void *src;
+    size_t n;
+    int rc = rc_get(env, field, &src, &n);
+    if (rc) return rc;
+    if (!host_dst) return fail(RC_ERR_INVALID, "host_dst is NULL");
+    if (bytes != n) return fail(RC_ERR_INVALID, "field %d holds %zu bytes, caller asked for %zu", field, n, bytes);
+    HIP_TRY(hipMemcpyAsync(host_dst, src, n, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    return RC_OK;
+}
+
+int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes) {
+    if (!env || !dev_ptr || !bytes) return fail(RC_ERR_INVALID, "NULL argument");
+    *dev_ptr = env->arena;
+    *bytes = env->layout.slab_bytes;
+    return RC_OK;
+}
+
+int rc_sync(rc_env *env) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    return RC_OK;
+}
+
+void *rc_stream(rc_env *env) { return env ? (void *)env->stream : nullptr; }
+
+int rc_set_profiling(rc_env *env, int32_t enabled) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!enabled) {
+        int rc = drain_events(env);
+        if (rc) return rc;
+    }
+    env->profiling = enabled != 0;
+    return RC_OK;
+}
+
+int rc_kernel_time(rc_env *env, int32_t kernel, double *total_ms, uint64_t *launches) {
+    if (!env || !total_ms || !launches) return fail(RC_ERR_INVALID, "NULL argument");
+    if (kernel < 0 || kernel >= RC_K_COUNT) return fail(RC_ERR_INVALID, "unknown kernel %d", kernel);
+    int rc = drain_events(env);
+    if (rc) return rc;
+    *total_ms = env->k_ms[kernel];
+    *launches = env->k_n[kernel];
+    return RC_OK;
+}
+
+int rc_reset_kernel_times(rc_env *env) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    int rc = drain_events(env);
+    if (rc) return rc;
+    for (int k = 0; k < RC_K_COUNT; ++k) { env->k_ms[k] = 0; env->k_n[k] = 0; }
+    return RC_OK;
+}
+
+int rc_set_raycast_variant(rc_env *env, int32_t variant) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (variant != 0) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    env->launch.raycast_variant = variant;
+    return RC_OK;
+}
+
+}  // extern "C"

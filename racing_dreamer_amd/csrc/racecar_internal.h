@@ -1,0 +1,63 @@
+// Internal structures shared by the C-ABI layer (racecar_abi.hip) and the kernels
+// (racecar_kernels.hip).  Not part of the public interface.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct RcTrackDev {
+    const uint32_t *ray_words;   // occupancy | sentinel ring, [h][pitch]
+    const uint32_t *drv_words;   // drivable area, [h][pitch]
+    const float *progress;       // [h][w], < 0 outside the drivable area
+    const float *centerline;     // [n_centerline][4] = x, y, heading, progress
+    const float *beams;          // [1080][2] = cos, sin of the beam angle in the sensor frame
+    const float *footprint;      // [34][2] body-frame perimeter points
+    int32_t h, w, pitch, n_centerline;
+    float org_x, org_y, res, inv_res, tmax;
+};
+
+struct RcStateDev {              // persistent per-car / per-env simulator state (SoA)
+    float *x, *y, *theta, *ct, *st, *v, *delta, *omega, *accel, *progress;
+    int32_t *lap, *cp;
+    uint8_t *wall, *opp, *wrong, *done, *trunc, *fresh;
+    int32_t *steps, *agent_steps;   // per env
+    uint32_t *episode;              // per env
+};
+
+struct RcOutDev {                // output arena sections (see rc_field)
+    float *lidar, *pose, *velocity, *speed, *action, *reward, *discount, *progress_total, *time;
+    uint8_t *patch;
+    float *progress;
+    int32_t *lap, *cp;
+    uint8_t *done, *trunc, *wall, *opp, *wrong, *fresh;
+    float *accel, *steer;
+};
+
+struct RcParams {
+    RcTrackDev trk;
+    RcStateDev st;
+    RcOutDev out;
+    int32_t num_envs, cars_per_env, n_cars;
+    uint32_t first_env;
+    int32_t task, laps, terminate_on_collision, remap_actions, time_limit_steps, auto_reset, render_patch;
+    float time_limit, collision_reward;
+    float act_lo0, act_lo1, act_hi0, act_hi1;
+    int32_t reset_mode;
+    uint32_t seed_lo, seed_hi;
+};
+
+struct RcLaunchInfo {            // per-handle launch geometry decided at rc_load_track
+    int32_t n_cu;
+    int32_t ray_blocks, ray_threads;
+    int32_t patch_blocks, patch_threads;
+    size_t lds_bytes;
+    int32_t raycast_variant;
+};
+
+// kernel launchers (racecar_kernels.hip); all asynchronous on `s`
+hipError_t rck_set_lds_limits(size_t lds_bytes);
+hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s);
+hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);
+hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
+hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
+hipError_t rck_launch_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t seed_lo,
+                                     uint32_t seed_hi, uint32_t step, hipStream_t s);

@@ -1,0 +1,545 @@
+// HIP kernels of the batched racecar environment for MI355X (gfx950, wave64).
+//
+//   rc_dynamics_kernel  one lane per env: action remap, bicycle integrator (H2), wall / car-car
+//                       collision (H5), progress + lap state machine, reward, done (H4, H15),
+//                       in-kernel action repeat (H9), time limit (H10), auto-reset (H6)
+//   rc_raycast_kernel   one lane per (car, beam): exact grid traversal against the track's
+//                       bit-packed occupancy staged in LDS (H3), inter-car returns (H18)
+//   rc_patch_kernel     lidar_occupancy 64x64 ego patch (H11), drivable bitmap staged in LDS
+//   rc_reset_kernel     masked reset from the centerline spawn table with Philox4x32-10 (H6)
+//
+// Numerics: fp32, one IEEE operation per written operator (-ffp-contract=off), same order as
+// oracle/racecar_oracle.py, so results are bit-identical to the CPU oracle.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "racecar_device.h"
+#include "racecar_internal.h"
+
+#define RC_N_BEAMS 1080
+#define RC_PATCH 64
+
+namespace {
+
+using rcd::clampf;
+using rcd::sincos32;
+
+__device__ __forceinline__ int bit_at(const uint32_t *words, int pitch, int ix, int iy) {
+    return (words[iy * pitch + (ix >> 5)] >> (ix & 31)) & 1u;
+}
+
+__device__ __forceinline__ void cell_of(const RcTrackDev &t, float wx, float wy, int &ix, int &iy) {
+    ix = (int)floorf((wx - t.org_x) * t.inv_res);
+    iy = (int)floorf((wy - t.org_y) * t.inv_res);
+}
+
+__device__ __forceinline__ float progress_at(const RcTrackDev &t, float wx, float wy) {
+    int ix, iy;
+    cell_of(t, wx, wy, ix, iy);
+    if ((unsigned)ix >= (unsigned)t.w || (unsigned)iy >= (unsigned)t.h) return -1.0f;
+    return t.progress[iy * t.w + ix];
+}
+
+struct Car {
+    float x, y, th, ct, st, v, dl, om, ac, pr, rew;
+    int lap, cp;
+    int wall, opp, wrong, done, trunc, fresh;
+};
+
+// Footprint perimeter vs occupancy (H5).  Outside the grid counts as wall.
+__device__ __forceinline__ int wall_hit(const RcTrackDev &t, const Car &c) {
+    int hit = 0;
+    for (int k = 0; k < RCS_N_FOOTPRINT; ++k) {
+        const float fx = t.footprint[2 * k], fy = t.footprint[2 * k + 1];
+        const float wx = c.x + (fx * c.ct - fy * c.st);
+        const float wy = c.y + (fx * c.st + fy * c.ct);
+        int ix, iy;
+        cell_of(t, wx, wy, ix, iy);
+        const bool inb = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+        hit |= inb ? bit_at(t.ray_words, t.pitch, ix, iy) : 1;
+    }
+    return hit;
+}
+
+// Oriented-rectangle overlap by separating axes (car-car collision, H5/H18).
+__device__ __forceinline__ int obb_overlap(const Car &a, const Car &b) {
+    const float ax = a.x + RCS_BOX_CX * a.ct, ay = a.y + RCS_BOX_CX * a.st;
+    const float bx = b.x + RCS_BOX_CX * b.ct, by = b.y + RCS_BOX_CX * b.st;
+    const float dx = bx - ax, dy = by - ay;
+    const float c = fabsf(a.ct * b.ct + a.st * b.st);
+    const float s = fabsf(a.st * b.ct - a.ct * b.st);
+    const float ra = RCS_BOX_HL + (RCS_BOX_HL * c + RCS_BOX_HW * s);
+    const float rb = RCS_BOX_HW + (RCS_BOX_HL * s + RCS_BOX_HW * c);
+    bool sep = fabsf(dx * a.ct + dy * a.st) > ra;
+    sep |= fabsf(dy * a.ct - dx * a.st) > rb;
+    sep |= fabsf(dx * b.ct + dy * b.st) > ra;
+    sep |= fabsf(dy * b.ct - dx * b.st) > rb;
+    return sep ? 0 : 1;
+}
+
+template <int A>
+__device__ __forceinline__ void reset_env(const RcParams &p, int e, Car (&car)[A], int &steps, int &agent_steps) {
+    const RcTrackDev &t = p.trk;
+    const uint32_t g = p.first_env + (uint32_t)e;
+    const uint32_t ep = p.st.episode[e];
+    const rcd::u32x4 r = rcd::philox4x32(g, ep, 0u, 0u, p.seed_lo, p.seed_hi);
+    p.st.episode[e] = ep + 1u;
+    const int n = t.n_centerline;
+    const int idx0 = p.reset_mode == 0 ? 0 : (int)__umulhi(r.x, (uint32_t)n);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        int idx = (idx0 - a * RCS_BALL_GAP_BINS) % n;
+        if (idx < 0) idx += n;
+        Car &c = car[a];
+        c.x = t.centerline[4 * idx + 0];
+        c.y = t.centerline[4 * idx + 1];
+        c.th = t.centerline[4 * idx + 2];
+        sincos32(c.th, c.st, c.ct);
+        float pr = progress_at(t, c.x, c.y);
+        pr = pr < 0.0f ? 0.0f : pr;
+        c.pr = pr;
+        const int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
+        c.cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
+        c.v = c.dl = c.om = c.ac = 0.0f;
+        c.wall = c.opp = c.wrong = c.done = c.trunc = 0;
+        c.lap = 1;
+        c.fresh = 1;
+    }
+    steps = 0;
+    agent_steps = 0;
+}
+
+template <int A>
+__device__ __forceinline__ void load_cars(const RcParams &p, int e, Car (&car)[A]) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        Car &c = car[a];
+        c.x = p.st.x[i]; c.y = p.st.y[i]; c.th = p.st.theta[i]; c.ct = p.st.ct[i]; c.st = p.st.st[i];
+        c.v = p.st.v[i]; c.dl = p.st.delta[i]; c.om = p.st.omega[i]; c.ac = p.st.accel[i];
+        c.pr = p.st.progress[i]; c.lap = p.st.lap[i]; c.cp = p.st.cp[i];
+        c.wall = p.st.wall[i]; c.opp = p.st.opp[i]; c.wrong = p.st.wrong[i];
+        c.done = p.st.done[i]; c.trunc = p.st.trunc[i]; c.fresh = 0;
+        c.rew = 0.0f;
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void store_state_and_obs(const RcParams &p, int e, const Car (&car)[A], int steps,
+                                                    int agent_steps) {
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        const Car &c = car[a];
+        p.st.x[i] = c.x; p.st.y[i] = c.y; p.st.theta[i] = c.th; p.st.ct[i] = c.ct; p.st.st[i] = c.st;
+        p.st.v[i] = c.v; p.st.delta[i] = c.dl; p.st.omega[i] = c.om; p.st.accel[i] = c.ac;
+        p.st.progress[i] = c.pr; p.st.lap[i] = c.lap; p.st.cp[i] = c.cp;
+        p.st.wall[i] = c.wall; p.st.opp[i] = c.opp; p.st.wrong[i] = c.wrong;
+        p.st.done[i] = c.done; p.st.trunc[i] = c.trunc; p.st.fresh[i] = c.fresh;
+        // observation of the current state (post auto-reset)
+        float *pose = p.out.pose + 6 * i, *vel = p.out.velocity + 6 * i;
+        pose[0] = c.x; pose[1] = c.y; pose[2] = 0.0f; pose[3] = 0.0f; pose[4] = 0.0f; pose[5] = c.th;
+        vel[0] = c.v; vel[1] = 0.0f; vel[2] = 0.0f; vel[3] = 0.0f; vel[4] = 0.0f; vel[5] = c.om;
+        p.out.speed[i] = fabsf(c.v);
+        p.out.accel[i] = c.ac;
+        p.out.steer[i] = c.dl;
+        p.out.fresh[i] = c.fresh;
+    }
+    p.st.steps[e] = steps;
+    p.st.agent_steps[e] = agent_steps;
+}
+
+// Results of the step that just ran (terminal values when the env finished).
+template <int A>
+__device__ __forceinline__ void store_step_results(const RcParams &p, int e, const Car (&car)[A], int steps) {
+    const float time = (float)steps * RCS_DT;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        const Car &c = car[a];
+        p.out.reward[i] = c.rew;
+        p.out.discount[i] = 1.0f - (float)c.done;
+        p.out.progress_total[i] = (float)(c.lap - 1) + c.pr;
+        p.out.time[i] = time;
+        p.out.progress[i] = c.pr;
+        p.out.lap[i] = c.lap;
+        p.out.cp[i] = c.cp;
+        p.out.done[i] = c.done;
+        p.out.trunc[i] = c.trunc;
+        p.out.wall[i] = c.wall;
+        p.out.opp[i] = c.opp;
+        p.out.wrong[i] = c.wrong;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int A>
+__global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, const float *__restrict__ actions, int repeat) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.num_envs) return;
+    const RcTrackDev &t = p.trk;
+    Car car[A];
+    load_cars<A>(p, e, car);
+    int steps = p.st.steps[e], agent_steps = p.st.agent_steps[e];
+    float motor[A], steer[A];
+    bool any_done = false;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        const float a0 = actions[2 * i], a1 = actions[2 * i + 1];
+        p.out.action[2 * i] = a0;
+        p.out.action[2 * i + 1] = a1;
+        float m = a0, s = a1;
+        if (p.remap_actions) {   // ReduceActionSpace, dreamer/wrappers.py:128-130
+            m = ((a0 + 1.0f) * 0.5f) * (p.act_hi0 - p.act_lo0) + p.act_lo0;
+            s = ((a1 + 1.0f) * 0.5f) * (p.act_hi1 - p.act_lo1) + p.act_lo1;
+        }
+        motor[a] = clampf(m, -1.0f, 1.0f);
+        steer[a] = clampf(s, -1.0f, 1.0f);
+        any_done |= car[a].done != 0;
+    }
+
+    if (!any_done) {
+        for (int sub = 0; sub < repeat; ++sub) {   // ActionRepeat, dreamer/wrappers.py:107-116
+            // --- kinematic bicycle, explicit Euler (H2)
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                Car &c = car[a];
+                const float m = motor[a];
+                const float v_t = m >= 0.0f ? RCS_MAX_VEL : 0.0f;
+                const float dv_max = (fabsf(m) * RCS_ACCEL_MAX) * RCS_DT;
+                const float dv = clampf(v_t - c.v, -dv_max, dv_max);
+                c.v = c.v + dv;
+                const float dd = clampf(steer[a] * RCS_MAX_STEER - c.dl, -RCS_STEER_STEP, RCS_STEER_STEP);
+                c.dl = c.dl + dd;
+                float sd, cd;
+                sincos32(c.dl, sd, cd);
+                c.om = (c.v / RCS_WHEELBASE) * (sd / cd);
+                c.x = c.x + (c.v * c.ct) * RCS_DT;
+                c.y = c.y + (c.v * c.st) * RCS_DT;
+                float th = c.th + c.om * RCS_DT;
+                th = th > RCS_PI ? th - RCS_TWO_PI : th;
+                th = th < -RCS_PI ? th + RCS_TWO_PI : th;
+                c.th = th;
+                sincos32(th, c.st, c.ct);
+                c.ac = dv * RCS_INV_DT;
+            }
+            steps += 1;
+            // --- collisions (H5)
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                car[a].wall = wall_hit(t, car[a]);
+                car[a].opp = 0;
+            }
+#pragma unroll
+            for (int a = 0; a < A; ++a)
+#pragma unroll
+                for (int b = a + 1; b < A; ++b) {
+                    const int o = obb_overlap(car[a], car[b]);
+                    car[a].opp |= o;
+                    car[b].opp |= o;
+                }
+            // --- progress, lap, reward, done (H4, H15)
+            const float time = (float)steps * RCS_DT;
+            bool stop = false;
+#pragma unroll
+            for (int a = 0; a < A; ++a) {
+                Car &c = car[a];
+                float p_new = progress_at(t, c.x, c.y);
+                const float p_old = c.pr;
+                const int lap_old = c.lap, cp_old = c.cp;
+                p_new = p_new >= 0.0f ? p_new : p_old;
+                int cp_new = (int)(p_new * (float)RCS_N_CHECKPOINTS);
+                cp_new = cp_new < RCS_N_CHECKPOINTS - 1 ? cp_new : RCS_N_CHECKPOINTS - 1;
+                int d = cp_new - cp_old;
+                d = d < 0 ? d + RCS_N_CHECKPOINTS : d;
+                const bool fwd = d > 0 && d <= RCS_N_CHECKPOINTS / 2;
+                const bool bwd = d > RCS_N_CHECKPOINTS / 2;
+                const int lap = lap_old + ((fwd && cp_new < cp_old) ? 1 : 0) - ((bwd && cp_new > cp_old) ? 1 : 0);
+                c.wrong = fwd ? 0 : (bwd ? 1 : c.wrong);
+                c.cp = (fwd || bwd) ? cp_new : cp_old;
+                c.lap = lap;
+                c.pr = p_new;
+                const bool collided = (c.wall | c.opp) != 0;
+                float r;
+                bool done;
+                if (p.task == 0) {
+                    const float delta = (float)(lap - lap_old) + (p_new - p_old);
+                    r = delta * RCS_PROGRESS_REWARD + (collided ? p.collision_reward : 0.0f);
+                    done = (collided && p.terminate_on_collision) || lap > p.laps || time > p.time_limit;
+                } else {   // baselines/racing/environment/tasks.py:6-18
+                    r = c.wall ? -1.0f : -rcd::exp32(fabsf(steer[a]) - c.v);
+                    done = false;
+                }
+                c.rew = c.rew + r;
+                c.done = done ? 1 : 0;
+                stop |= done;
+            }
+            if (stop) break;
+        }
+        agent_steps += 1;
+        if (p.time_limit_steps > 0 && agent_steps >= p.time_limit_steps) {   // TimeLimit, wrappers.py:147-154
+#pragma unroll
+            for (int a = 0; a < A; ++a) { car[a].done = 1; car[a].trunc = 1; }
+        }
+    }
+    store_step_results<A>(p, e, car, steps);
+    if (p.auto_reset) {
+        bool fin = false;
+#pragma unroll
+        for (int a = 0; a < A; ++a) fin |= car[a].done != 0;
+        if (fin) reset_env<A>(p, e, car, steps, agent_steps);
+    }
+    store_state_and_obs<A>(p, e, car, steps, agent_steps);
+}
+
+template <int A>
+__global__ __launch_bounds__(256) void rc_reset_kernel(RcParams p, const uint8_t *__restrict__ mask) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.num_envs) return;
+    if (mask != nullptr && mask[e] == 0) {
+        // an env that keeps running: its next observation is no longer the first of an episode
+        return;
+    }
+    Car car[A];
+    int steps, agent_steps;
+#pragma unroll
+    for (int a = 0; a < A; ++a) car[a].rew = 0.0f;
+    reset_env<A>(p, e, car, steps, agent_steps);
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        p.out.action[2 * i] = 0.0f;       // Collect.reset, dreamer/wrappers.py:232
+        p.out.action[2 * i + 1] = 0.0f;
+    }
+    store_step_results<A>(p, e, car, steps);
+    store_state_and_obs<A>(p, e, car, steps, agent_steps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage a [h][pitch] bitmap into LDS with 16-byte loads (the buffers are padded to 4 words).
+__device__ __forceinline__ void stage_bitmap(uint32_t *lds, const uint32_t *__restrict__ src, int nwords) {
+    const int nvec = (nwords + 3) >> 2;
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+    uint4 *d4 = reinterpret_cast<uint4 *>(lds);
+    for (int i = threadIdx.x; i < nvec; i += blockDim.x) d4[i] = s4[i];
+    __syncthreads();
+}
+
+// Distance [m] along the ray to another car's rectangle, +inf if none within range (H18).
+__device__ __forceinline__ float ray_vs_car(float lx, float ly, float dx, float dy, float ox, float oy, float ct2,
+                                            float st2) {
+    const float cx = ox + RCS_BOX_CX * ct2, cy = oy + RCS_BOX_CX * st2;
+    const float rx = lx - cx, ry = ly - cy;
+    const float px = rx * ct2 + ry * st2;
+    const float py = ry * ct2 - rx * st2;
+    const float ex = dx * ct2 + dy * st2;
+    const float ey = dy * ct2 - dx * st2;
+    float tn = -INFINITY, tf = INFINITY;
+    bool miss = false;
+    if (ex != 0.0f) {
+        const float inv = 1.0f / ex;
+        const float t1 = (-RCS_BOX_HL - px) * inv, t2 = (RCS_BOX_HL - px) * inv;
+        const float lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+        tn = lo > tn ? lo : tn;
+        tf = hi < tf ? hi : tf;
+    } else {
+        miss |= fabsf(px) > RCS_BOX_HL;
+    }
+    if (ey != 0.0f) {
+        const float inv = 1.0f / ey;
+        const float t1 = (-RCS_BOX_HW - py) * inv, t2 = (RCS_BOX_HW - py) * inv;
+        const float lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+        tn = lo > tn ? lo : tn;
+        tf = hi < tf ? hi : tf;
+    } else {
+        miss |= fabsf(py) > RCS_BOX_HW;
+    }
+    const bool hit = !miss && tn <= tf && tf >= 0.0f;
+    const float tt = tn > 0.0f ? tn : 0.0f;
+    return (hit && tt < RCS_MAX_RANGE) ? tt : INFINITY;
+}
+
+// Exact grid traversal (H3).  Cell boundaries are derived from the integer cell index at every
+// step (t = (boundary - origin) * 1/d), so the visited cell sequence and the returned range do
+// not depend on how the traversal is scheduled.  The bitmap's outermost ring is set and means
+// "no return", so no per-step bounds check is needed.
+__device__ __forceinline__ float cast_ray_dda(const uint32_t *bits, const RcTrackDev &t, float gx, float gy,
+                                              float dx, float dy) {
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    if ((unsigned)ix >= (unsigned)t.w || (unsigned)iy >= (unsigned)t.h) return 0.0f;
+    if (bit_at(bits, t.pitch, ix, iy)) return 0.0f;
+    const float idx = dx != 0.0f ? 1.0f / dx : 0.0f;
+    const float idy = dy != 0.0f ? 1.0f / dy : 0.0f;
+    const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+    const float sxf = (float)sx, syf = (float)sy;
+    float bx = (float)(ix + (dx > 0.0f ? 1 : 0));
+    float by = (float)(iy + (dy > 0.0f ? 1 : 0));
+    float tx = dx != 0.0f ? (bx - gx) * idx : INFINITY;
+    float ty = dy != 0.0f ? (by - gy) * idy : INFINITY;
+    const int wm1 = t.w - 1, hm1 = t.h - 1;
+    for (;;) {
+        const bool stepx = tx < ty;
+        const float tt = stepx ? tx : ty;
+        if (tt >= t.tmax) return RCS_MAX_RANGE;
+        if (stepx) {
+            ix += sx;
+            bx += sxf;
+            tx = (bx - gx) * idx;
+        } else {
+            iy += sy;
+            by += syf;
+            ty = (by - gy) * idy;
+        }
+        if (bit_at(bits, t.pitch, ix, iy)) {
+            const bool ring = ix == 0 || iy == 0 || ix == wm1 || iy == hm1;
+            return ring ? RCS_MAX_RANGE : tt * t.res;
+        }
+    }
+}
+
+template <int A>
+__global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_rays) {
+    extern __shared__ uint32_t lds_words[];
+    const RcTrackDev &t = p.trk;
+    stage_bitmap(lds_words, t.ray_words, t.h * t.pitch);
+    for (int base = blockIdx.x * blockDim.x; base < total_rays; base += gridDim.x * blockDim.x) {
+        const int g = base + threadIdx.x;
+        if (g >= total_rays) break;
+        const int car = g / RC_N_BEAMS;
+        const int beam = g - car * RC_N_BEAMS;
+        const float ct = p.st.ct[car], st = p.st.st[car];
+        const float lx = p.st.x[car] + RCS_LIDAR_X * ct;
+        const float ly = p.st.y[car] + RCS_LIDAR_X * st;
+        const float cb = t.beams[2 * beam], sb = t.beams[2 * beam + 1];
+        const float dx = ct * cb - st * sb;
+        const float dy = st * cb + ct * sb;
+        const float gx = (lx - t.org_x) * t.inv_res;
+        const float gy = (ly - t.org_y) * t.inv_res;
+        float rng = cast_ray_dda(lds_words, t, gx, gy, dx, dy);
+        if (A > 1) {
+            const int env = car / A;
+#pragma unroll
+            for (int o = 0; o < A; ++o) {
+                const int oc = env * A + o;
+                if (oc != car) {
+                    const float tc = ray_vs_car(lx, ly, dx, dy, p.st.x[oc], p.st.y[oc], p.st.ct[oc], p.st.st[oc]);
+                    rng = tc < rng ? tc : rng;
+                }
+            }
+        }
+        p.out.lidar[g] = rng;
+    }
+}
+
+// lidar_occupancy (H11): ego-aligned 64x64 patch of the drivable area, heading = +col, car at the
+// centre, 0.15625 m per pixel, 2x2 taps per pixel, 1 = drivable.  One lane renders 4 adjacent
+// pixels of a row and stores them as one 32-bit word.
+__global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_quads) {
+    extern __shared__ uint32_t lds_words[];
+    const RcTrackDev &t = p.trk;
+    stage_bitmap(lds_words, t.drv_words, t.h * t.pitch);
+    uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out.patch);
+    for (int base = blockIdx.x * blockDim.x; base < total_quads; base += gridDim.x * blockDim.x) {
+        const int q = base + threadIdx.x;
+        if (q >= total_quads) break;
+        const int car = q >> 10;              // 64 rows * 16 quads
+        const int row = (q >> 4) & 63;
+        const int c0 = (q & 15) * 4;
+        uint32_t word = 0;
+        if (!p.st.fresh[car]) {               // reset observation is all zeros, dreamer/wrappers.py:413
+            const float ct = p.st.ct[car], st = p.st.st[car];
+            const float x = p.st.x[car], y = p.st.y[car];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < RCS_PATCH_TAPS; ++j) {
+                    const float subr = (float)(2 * row + j) * 0.5f + (0.25f - 32.0f);
+                    const float yb = -(subr * RCS_PATCH_PX);
+#pragma unroll
+                    for (int i = 0; i < RCS_PATCH_TAPS; ++i) {
+                        const float subc = (float)(2 * (c0 + k) + i) * 0.5f + (0.25f - 32.0f);
+                        const float xb = subc * RCS_PATCH_PX;
+                        const float wx = x + (xb * ct - yb * st);
+                        const float wy = y + (xb * st + yb * ct);
+                        int ix, iy;
+                        cell_of(t, wx, wy, ix, iy);
+                        const bool inb = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+                        cnt += inb ? bit_at(lds_words, t.pitch, ix, iy) : 0;
+                    }
+                }
+                word |= (cnt * 2 >= RCS_PATCH_TAPS * RCS_PATCH_TAPS ? 1u : 0u) << (8 * k);
+            }
+        }
+        out32[q] = word;
+    }
+}
+
+__global__ __launch_bounds__(256) void rc_random_actions_kernel(float *__restrict__ actions, int n_cars,
+                                                                 uint32_t first_car, uint32_t seed_lo,
+                                                                 uint32_t seed_hi, uint32_t step) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cars) return;
+    const rcd::u32x4 r = rcd::philox4x32(first_car + (uint32_t)i, step, 1u, 0u, seed_lo, seed_hi);
+    const float u0 = (float)(r.x >> 8) * 5.9604644775390625e-8f;   // 2^-24
+    const float u1 = (float)(r.y >> 8) * 5.9604644775390625e-8f;
+    actions[2 * i] = u0 * 2.0f - 1.0f;
+    actions[2 * i + 1] = u1 * 2.0f - 1.0f;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+hipError_t rck_set_lds_limits(size_t lds_bytes) {
+    hipError_t e;
+    const int b = (int)lds_bytes;
+#define SET(k) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, b); if (e != hipSuccess) return e;
+    SET(rc_raycast_kernel<1>)
+    SET(rc_raycast_kernel<2>)
+    SET(rc_raycast_kernel<3>)
+    SET(rc_raycast_kernel<4>)
+    SET(rc_patch_kernel)
+#undef SET
+    return hipSuccess;
+}
+
+#define DISPATCH_A(A, ...)                                     \
+    switch (A) {                                               \
+        case 1: { constexpr int kA = 1; __VA_ARGS__; } break;  \
+        case 2: { constexpr int kA = 2; __VA_ARGS__; } break;  \
+        case 3: { constexpr int kA = 3; __VA_ARGS__; } break;  \
+        default: { constexpr int kA = 4; __VA_ARGS__; } break; \
+    }
+
+hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s) {
+    const int threads = 256, blocks = (p.num_envs + threads - 1) / threads;
+    DISPATCH_A(p.cars_per_env, rc_dynamics_kernel<kA><<<dim3(blocks), dim3(threads), 0, s>>>(p, actions, repeat));
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s) {
+    const int threads = 256, blocks = (p.num_envs + threads - 1) / threads;
+    DISPATCH_A(p.cars_per_env, rc_reset_kernel<kA><<<dim3(blocks), dim3(threads), 0, s>>>(p, mask_dev));
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
+    const int total = p.n_cars * RC_N_BEAMS;
+    DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes, s>>>(p, total));
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
+    const int total = p.n_cars * RC_PATCH * (RC_PATCH / 4);
+    hipLaunchKernelGGL(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t seed_lo,
+                                     uint32_t seed_hi, uint32_t step, hipStream_t s) {
+    const int threads = 256, blocks = (n_cars + threads - 1) / threads;
+    hipLaunchKernelGGL(rc_random_actions_kernel, dim3(blocks), dim3(threads), 0, s, actions, n_cars, first_car, seed_lo, seed_hi, step);
+    return hipGetLastError();
+}

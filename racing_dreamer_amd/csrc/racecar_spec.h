@@ -1,0 +1,24 @@
+// Env spec constants shared by host and device code.
+// The CPU oracle (oracle/) restates the same numbers independently.
+#pragma once
+
+#define RCS_DT 0.01f              // dreamer/callbacks.py:23
+#define RCS_INV_DT 100.0f
+#define RCS_MAX_RANGE 15.0f       // dreamer/tools.py:274
+#define RCS_LIDAR_X 0.25f
+#define RCS_WHEELBASE 0.3302f     // ros_agent/agents/follow_the_gap/src/agent.py:78
+#define RCS_MAX_STEER 0.42f       // ros_agent/models/dreamer/racing_dreamer.py:14
+#define RCS_MAX_VEL 5.0f          // ros_agent/models/dreamer/racing_dreamer.py:16
+#define RCS_ACCEL_MAX 4.0f        // max_force 0.5 (racing_dreamer.py:15) * 8 m/s^2 per unit force
+#define RCS_STEER_STEP 0.032f     // 3.2 rad/s * dt
+#define RCS_BOX_CX 0.175f         // car rectangle centre ahead of the rear axle
+#define RCS_BOX_HL 0.275f         // half length
+#define RCS_BOX_HW 0.15f          // half width
+#define RCS_N_CHECKPOINTS 20
+#define RCS_PROGRESS_REWARD 100.0f
+#define RCS_PATCH_PX 0.15625f     // 200 cells * 0.05 m / 64 px   (dreamer/wrappers.py:374-378,398-405)
+#define RCS_PATCH_TAPS 2
+#define RCS_BALL_GAP_BINS 12
+#define RCS_N_FOOTPRINT 34
+#define RCS_PI 3.14159274101257324f
+#define RCS_TWO_PI 6.28318548202514648f

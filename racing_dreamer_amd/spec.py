@@ -1,0 +1,76 @@
+"""Frozen constants of the batched racecar environment spec.
+
+Values with a reference citation are taken from the reference tree; the rest are this
+build's free parameters (the reference's simulator, racecar_gym + PyBullet, is an
+un-vendored dependency, so nothing in the reference fixes them - SURVEY.md §8a).
+The device code (csrc/racecar_spec.h) and the CPU oracle (oracle/) restate the same
+numbers independently; tests/test_spec_consistency.py checks the three agree.
+"""
+import math
+
+import numpy as np
+
+# --- simulation clock -------------------------------------------------------------
+DT = 0.01                     # dreamer/callbacks.py:23, ros_agent/utils.py:10
+
+# --- LiDAR ------------------------------------------------------------------------
+N_BEAMS = 1080                # dreamer/dream.py:66
+FOV_DEG = 270.0               # dreamer/tools.py:84-86
+MAX_RANGE = 15.0              # dreamer/tools.py:274
+LIDAR_X = 0.25                # sensor origin ahead of the rear axle [m]            (free)
+
+# --- vehicle ----------------------------------------------------------------------
+WHEELBASE = 0.3302            # ros_agent/agents/follow_the_gap/src/agent.py:78
+MAX_STEER = 0.42              # ros_agent/models/dreamer/racing_dreamer.py:14
+MAX_FORCE = 0.5               # ros_agent/models/dreamer/racing_dreamer.py:15
+MAX_VEL = 5.0                 # ros_agent/models/dreamer/racing_dreamer.py:16
+FORCE_TO_ACCEL = 8.0          # m/s^2 per unit motor force                          (free)
+ACCEL_MAX = MAX_FORCE * FORCE_TO_ACCEL
+STEER_RATE = 3.2              # rad/s steering slew limit                           (free)
+X_REAR, X_FRONT, HALF_W = -0.10, 0.45, 0.15   # footprint in the body frame [m]    (free)
+FOOTPRINT_LONG_PTS, FOOTPRINT_SHORT_PTS = 12, 5
+
+# --- task (dreamer/scenarios/max_progress/columbia.yml:9-10) ------------------------
+N_CHECKPOINTS = 20            # (free)
+PROGRESS_REWARD = 100.0       # (free; racecar_gym default)
+TASK_MAX_PROGRESS, TASK_MAX_SPEED = 0, 1
+
+# --- lidar_occupancy patch (dreamer/wrappers.py:374-378,398-405) --------------------
+PATCH = 64
+PATCH_WINDOW_CELLS = 200      # 2 * neigh_size
+PATCH_TAPS = 2                # sub-samples per axis per output pixel               (free)
+
+# --- reset modes (dreamer/dream.py:105-108,120) --------------------------------------
+RESET_GRID, RESET_RANDOM, RESET_RANDOM_BALL = 0, 1, 2
+RESET_MODES = {"grid": RESET_GRID, "random": RESET_RANDOM, "random_ball": RESET_RANDOM_BALL}
+BALL_GAP_BINS = 12            # centerline bins (0.1 m each) between cars           (free)
+
+# --- action remap (dreamer/dream.py:138) ---------------------------------------------
+ACTION_LOW = (0.005, -1.0)
+ACTION_HIGH = (1.0, 1.0)
+
+# trajectory record, bytes per car per agent step (dreamer/wrappers.py:213-219)
+RECORD_FLOATS = N_BEAMS + 6 + 6 + 1 + 2 + 1 + 1 + 1 + 1      # 1099 floats = 4396 B
+
+
+def beam_table() -> np.ndarray:
+    """float32 [N_BEAMS, 2] = (cos, sin) of the beam angle in the sensor frame.
+
+    Beam 0 points to +135 deg (left-rear), the sweep is clockwise to -135 deg
+    (dreamer/tools.py:84-86).  Evaluated in float64, rounded once to float32.
+    """
+    half = math.radians(FOV_DEG) / 2.0
+    ang = half - np.arange(N_BEAMS, dtype=np.float64) * (2.0 * half / (N_BEAMS - 1))
+    return np.stack([np.cos(ang), np.sin(ang)], axis=1).astype(np.float32)
+
+
+def footprint_table() -> np.ndarray:
+    """float32 [34, 2] perimeter sample points of the car rectangle in the body frame."""
+    xs = np.linspace(X_REAR, X_FRONT, FOOTPRINT_LONG_PTS)
+    ys = np.linspace(-HALF_W, HALF_W, FOOTPRINT_SHORT_PTS + 2)[1:-1]
+    pts = [(x, -HALF_W) for x in xs] + [(x, HALF_W) for x in xs]
+    pts += [(X_REAR, y) for y in ys] + [(X_FRONT, y) for y in ys]
+    return np.asarray(pts, np.float64).astype(np.float32)
+
+
+N_FOOTPRINT = 2 * FOOTPRINT_LONG_PTS + 2 * FOOTPRINT_SHORT_PTS
