@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: env-steps/s of the batched racing env on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+
+A "step" is one pass of the hot path over one batch: random actions (Philox, on device) ->
+integrator + collision + progress/reward/done + auto-reset -> 1080-beam LiDAR scan, for 65 536 envs
+per GPU (weak scaling), action_repeat 1, so one step = one simulator sub-step (dt = 0.01 s) of every
+env.  For N > 1 every step also feeds the overlapped RCCL all-gather of the trajectory slab.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+RAYCAST_BYTES_PER_CAR = 4 * 1080 + 16       # lidar row written + (x, y, cos, sin) read, DESIGN.md §5
+STEP_BYTES_PER_CAR = 4 * 1080 + 159         # whole env-step, obs_type=lidar
+PATCH_BYTES_PER_CAR = 4096
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--cars", type=int, default=1)
+    ap.add_argument("--track", default="austria")
+    ap.add_argument("--obs-type", default="lidar", choices=["lidar", "lidar_occupancy"])
+    ap.add_argument("--repeat", type=int, default=1, help="action repeat (sub-steps per step)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--raycast-variant", type=int, default=None)
+    return ap.parse_args()
+
+
+def cpu_baseline(track, cars, obs_type, repeat, n_envs):
+    """The CPU oracle timed on this host's cores on a bounded sample of the same workload."""
+    from oracle import cpu_baseline as cb
+    return cb.run(track, cars=cars, occupancy=(obs_type == "lidar_occupancy"), repeat=repeat, n_envs=n_envs)
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
+            sys.exit(2)
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.distributed import TrajectoryGather, shard_envs
+    from racing_dreamer_amd.track_assets import load_track
+
+    track = load_track(args.track)
+    shard = shard_envs(args.envs * world, rank, world)
+    env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
+                         device=local_rank, first_env=shard.first_env, auto_reset=True, profiling=False)
+    if args.raycast_variant is not None:
+        from racing_dreamer_amd import _lib as L
+        L.check(env._lib.rc_set_raycast_variant(env._h, args.raycast_variant))
+    env.reset(mode="random", seed=0)
+    gather = TrajectoryGather(env.slab) if (distributed and not args.no_gather) else None
+
+    def one_step(k):
+        env.fill_random_actions(seed=1, step=k)
+        env.step(None)
+        if gather is not None:
+            gather.launch(env.slab)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        one_step(k)
+    if gather is not None:
+        gather.wait()
+    env.sync()
+    env.reset_kernel_times()
+    env.set_profiling(True)          # HIP events around every kernel, on the stream they run on
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(args.warmup + k)
+    if gather is not None:
+        gather.wait()
+    env.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    env.set_profiling(False)
+    ktimes = env.kernel_times()
+
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    total_envs = args.envs * world
+    env_steps = total_envs * args.steps * args.repeat
+    value = env_steps / dt
+    if rank == 0:
+        n_cars = shard.num_envs * args.cars
+        ray = ktimes["rc_raycast_kernel"]
+        ray_s = ray["avg_ms"] * 1e-3
+        achieved = RAYCAST_BYTES_PER_CAR * n_cars / ray_s / 1e9 if ray_s > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                traffic = json.load(f).get(f"{args.track}:{shard.num_envs}x{args.cars}:{args.obs_type}")
+        out = {
+            "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.envs} envs/GPU x {args.cars} car, track {args.track}, obs_type={args.obs_type}, "
+                            f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
+                            f"auto-reset, action_repeat {args.repeat}",
+                "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
+                "track": args.track, "obs_type": args.obs_type, "action_repeat": args.repeat,
+                "parallelism": f"env-sharded x{world}" + ("" if gather is None else " + overlapped RCCL all-gather of the trajectory slab every step"),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "rc_raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
+                "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
+                "rays_per_s": n_cars * 1080 / ray_s if ray_s > 0 else 0.0,
+                "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by VALU/LDS work "
+                        "of the grid traversal, not by HBM (SURVEY.md §8d); see DESIGN.md §5",
+            },
+            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
+            "agent_steps_per_s_at_repeat4": None,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
+        print(json.dumps(out), flush=True)
+    env.close()
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

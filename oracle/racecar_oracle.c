@@ -1,0 +1,425 @@
+/*
+ * racecar_oracle.c - plain-C CPU oracle of the batched racecar environment.
+ * TEST INFRASTRUCTURE, NOT PRODUCT: only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may build, load or call this.  PARITY UNPINNED for the simulator core (the
+ * reference's env.step() lives in the un-vendored racecar_gym + pybullet packages, see the header
+ * of racecar_oracle.py); this file is the scalar restatement of the same env spec
+ * as oracle/racecar_oracle.py and is pinned bit-for-bit to it by tests/test_oracle.py.
+ *
+ * Interface cited from the reference: step()/reset() contract dreamer/wrappers.py:62-77;
+ * 1080 beams / 270 deg clockwise dreamer/tools.py:84-86; 15 m range dreamer/tools.py:274;
+ * vehicle limits ros_agent/models/dreamer/racing_dreamer.py:14-16; wheelbase
+ * ros_agent/agents/follow_the_gap/src/agent.py:78; task params
+ * dreamer/scenarios/max_progress/columbia.yml:10; max_speed reward
+ * baselines/racing/environment/tasks.py:6-18; action repeat dreamer/wrappers.py:107-116;
+ * action remap dreamer/wrappers.py:128-130; time limit dreamer/wrappers.py:147-154;
+ * occupancy patch dreamer/wrappers.py:390-408.
+ *
+ * Numerics: binary32, one IEEE operation per operator, no FMA (build with -ffp-contract=off,
+ * SSE2 scalar math), no libm beyond floorf/rintf/fabsf.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#define N_BEAMS 1080
+#define PATCH 64
+#define MAX_CARS 4
+#define N_FOOT 34
+#define DT 0.01f
+#define INV_DT 100.0f
+#define MAX_RANGE 15.0f
+#define LIDAR_X 0.25f
+#define WHEELBASE 0.3302f
+#define MAX_STEER 0.42f
+#define MAX_VEL 5.0f
+#define ACCEL_MAX 4.0f
+#define STEER_STEP 0.032f
+#define BOX_CX 0.175f
+#define BOX_HL 0.275f
+#define BOX_HW 0.15f
+#define N_CP 20
+#define PROGRESS_REWARD 100.0f
+#define PATCH_PX 0.15625f
+#define BALL_GAP 12
+#define PI_F 3.14159274101257324f
+#define TWO_PI_F 6.28318548202514648f
+
+typedef struct {
+    const uint8_t *occ;      /* [h][w] occupancy with the sentinel ring set */
+    const uint8_t *ring;     /* [h][w] 1 on the outermost cells             */
+    const uint8_t *drv;      /* [h][w] drivable area                        */
+    const float *progress;   /* [h][w]                                      */
+    const float *centerline; /* [n][4]                                      */
+    const float *beams;      /* [1080][2] cos, sin                          */
+    const float *foot;       /* [34][2]                                     */
+    int32_t h, w, n_centerline;
+    float org_x, org_y, res, inv_res, tmax;
+} oc_track;
+
+typedef struct {
+    int32_t num_envs, cars_per_env;
+    uint32_t first_env;
+    int32_t task, laps, terminate_on_collision, remap_actions, time_limit_steps, auto_reset;
+    float time_limit, collision_reward, act_lo[2], act_hi[2];
+    int32_t reset_mode;
+    uint32_t seed_lo, seed_hi;
+} oc_cfg;
+
+typedef struct {
+    float *x, *y, *theta, *ct, *st, *v, *delta, *omega, *accel, *progress;
+    int32_t *lap, *cp;
+    uint8_t *wall, *opp, *wrong, *done, *trunc, *fresh;
+    int32_t *steps, *agent_steps;
+    uint32_t *episode;
+    /* per-step results */
+    float *reward, *discount, *progress_total, *time, *action;
+    float *out_progress;
+    int32_t *out_lap, *out_cp;
+    uint8_t *out_done, *out_trunc, *out_wall, *out_opp, *out_wrong;
+} oc_state;
+
+static inline float clampf(float d, float lo, float hi) { return d < lo ? lo : (d > hi ? hi : d); }
+
+static inline void sincos32(float a, float *sn, float *cs) {
+    const float kf = rintf(a * 0.636619772367581343f);
+    const float r = ((a - kf * 1.5703125f) - kf * 4.837512969970703125e-4f) - kf * 7.54978995489188216e-8f;
+    const int q = ((int)kf) & 3;
+    const float z = r * r;
+    const float s = r + (r * z) * (-1.6666654611e-1f + z * (8.3321608736e-3f + z * -1.9515295891e-4f));
+    const float c = (1.0f - 0.5f * z) + (z * z) * (4.166664568298827e-2f + z * (-1.388731625493765e-3f + z * 2.443315711809948e-5f));
+    *sn = q == 0 ? s : (q == 1 ? c : (q == 2 ? -s : -c));
+    *cs = q == 0 ? c : (q == 1 ? -s : (q == 2 ? -c : s));
+}
+
+static inline float exp32(float x) {
+    union { int32_t i; float f; } u;
+    x = clampf(x, -80.0f, 80.0f);
+    const float kf = rintf(x * 1.44269504088896341f);
+    const float r = (x - kf * 0.693359375f) - kf * -2.12194440e-4f;
+    const float z = r * r;
+    float p = 1.9875691500e-4f;
+    p = p * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    const float y = (p * z + r) + 1.0f;
+    u.i = (((int32_t)kf) + 127) << 23;
+    return y * u.f;
+}
+
+static void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int i = 0; i < 10; ++i) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        c[0] = n0; c[1] = (uint32_t)p1; c[2] = n2; c[3] = (uint32_t)p0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+static inline void cell_of(const oc_track *t, float wx, float wy, int *ix, int *iy) {
+    *ix = (int)floorf((wx - t->org_x) * t->inv_res);
+    *iy = (int)floorf((wy - t->org_y) * t->inv_res);
+}
+static inline int inb(const oc_track *t, int ix, int iy) { return ix >= 0 && ix < t->w && iy >= 0 && iy < t->h; }
+
+static inline float progress_at(const oc_track *t, float wx, float wy) {
+    int ix, iy;
+    cell_of(t, wx, wy, &ix, &iy);
+    return inb(t, ix, iy) ? t->progress[(size_t)iy * t->w + ix] : -1.0f;
+}
+
+void oc_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t seed_lo, uint32_t seed_hi, uint32_t step) {
+    for (int i = 0; i < n_cars; ++i) {
+        uint32_t c[4] = {first_car + (uint32_t)i, step, 1u, 0u};
+        philox4x32(c, seed_lo, seed_hi);
+        actions[2 * i] = ((float)(c[0] >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f;
+        actions[2 * i + 1] = ((float)(c[1] >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f;
+    }
+}
+
+static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
+    const int A = c->cars_per_env, n = t->n_centerline;
+    uint32_t r[4] = {c->first_env + (uint32_t)e, s->episode[e], 0u, 0u};
+    philox4x32(r, c->seed_lo, c->seed_hi);
+    s->episode[e] += 1u;
+    const int idx0 = c->reset_mode == 0 ? 0 : (int)(((uint64_t)r[0] * (uint64_t)n) >> 32);
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        int idx = (idx0 - a * BALL_GAP) % n;
+        if (idx < 0) idx += n;
+        s->x[i] = t->centerline[4 * idx];
+        s->y[i] = t->centerline[4 * idx + 1];
+        s->theta[i] = t->centerline[4 * idx + 2];
+        sincos32(s->theta[i], &s->st[i], &s->ct[i]);
+        float pr = progress_at(t, s->x[i], s->y[i]);
+        pr = pr < 0.0f ? 0.0f : pr;
+        s->progress[i] = pr;
+        const int cp = (int)(pr * (float)N_CP);
+        s->cp[i] = cp < N_CP - 1 ? cp : N_CP - 1;
+        s->v[i] = s->delta[i] = s->omega[i] = s->accel[i] = 0.0f;
+        s->wall[i] = s->opp[i] = s->wrong[i] = s->done[i] = s->trunc[i] = 0;
+        s->lap[i] = 1;
+        s->fresh[i] = 1;
+    }
+    s->steps[e] = 0;
+    s->agent_steps[e] = 0;
+}
+
+static void store_results(const oc_cfg *c, oc_state *s, int e) {
+    const int A = c->cars_per_env;
+    const float time = (float)s->steps[e] * DT;
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        s->discount[i] = 1.0f - (float)s->done[i];
+        s->progress_total[i] = (float)(s->lap[i] - 1) + s->progress[i];
+        s->time[i] = time;
+        s->out_progress[i] = s->progress[i];
+        s->out_lap[i] = s->lap[i];
+        s->out_cp[i] = s->cp[i];
+        s->out_done[i] = s->done[i];
+        s->out_trunc[i] = s->trunc[i];
+        s->out_wall[i] = s->wall[i];
+        s->out_opp[i] = s->opp[i];
+        s->out_wrong[i] = s->wrong[i];
+    }
+}
+
+void oc_reset(const oc_track *t, const oc_cfg *c, oc_state *s, const uint8_t *mask) {
+    for (int e = 0; e < c->num_envs; ++e) {
+        if (mask && !mask[e]) continue;
+        reset_env(t, c, s, e);
+        for (int a = 0; a < c->cars_per_env; ++a) {
+            const int i = e * c->cars_per_env + a;
+            s->reward[i] = 0.0f;
+            s->action[2 * i] = s->action[2 * i + 1] = 0.0f;
+        }
+        store_results(c, s, e);
+    }
+}
+
+static int wall_hit(const oc_track *t, const oc_state *s, int i) {
+    int hit = 0;
+    for (int k = 0; k < N_FOOT; ++k) {
+        const float fx = t->foot[2 * k], fy = t->foot[2 * k + 1];
+        const float wx = s->x[i] + (fx * s->ct[i] - fy * s->st[i]);
+        const float wy = s->y[i] + (fx * s->st[i] + fy * s->ct[i]);
+        int ix, iy;
+        cell_of(t, wx, wy, &ix, &iy);
+        hit |= inb(t, ix, iy) ? t->occ[(size_t)iy * t->w + ix] : 1;
+    }
+    return hit;
+}
+
+static int obb_overlap(const oc_state *s, int a, int b) {
+    const float ax = s->x[a] + BOX_CX * s->ct[a], ay = s->y[a] + BOX_CX * s->st[a];
+    const float bx = s->x[b] + BOX_CX * s->ct[b], by = s->y[b] + BOX_CX * s->st[b];
+    const float dx = bx - ax, dy = by - ay;
+    const float c = fabsf(s->ct[a] * s->ct[b] + s->st[a] * s->st[b]);
+    const float sn = fabsf(s->st[a] * s->ct[b] - s->ct[a] * s->st[b]);
+    const float ra = BOX_HL + (BOX_HL * c + BOX_HW * sn);
+    const float rb = BOX_HW + (BOX_HL * sn + BOX_HW * c);
+    int sep = fabsf(dx * s->ct[a] + dy * s->st[a]) > ra;
+    sep |= fabsf(dy * s->ct[a] - dx * s->st[a]) > rb;
+    sep |= fabsf(dx * s->ct[b] + dy * s->st[b]) > ra;
+    sep |= fabsf(dy * s->ct[b] - dx * s->st[b]) > rb;
+    return !sep;
+}
+
+/* One agent step (up to `repeat` sub-steps) for envs [e0, e1). */
+void oc_step_range(const oc_track *t, const oc_cfg *c, oc_state *s, const float *actions, int repeat, int e0, int e1) {
+    const int A = c->cars_per_env;
+    for (int e = e0; e < e1; ++e) {
+        float motor[MAX_CARS], steer[MAX_CARS];
+        int any_done = 0;
+        for (int a = 0; a < A; ++a) {
+            const int i = e * A + a;
+            const float a0 = actions[2 * i], a1 = actions[2 * i + 1];
+            s->action[2 * i] = a0;
+            s->action[2 * i + 1] = a1;
+            float m = a0, st = a1;
+            if (c->remap_actions) {
+                m = ((a0 + 1.0f) * 0.5f) * (c->act_hi[0] - c->act_lo[0]) + c->act_lo[0];
+                st = ((a1 + 1.0f) * 0.5f) * (c->act_hi[1] - c->act_lo[1]) + c->act_lo[1];
+            }
+            motor[a] = clampf(m, -1.0f, 1.0f);
+            steer[a] = clampf(st, -1.0f, 1.0f);
+            any_done |= s->done[i];
+            s->reward[i] = 0.0f;
+            s->fresh[i] = 0;
+        }
+        if (!any_done) {
+            for (int sub = 0; sub < repeat; ++sub) {
+                for (int a = 0; a < A; ++a) {
+                    const int i = e * A + a;
+                    const float m = motor[a];
+                    const float v_t = m >= 0.0f ? MAX_VEL : 0.0f;
+                    const float dv_max = (fabsf(m) * ACCEL_MAX) * DT;
+                    const float dv = clampf(v_t - s->v[i], -dv_max, dv_max);
+                    const float v = s->v[i] + dv;
+                    const float dd = clampf(steer[a] * MAX_STEER - s->delta[i], -STEER_STEP, STEER_STEP);
+                    const float dl = s->delta[i] + dd;
+                    float sd, cd;
+                    sincos32(dl, &sd, &cd);
+                    const float om = (v / WHEELBASE) * (sd / cd);
+                    s->x[i] = s->x[i] + (v * s->ct[i]) * DT;
+                    s->y[i] = s->y[i] + (v * s->st[i]) * DT;
+                    float th = s->theta[i] + om * DT;
+                    th = th > PI_F ? th - TWO_PI_F : th;
+                    th = th < -PI_F ? th + TWO_PI_F : th;
+                    s->theta[i] = th;
+                    sincos32(th, &s->st[i], &s->ct[i]);
+                    s->v[i] = v; s->delta[i] = dl; s->omega[i] = om;
+                    s->accel[i] = dv * INV_DT;
+                }
+                s->steps[e] += 1;
+                for (int a = 0; a < A; ++a) {
+                    s->wall[e * A + a] = (uint8_t)wall_hit(t, s, e * A + a);
+                    s->opp[e * A + a] = 0;
+                }
+                for (int a = 0; a < A; ++a)
+                    for (int b = a + 1; b < A; ++b) {
+                        const int o = obb_overlap(s, e * A + a, e * A + b);
+                        s->opp[e * A + a] |= (uint8_t)o;
+                        s->opp[e * A + b] |= (uint8_t)o;
+                    }
+                const float time = (float)s->steps[e] * DT;
+                int stop = 0;
+                for (int a = 0; a < A; ++a) {
+                    const int i = e * A + a;
+                    float p_new = progress_at(t, s->x[i], s->y[i]);
+                    const float p_old = s->progress[i];
+                    const int lap_old = s->lap[i], cp_old = s->cp[i];
+                    p_new = p_new >= 0.0f ? p_new : p_old;
+                    int cp_new = (int)(p_new * (float)N_CP);
+                    cp_new = cp_new < N_CP - 1 ? cp_new : N_CP - 1;
+                    int d = cp_new - cp_old;
+                    d = d < 0 ? d + N_CP : d;
+                    const int fwd = d > 0 && d <= N_CP / 2, bwd = d > N_CP / 2;
+                    const int lap = lap_old + ((fwd && cp_new < cp_old) ? 1 : 0) - ((bwd && cp_new > cp_old) ? 1 : 0);
+                    s->wrong[i] = fwd ? 0 : (bwd ? 1 : s->wrong[i]);
+                    s->cp[i] = (fwd || bwd) ? cp_new : cp_old;
+                    s->lap[i] = lap;
+                    s->progress[i] = p_new;
+                    const int collided = s->wall[i] | s->opp[i];
+                    float r;
+                    int done;
+                    if (c->task == 0) {
+                        const float delta = (float)(lap - lap_old) + (p_new - p_old);
+                        r = delta * PROGRESS_REWARD + (collided ? c->collision_reward : 0.0f);
+                        done = (collided && c->terminate_on_collision) || lap > c->laps || time > c->time_limit;
+                    } else {
+                        r = s->wall[i] ? -1.0f : -exp32(fabsf(steer[a]) - s->v[i]);
+                        done = 0;
+                    }
+                    s->reward[i] = s->reward[i] + r;
+                    s->done[i] = (uint8_t)done;
+                    stop |= done;
+                }
+                if (stop) break;
+            }
+            s->agent_steps[e] += 1;
+            if (c->time_limit_steps > 0 && s->agent_steps[e] >= c->time_limit_steps)
+                for (int a = 0; a < A; ++a) { s->done[e * A + a] = 1; s->trunc[e * A + a] = 1; }
+        }
+        store_results(c, s, e);
+        if (c->auto_reset) {
+            int fin = 0;
+            for (int a = 0; a < A; ++a) fin |= s->done[e * A + a];
+            if (fin) reset_env(t, c, s, e);
+        }
+    }
+}
+
+static float ray_vs_car(float lx, float ly, float dx, float dy, float ox, float oy, float ct2, float st2) {
+    const float cx = ox + BOX_CX * ct2, cy = oy + BOX_CX * st2;
+    const float rx = lx - cx, ry = ly - cy;
+    const float p[2] = {rx * ct2 + ry * st2, ry * ct2 - rx * st2};
+    const float e[2] = {dx * ct2 + dy * st2, dy * ct2 - dx * st2};
+    const float h[2] = {BOX_HL, BOX_HW};
+    float tn = -INFINITY, tf = INFINITY;
+    int miss = 0;
+    for (int k = 0; k < 2; ++k) {
+        if (e[k] != 0.0f) {
+            const float inv = 1.0f / e[k];
+            const float t1 = (-h[k] - p[k]) * inv, t2 = (h[k] - p[k]) * inv;
+            const float lo = t1 < t2 ? t1 : t2, hi = t1 < t2 ? t2 : t1;
+            tn = lo > tn ? lo : tn;
+            tf = hi < tf ? hi : tf;
+        } else {
+            miss |= fabsf(p[k]) > h[k];
+        }
+    }
+    const int hit = !miss && tn <= tf && tf >= 0.0f;
+    const float tt = tn > 0.0f ? tn : 0.0f;
+    return (hit && tt < MAX_RANGE) ? tt : INFINITY;
+}
+
+static float cast_ray(const oc_track *t, float gx, float gy, float dx, float dy) {
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    if (!inb(t, ix, iy) || t->occ[(size_t)iy * t->w + ix]) return 0.0f;
+    const float idx = dx != 0.0f ? 1.0f / dx : 0.0f, idy = dy != 0.0f ? 1.0f / dy : 0.0f;
+    const int sx = dx > 0.0f ? 1 : -1, sy = dy > 0.0f ? 1 : -1;
+    float bx = (float)(ix + (dx > 0.0f ? 1 : 0)), by = (float)(iy + (dy > 0.0f ? 1 : 0));
+    float tx = dx != 0.0f ? (bx - gx) * idx : INFINITY;
+    float ty = dy != 0.0f ? (by - gy) * idy : INFINITY;
+    for (;;) {
+        const int stepx = tx < ty;
+        const float tt = stepx ? tx : ty;
+        if (tt >= t->tmax) return MAX_RANGE;
+        if (stepx) { ix += sx; bx += (float)sx; tx = (bx - gx) * idx; }
+        else       { iy += sy; by += (float)sy; ty = (by - gy) * idy; }
+        const size_t c = (size_t)iy * t->w + ix;
+        if (t->occ[c]) return t->ring[c] ? MAX_RANGE : tt * t->res;
+    }
+}
+
+/* LiDAR scans of cars [c0, c1). */
+void oc_raycast_range(const oc_track *t, const oc_cfg *c, const oc_state *s, float *lidar, int c0, int c1) {
+    const int A = c->cars_per_env;
+    for (int car = c0; car < c1; ++car) {
+        const float ct = s->ct[car], st = s->st[car];
+        const float lx = s->x[car] + LIDAR_X * ct, ly = s->y[car] + LIDAR_X * st;
+        const float gx = (lx - t->org_x) * t->inv_res, gy = (ly - t->org_y) * t->inv_res;
+        for (int b = 0; b < N_BEAMS; ++b) {
+            const float cb = t->beams[2 * b], sb = t->beams[2 * b + 1];
+            const float dx = ct * cb - st * sb, dy = st * cb + ct * sb;
+            float rng = cast_ray(t, gx, gy, dx, dy);
+            if (A > 1) {
+                const int env = car / A;
+                for (int o = 0; o < A; ++o) {
+                    const int oc = env * A + o;
+                    if (oc == car) continue;
+                    const float tc = ray_vs_car(lx, ly, dx, dy, s->x[oc], s->y[oc], s->ct[oc], s->st[oc]);
+                    rng = tc < rng ? tc : rng;
+                }
+            }
+            lidar[(size_t)car * N_BEAMS + b] = rng;
+        }
+    }
+}
+
+/* lidar_occupancy patches of cars [c0, c1). */
+void oc_patch_range(const oc_track *t, const oc_state *s, uint8_t *patch, int c0, int c1) {
+    for (int car = c0; car < c1; ++car) {
+        uint8_t *out = patch + (size_t)car * PATCH * PATCH;
+        if (s->fresh[car]) { memset(out, 0, PATCH * PATCH); continue; }
+        const float ct = s->ct[car], st = s->st[car], x = s->x[car], y = s->y[car];
+        for (int row = 0; row < PATCH; ++row)
+            for (int col = 0; col < PATCH; ++col) {
+                int cnt = 0;
+                for (int j = 0; j < 2; ++j) {
+                    const float yb = -(((float)(2 * row + j) * 0.5f + (0.25f - 32.0f)) * PATCH_PX);
+                    for (int i = 0; i < 2; ++i) {
+                        const float xb = ((float)(2 * col + i) * 0.5f + (0.25f - 32.0f)) * PATCH_PX;
+                        const float wx = x + (xb * ct - yb * st), wy = y + (xb * st + yb * ct);
+                        int ix, iy;
+                        cell_of(t, wx, wy, &ix, &iy);
+                        cnt += inb(t, ix, iy) ? t->drv[(size_t)iy * t->w + ix] : 0;
+                    }
+                }
+                out[row * PATCH + col] = cnt * 2 >= 4 ? 1 : 0;
+            }
+    }
+}
