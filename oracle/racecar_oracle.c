@@ -40,8 +40,10 @@
 #define BOX_HW 0.15f
 #define N_CP 20
 #define PROGRESS_REWARD 100.0f
-#define PATCH_PX 0.15625f
+#define PATCH_CELLS 3.125f
+#define PATCH_WINDOW 110.0f
 #define BALL_GAP 12
+#define GRID_LEAD 8
 #define PI_F 3.14159274101257324f
 #define TWO_PI_F 6.28318548202514648f
 
@@ -144,7 +146,7 @@ static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
     uint32_t r[4] = {c->first_env + (uint32_t)e, s->episode[e], 0u, 0u};
     philox4x32(r, c->seed_lo, c->seed_hi);
     s->episode[e] += 1u;
-    const int idx0 = c->reset_mode == 0 ? 0 : (int)(((uint64_t)r[0] * (uint64_t)n) >> 32);
+    const int idx0 = c->reset_mode == 0 ? BALL_GAP * (A - 1) + GRID_LEAD : (int)(((uint64_t)r[0] * (uint64_t)n) >> 32);
     for (int a = 0; a < A; ++a) {
         const int i = e * A + a;
         int idx = (idx0 - a * BALL_GAP) % n;
@@ -400,26 +402,23 @@ void oc_raycast_range(const oc_track *t, const oc_cfg *c, const oc_state *s, flo
     }
 }
 
-/* lidar_occupancy patches of cars [c0, c1). */
+/* lidar_occupancy patches of cars [c0, c1) (dreamer/wrappers.py:390-408, see racecar_oracle.py). */
 void oc_patch_range(const oc_track *t, const oc_state *s, uint8_t *patch, int c0, int c1) {
     for (int car = c0; car < c1; ++car) {
         uint8_t *out = patch + (size_t)car * PATCH * PATCH;
         if (s->fresh[car]) { memset(out, 0, PATCH * PATCH); continue; }
-        const float ct = s->ct[car], st = s->st[car], x = s->x[car], y = s->y[car];
-        for (int row = 0; row < PATCH; ++row)
+        const float ct = s->ct[car], st = s->st[car];
+        int icx, icy;
+        cell_of(t, s->x[car], s->y[car], &icx, &icy);
+        for (int row = 0; row < PATCH; ++row) {
+            const float v = -(((float)row + (0.5f - 32.0f)) * PATCH_CELLS);
             for (int col = 0; col < PATCH; ++col) {
-                int cnt = 0;
-                for (int j = 0; j < 2; ++j) {
-                    const float yb = -(((float)(2 * row + j) * 0.5f + (0.25f - 32.0f)) * PATCH_PX);
-                    for (int i = 0; i < 2; ++i) {
-                        const float xb = ((float)(2 * col + i) * 0.5f + (0.25f - 32.0f)) * PATCH_PX;
-                        const float wx = x + (xb * ct - yb * st), wy = y + (xb * st + yb * ct);
-                        int ix, iy;
-                        cell_of(t, wx, wy, &ix, &iy);
-                        cnt += inb(t, ix, iy) ? t->drv[(size_t)iy * t->w + ix] : 0;
-                    }
-                }
-                out[row * PATCH + col] = cnt * 2 >= 4 ? 1 : 0;
+                const float u = ((float)col + (0.5f - 32.0f)) * PATCH_CELLS;
+                const float ox = u * ct - v * st, oy = u * st + v * ct;
+                const int inwin = ox >= -PATCH_WINDOW && ox < PATCH_WINDOW && oy >= -PATCH_WINDOW && oy < PATCH_WINDOW;
+                const int ix = icx + (int)floorf(ox), iy = (icy + 1) + (int)floorf(oy);
+                out[row * PATCH + col] = (inwin && inb(t, ix, iy)) ? t->drv[(size_t)iy * t->w + ix] : 0;
             }
+        }
     }
 }

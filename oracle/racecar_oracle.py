@@ -66,9 +66,10 @@ BOX_HW = f32(0.15)
 N_CHECKPOINTS = 20
 PROGRESS_REWARD = f32(100.0)
 PATCH = 64
-PATCH_PX = f32(0.15625)          # 200 cells * 0.05 m / 64
-PATCH_TAPS = 2
-BALL_GAP_BINS = 12
+PATCH_CELLS = f32(3.125)         # 200 cells / 64 px      (dreamer/wrappers.py:402-405)
+PATCH_WINDOW = f32(110.0)        # neigh_size + 10 cells  (dreamer/wrappers.py:398-399)
+BALL_GAP_BINS = 12               # 1.2 m between cars of one env at reset
+GRID_LEAD_BINS = 8               # grid mode: the last car starts 0.8 m after the start line
 PI = f32(3.14159274101257324)
 TWO_PI = f32(6.28318548202514648)
 INF = f32(np.inf)
@@ -249,7 +250,7 @@ class OracleRaceEnv:
                                  self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
         self.episode[envs] += u32(1)
         if self.mode == RESET_GRID:
-            idx0 = np.zeros(envs.size, np.int64)
+            idx0 = np.full(envs.size, BALL_GAP_BINS * (self.A - 1) + GRID_LEAD_BINS, np.int64)
         else:
             idx0 = ((r0.astype(u64) * u64(n_cl)) >> u64(32)).astype(np.int64)
         for a in range(self.A):
@@ -498,22 +499,27 @@ class OracleRaceEnv:
         return np.where(hit & (t < MAX_RANGE), t, INF).astype(f32)
 
     def render_patch(self, cars=None):
-        """lidar_occupancy (H11): ego-aligned 64x64, heading = +col, 1 = drivable."""
+        """lidar_occupancy (H11, dreamer/wrappers.py:390-408): ego-aligned 64x64, heading = +col,
+        1 = drivable.  Direct inverse map of the reference's crop -> rotate -> centre-crop -> resize
+        chain: the patch is centred on the north-west corner of the car's cell (the centre of the
+        reference's [pr-110, pr+110) x [pc-110, pc+110) crop), one nearest-cell tap per output pixel
+        (3.125 cells per pixel), and taps outside that 220-cell window read 0 like the corners the
+        reference's rotation leaves empty."""
         cars = np.arange(self.NC) if cars is None else cars
-        S = PATCH_TAPS
-        sub = ((np.arange(PATCH * S, dtype=np.float64) + 0.5) / S - PATCH / 2).astype(f32)
-        xb = (sub * PATCH_PX)[None, None, :]                  # forward  -> columns
-        yb = (-(sub * PATCH_PX))[None, :, None]               # left     -> rows (row 0 = left-most)
+        sub = (np.arange(PATCH, dtype=np.float64) + 0.5 - PATCH / 2).astype(f32)
+        u = (sub * PATCH_CELLS)[None, None, :]                # forward  -> columns   [cells]
+        v = (-(sub * PATCH_CELLS))[None, :, None]             # left     -> rows (row 0 = left-most)
         out = np.zeros((cars.size, PATCH, PATCH), np.uint8)
         for k0 in range(0, cars.size, 256):
             c = cars[k0:k0 + 256]
             ct, st = self.ct[c][:, None, None], self.st[c][:, None, None]
-            wx = self.x[c][:, None, None] + (xb * ct - yb * st)
-            wy = self.y[c][:, None, None] + (xb * st + yb * ct)
-            ix, iy = self._cell(wx, wy)
-            v = self._lookup(self.drv, ix, iy, False)
-            cnt = v.reshape(c.size, PATCH, S, PATCH, S).sum(axis=(2, 4))
-            img = (cnt * 2 >= S * S).astype(np.uint8)
+            icx, icy = self._cell(self.x[c], self.y[c])
+            ox = u * ct - v * st
+            oy = u * st + v * ct
+            inwin = (ox >= -PATCH_WINDOW) & (ox < PATCH_WINDOW) & (oy >= -PATCH_WINDOW) & (oy < PATCH_WINDOW)
+            ix = icx[:, None, None] + np.floor(ox).astype(i32)
+            iy = (icy[:, None, None] + 1) + np.floor(oy).astype(i32)
+            img = (self._lookup(self.drv, ix, iy, False) & inwin).astype(np.uint8)
             img[self.fresh[c].astype(bool)] = 0               # dreamer/wrappers.py:413
             out[k0:k0 + 256] = img
         return out

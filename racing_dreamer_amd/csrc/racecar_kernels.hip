@@ -85,7 +85,7 @@ __device__ __forceinline__ void reset_env(const RcParams &p, int e, Car (&car)[A
     const rcd::u32x4 r = rcd::philox4x32(g, ep, 0u, 0u, p.seed_lo, p.seed_hi);
     p.st.episode[e] = ep + 1u;
     const int n = t.n_centerline;
-    const int idx0 = p.reset_mode == 0 ? 0 : (int)__umulhi(r.x, (uint32_t)n);
+    const int idx0 = p.reset_mode == 0 ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r.x, (uint32_t)n);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         int idx = (idx0 - a * RCS_BALL_GAP_BINS) % n;
@@ -432,9 +432,11 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
     }
 }
 
-// lidar_occupancy (H11): ego-aligned 64x64 patch of the drivable area, heading = +col, car at the
-// centre, 0.15625 m per pixel, 2x2 taps per pixel, 1 = drivable.  One lane renders 4 adjacent
-// pixels of a row and stores them as one 32-bit word.
+// lidar_occupancy (H11, dreamer/wrappers.py:390-408): ego-aligned 64x64 patch of the drivable area,
+// heading = +col, 3.125 cells per pixel, 1 = drivable.  Direct inverse map of the reference's
+// crop -> rotate -> centre-crop -> resize chain: centred on the north-west corner of the car's cell,
+// one nearest-cell tap per pixel, taps outside the reference's 220-cell crop window read 0.
+// One lane renders 4 adjacent pixels of a row and stores them as one 32-bit word.
 __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_quads) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
@@ -449,27 +451,21 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_qu
         uint32_t word = 0;
         if (!p.st.fresh[car]) {               // reset observation is all zeros, dreamer/wrappers.py:413
             const float ct = p.st.ct[car], st = p.st.st[car];
-            const float x = p.st.x[car], y = p.st.y[car];
+            int icx, icy;
+            cell_of(t, p.st.x[car], p.st.y[car], icx, icy);
+            const float v = -(((float)row + (0.5f - 32.0f)) * RCS_PATCH_CELLS);
+            const float vst = v * st, vct = v * ct;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                int cnt = 0;
-#pragma unroll
-                for (int j = 0; j < RCS_PATCH_TAPS; ++j) {
-                    const float subr = (float)(2 * row + j) * 0.5f + (0.25f - 32.0f);
-                    const float yb = -(subr * RCS_PATCH_PX);
-#pragma unroll
-                    for (int i = 0; i < RCS_PATCH_TAPS; ++i) {
-                        const float subc = (float)(2 * (c0 + k) + i) * 0.5f + (0.25f - 32.0f);
-                        const float xb = subc * RCS_PATCH_PX;
-                        const float wx = x + (xb * ct - yb * st);
-                        const float wy = y + (xb * st + yb * ct);
-                        int ix, iy;
-                        cell_of(t, wx, wy, ix, iy);
-                        const bool inb = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
-                        cnt += inb ? bit_at(lds_words, t.pitch, ix, iy) : 0;
-                    }
-                }
-                word |= (cnt * 2 >= RCS_PATCH_TAPS * RCS_PATCH_TAPS ? 1u : 0u) << (8 * k);
+                const float u = ((float)(c0 + k) + (0.5f - 32.0f)) * RCS_PATCH_CELLS;
+                const float ox = u * ct - vst;
+                const float oy = u * st + vct;
+                const bool inwin = ox >= -RCS_PATCH_WINDOW && ox < RCS_PATCH_WINDOW && oy >= -RCS_PATCH_WINDOW &&
+                                   oy < RCS_PATCH_WINDOW;
+                const int ix = icx + (int)floorf(ox), iy = (icy + 1) + (int)floorf(oy);
+                const bool ok = inwin && (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+                const uint32_t bit = ok ? (uint32_t)bit_at(lds_words, t.pitch, ix, iy) : 0u;
+                word |= bit << (8 * k);
             }
         }
         out32[q] = word;

@@ -16,9 +16,10 @@
 #define RCS_BOX_HW 0.15f          // half width
 #define RCS_N_CHECKPOINTS 20
 #define RCS_PROGRESS_REWARD 100.0f
-#define RCS_PATCH_PX 0.15625f     // 200 cells * 0.05 m / 64 px   (dreamer/wrappers.py:374-378,398-405)
-#define RCS_PATCH_TAPS 2
-#define RCS_BALL_GAP_BINS 12
+#define RCS_PATCH_CELLS 3.125f    // 200 cells / 64 px            (dreamer/wrappers.py:402-405)
+#define RCS_PATCH_WINDOW 110.0f   // neigh_size + 10 cells        (dreamer/wrappers.py:398-399)
+#define RCS_BALL_GAP_BINS 12      // 1.2 m between the cars of one env at reset
+#define RCS_GRID_LEAD_BINS 8      // grid mode: the last car starts 0.8 m after the start line
 #define RCS_N_FOOTPRINT 34
 #define RCS_PI 3.14159274101257324f
 #define RCS_TWO_PI 6.28318548202514648f

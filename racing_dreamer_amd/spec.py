@@ -37,13 +37,14 @@ TASK_MAX_PROGRESS, TASK_MAX_SPEED = 0, 1
 
 # --- lidar_occupancy patch (dreamer/wrappers.py:374-378,398-405) --------------------
 PATCH = 64
-PATCH_WINDOW_CELLS = 200      # 2 * neigh_size
-PATCH_TAPS = 2                # sub-samples per axis per output pixel               (free)
+PATCH_WINDOW_CELLS = 200      # 2 * neigh_size -> 3.125 cells per output pixel
+PATCH_CROP_HALF = 110         # neigh_size + 10: taps outside this window read 0
 
 # --- reset modes (dreamer/dream.py:105-108,120) --------------------------------------
 RESET_GRID, RESET_RANDOM, RESET_RANDOM_BALL = 0, 1, 2
 RESET_MODES = {"grid": RESET_GRID, "random": RESET_RANDOM, "random_ball": RESET_RANDOM_BALL}
 BALL_GAP_BINS = 12            # centerline bins (0.1 m each) between cars           (free)
+GRID_LEAD_BINS = 8            # grid reset: last car 0.8 m after the start line     (free)
 
 # --- action remap (dreamer/dream.py:138) ---------------------------------------------
 ACTION_LOW = (0.005, -1.0)

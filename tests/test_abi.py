@@ -1,0 +1,101 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/racecar_hip.h declares.
+No compute call is made here (there is no GPU); error paths that do not need a device are exercised."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "racecar_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rc_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(hip_lib):
+    from racing_dreamer_amd import _lib
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(hip_lib, name), f"{name} declared in racecar_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == declared, "ctypes binding and header disagree"
+    assert hip_lib.rc_abi_version() == 1
+
+
+def test_config_struct_matches_header(hip_lib):
+    from racing_dreamer_amd import _lib
+    cfg = _lib.RcConfig()
+    hip_lib.rc_default_config(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(_lib.RcConfig)
+    # defaults = dreamer/scenarios/max_progress/columbia.yml:10 and dream.py:138
+    assert (cfg.laps, cfg.time_limit, cfg.terminate_on_collision, cfg.collision_reward) == (10, 180.0, 1, -1.0)
+    assert np.allclose(list(cfg.action_low), [0.005, -1.0]) and list(cfg.action_high) == [1.0, 1.0]
+    assert cfg.num_envs == 1 and cfg.cars_per_env == 1
+
+
+def test_arena_layout_is_the_trajectory_record(hip_lib):
+    from racing_dreamer_amd import _lib, spec
+    cfg = _lib.RcConfig()
+    hip_lib.rc_default_config(C.byref(cfg))
+    cfg.num_envs = 65536
+    per_car = hip_lib.rc_arena_bytes(C.byref(cfg)) / 65536
+    assert 4 * spec.RECORD_FLOATS == 4396                       # dreamer/wrappers.py:213-219 record
+    assert 4396 <= per_car <= 4396 + 40                         # record + flags/info, no padding waste
+    cfg.obs_type = 1
+    assert hip_lib.rc_arena_bytes(C.byref(cfg)) / 65536 - per_car == 4096
+
+
+def test_spec_tables_match_python_spec(hip_lib):
+    from racing_dreamer_amd import spec
+    beams = np.zeros((1080, 2), np.float32)
+    foot = np.zeros((34, 2), np.float32)
+    hip_lib.rc_spec_tables(beams.ctypes.data, foot.ctypes.data)
+    assert np.array_equal(beams, spec.beam_table())
+    assert np.array_equal(foot, spec.footprint_table())
+    # beam 0 at +135 deg, clockwise sweep to -135 deg (dreamer/tools.py:84-86)
+    ang = np.degrees(np.arctan2(beams[:, 1], beams[:, 0]))
+    assert abs(ang[0] - 135) < 1e-4 and abs(ang[-1] + 135) < 1e-4 and np.all(np.diff(ang) < 0)
+
+
+def test_errors_are_codes_with_messages_not_exceptions(hip_lib):
+    from racing_dreamer_amd import _lib
+    cfg = _lib.RcConfig()
+    hip_lib.rc_default_config(C.byref(cfg))
+    h = C.c_void_p()
+    cfg.cars_per_env = 9
+    assert hip_lib.rc_create(C.byref(cfg), C.byref(h)) == -1 and b"cars_per_env" in hip_lib.rc_last_error()
+    cfg.cars_per_env = 1
+    cfg.struct_size = 8
+    assert hip_lib.rc_create(C.byref(cfg), C.byref(h)) == -1 and b"ABI mismatch" in hip_lib.rc_last_error()
+    assert hip_lib.rc_step(None, None, 1) == -1
+    assert hip_lib.rc_sync(None) == -1
+    assert h.value is None
+
+
+def test_product_never_imports_the_oracle():
+    """The product path must not route through the oracle (or any CPU fallback)."""
+    pkg = os.path.join(ROOT, "racing_dreamer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "libracecar_oracle" not in src and "c_oracle" not in src and "import_module" not in src, f
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from racing_dreamer_amd import _lib
+    saved = _lib._lib
+    _lib._lib = None
+    try:
+        try:
+            _lib.load_library(str(tmp_path / "nope.so"))
+            raised = False
+        except _lib.RacecarHipError as e:
+            raised = "no CPU fallback" in str(e)
+        assert raised
+    finally:
+        _lib._lib = saved

@@ -1,0 +1,101 @@
+"""Multi-GPU host logic on CPU: env sharding and the trajectory all-gather over gloo, world_size 2."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_envs_partition():
+    from racing_dreamer_amd.distributed import shard_envs
+    for total, world in ((524288, 8), (65536, 1), (10, 3), (7, 7)):
+        shards = [shard_envs(total, r, world) for r in range(world)]
+        assert shards[0].first_env == 0 and sum(s.num_envs for s in shards) == total
+        for a, b in zip(shards[:-1], shards[1:]):
+            assert a.first_env + a.num_envs == b.first_env
+        assert max(s.num_envs for s in shards) - min(s.num_envs for s in shards) <= 1
+    with pytest.raises(ValueError):
+        shard_envs(3, 0, 4)
+    with pytest.raises(ValueError):
+        shard_envs(8, 8, 8)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_envs, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from helpers import make_oracle
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.distributed import TrajectoryGather, shard_envs, slab_field_views
+    from racing_dreamer_amd.track_assets import synthetic_track
+    track = synthetic_track()
+    sh = shard_envs(total_envs, rank, world)
+    env = make_oracle(track, num_envs=sh.num_envs, auto_reset=True, first_env=sh.first_env)
+    env.reset(mode=ro.RESET_RANDOM, seed=4)
+
+    def slab_of(out, n):       # same byte layout as rc_trajectory_slab (sections 64-byte aligned)
+        parts = []
+        for key in ("lidar", "pose", "velocity", "speed", "action", "reward", "discount", "progress_total", "time"):
+            b = np.ascontiguousarray(out[key], np.float32).tobytes()
+            parts.append(b + b"\0" * ((-len(b)) % 64))
+        raw = b"".join(parts)
+        return torch.frombuffer(bytearray(raw[:len(raw) - ((-len(b)) % 64)]), dtype=torch.uint8)
+
+    gather = None
+    last = None
+    for k in range(3):
+        act = ro.random_actions(1, k, sh.num_envs, first_car=sh.first_env)
+        out = env.step(act)
+        slab = slab_of(out, sh.num_envs)
+        if gather is None:
+            gather = TrajectoryGather(slab)
+        gather.launch(slab)            # overlaps with the next step
+        last = out
+    g = gather.wait()
+    views = [slab_field_views(g[r], sh.num_envs, False) for r in range(world)]
+    lidar = torch.cat([v["lidar"] for v in views]).numpy()
+    reward = torch.cat([v["reward"] for v in views]).numpy()
+    mine = slice(sh.first_env, sh.first_env + sh.num_envs)
+    ok = np.array_equal(lidar[mine], last["lidar"]) and np.array_equal(reward[mine], last["reward"])
+    q.put((rank, ok, lidar, reward))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_equals_single_rank_run():
+    """world_size 2 over gloo: the gathered buffer equals the unsharded job (global-id RNG streams)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import make_oracle
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.track_assets import synthetic_track
+    total = 12
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = make_oracle(synthetic_track(), num_envs=total, auto_reset=True)
+    ref.reset(mode=ro.RESET_RANDOM, seed=4)
+    for k in range(3):
+        out = ref.step(ro.random_actions(1, k, total))
+    for rank, ok, lidar, reward in results:
+        assert ok
+        assert np.array_equal(lidar, out["lidar"]) and np.array_equal(reward, out["reward"])

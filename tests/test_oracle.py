@@ -1,0 +1,242 @@
+"""The CPU oracle itself: published known answers, hand-derived known answers, properties, and the
+C restatement pinned bit-for-bit to the NumPy one."""
+import numpy as np
+import pytest
+
+from helpers import make_oracle
+from oracle import c_oracle
+from oracle import racecar_oracle as ro
+from racing_dreamer_amd.track_assets import load_track, synthetic_track
+
+
+def test_philox4x32_10_random123_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = tuple(int(v) for v in ro.philox4x32(*ctr, *key))
+        assert got == want
+
+
+def test_sincos_and_exp_accuracy():
+    a = np.linspace(-6.6, 6.6, 400001).astype(np.float32)
+    s, c = ro.sincos32(a)
+    assert np.abs(s - np.sin(a.astype(np.float64))).max() < 2e-7
+    assert np.abs(c - np.cos(a.astype(np.float64))).max() < 2e-7
+    x = np.linspace(-8, 3, 20001).astype(np.float32)
+    assert np.max(np.abs(ro.exp32(x) / np.exp(x.astype(np.float64)) - 1)) < 2e-7
+
+
+def _box_env(n=1, size=200):
+    """Empty square room: walls only on the border, car anywhere."""
+    occ = np.zeros((size, size), bool)
+    occ[:3, :] = occ[-3:, :] = occ[:, :3] = occ[:, -3:] = True
+    drv = ~occ
+    prog = np.where(drv, 0.5, -1.0).astype(np.float32)
+    cl = np.array([[5.0, 5.0, 0.0, 0.5]], np.float32)
+    return ro.OracleRaceEnv(occ, drv, prog, cl, (0.0, 0.0), 0.05, ro.OracleConfig(num_envs=n))
+
+
+def test_raycast_known_answer_axis_aligned_walls():
+    env = _box_env()
+    env.reset()
+    # car at (5, 5) heading +x: sensor at x = 5.25.  Walls: cells 0..2 and 197..199 -> x in [9.85, 10).
+    lid = env.lidar[0]
+    beam_fwd = (ro.N_BEAMS - 1) / 2            # 539.5: no beam is exactly forward; use the side beams
+    i_left = int(round((135 - 90) / (270 / 1079)))      # beam at +90 deg
+    ang = np.deg2rad(135 - i_left * 270 / 1079)
+    want_left = (9.85 - 5.0) / np.sin(ang)               # wall face at y = 9.85
+    assert abs(lid[i_left] - want_left) < 1e-4
+    i_right = ro.N_BEAMS - 1 - i_left
+    assert abs(lid[i_right] - want_left) < 1e-4          # symmetric room -> symmetric scan
+    assert np.allclose(lid, lid[::-1], atol=1e-4)
+    # the most forward beams see the front wall at x = 9.85
+    k = 539
+    ang = np.deg2rad(135 - k * 270 / 1079)
+    assert abs(lid[k] - (9.85 - 5.25) / np.cos(ang)) < 1e-4
+    assert lid.min() > 0 and lid.max() <= 15.0
+
+
+def test_raycast_max_range_and_start_inside_wall():
+    occ = np.zeros((700, 700), bool)
+    occ[:3, :] = occ[-3:, :] = occ[:, :3] = occ[:, -3:] = True
+    env = ro.OracleRaceEnv(occ, ~occ, np.where(~occ, 0.5, -1).astype(np.float32),
+                           np.array([[17.5, 17.5, 0.0, 0.5], [0.05, 17.5, 0.0, 0.5]], np.float32),
+                           (0.0, 0.0), 0.05, ro.OracleConfig(num_envs=1))
+    env.reset()
+    assert np.all(env.lidar[0] == np.float32(15.0))      # nearest wall 17.35 m away: no return
+    env.x[:], env.y[:] = -0.2, 17.5                      # sensor at x = 0.05: inside the wall cells
+    assert np.all(env.raycast()[0] == 0.0)
+
+
+def test_bicycle_known_answer_circle_arc():
+    """Constant speed and steering -> circle of radius L / tan(delta) (explicit Euler, dt = 0.01)."""
+    env = _box_env(size=600)
+    env.centerline[0, :2] = 15.0
+    env.reset()
+    env.v[:] = 2.0
+    env.delta[:] = 0.3
+    act = np.array([[0.0, 0.3 / 0.42]], np.float32)      # motor 0 keeps |dv| <= 0, steering holds delta
+    env.v[:] = 2.0
+    r = 0.3302 / np.tan(0.3)
+    x0, y0, th0 = float(env.x[0]), float(env.y[0]), float(env.theta[0])
+    n = 200
+    for _ in range(n):
+        env.v[:] = 2.0                                    # hold speed (motor = 0 would brake)
+        env.step(act)
+    th = th0 + 2.0 / r * 0.01 * n
+    cx, cy = x0 - r * np.sin(th0), y0 + r * np.cos(th0)
+    want = (cx + r * np.sin(th), cy - r * np.cos(th))
+    assert abs(float(env.x[0]) - want[0]) < 0.02 and abs(float(env.y[0]) - want[1]) < 0.02
+    assert abs(((float(env.theta[0]) - th + np.pi) % (2 * np.pi)) - np.pi) < 1e-3
+
+
+def test_longitudinal_model_limits():
+    env = _box_env(size=2000)
+    env.centerline[0, :2] = (5.0, 50.0)
+    env.reset()
+    full = np.array([[1.0, 0.0]], np.float32)
+    for k in range(200):
+        out = env.step(full)
+    assert out["speed"][0] == np.float32(5.0)             # saturates at max_velocity after 1.25 s
+    assert abs(out["pose"][0, 0] - (5.0 + 0.5 * 4 * 1.25 ** 2 + 5.0 * 0.75)) < 0.05
+    brake = np.array([[-1.0, 0.0]], np.float32)
+    for k in range(130):
+        out = env.step(brake)
+    assert out["speed"][0] == 0.0                         # negative motor = brake to standstill, never reverse
+
+
+def test_progress_lap_and_reward_over_a_scripted_lap():
+    t = synthetic_track()
+    env = make_oracle(t, num_envs=1, laps=1)
+    p0 = float(env.reset()["progress_total"][0])
+    total, laps_seen, prog = 0.0, [], []
+    for k in range(len(t.centerline) + 5):                # teleport along the centerline, one bin per step
+        i = (k + ro.GRID_LEAD_BINS + 1) % len(t.centerline)
+        env.x[:], env.y[:], env.theta[:] = t.centerline[i, 0], t.centerline[i, 1], t.centerline[i, 2]
+        env.st[:], env.ct[:] = ro.sincos32(env.theta)
+        env.v[:] = 0.0
+        out = env.step(np.zeros((1, 2), np.float32))
+        total += float(out["reward"][0])
+        laps_seen.append(int(out["lap"][0]))
+        prog.append(float(out["progress_total"][0]))
+        if out["done"][0]:
+            break
+    assert laps_seen[0] == 1 and laps_seen[-1] == 2 and out["done"][0] == 1      # lap > laps ends the episode
+    assert not out["wrong_way"][0]
+    assert np.all(np.diff(prog) > -1e-6)                                          # monotone through the line
+    assert abs(total - 100.0 * (prog[-1] - p0)) < 0.2          # reward = 100 * delta progress
+
+
+def test_wrong_way_flag():
+    t = synthetic_track()
+    env = make_oracle(t, num_envs=1)
+    env.reset()
+    n = len(t.centerline)
+    for k in range(1, n // 3):
+        i = (-k * 3) % n
+        env.x[:], env.y[:] = t.centerline[i, 0], t.centerline[i, 1]
+        out = env.step(np.zeros((1, 2), np.float32))
+    assert out["wrong_way"][0] == 1 and out["lap"][0] <= 1
+
+
+def test_collision_terminates_with_collision_reward():
+    t = synthetic_track()
+    env = make_oracle(t, num_envs=1)
+    env.reset()
+    out = None
+    for _ in range(400):
+        out = env.step(np.array([[1.0, 1.0]], np.float32))    # full throttle, full left lock
+        if out["done"][0]:
+            break
+    assert out["done"][0] == 1 and out["wall_collision"][0] == 1 and out["discount"][0] == 0.0
+    assert out["reward"][0] < -0.9                             # collision_reward -1 dominates one step's progress
+    frozen = env.step(np.array([[1.0, 0.0]], np.float32))      # finished env without auto-reset is frozen
+    assert frozen["reward"][0] == 0.0 and frozen["done"][0] == 1
+    assert np.array_equal(frozen["pose"], out["pose"])
+
+
+def test_step_before_reset_raises():
+    env = make_oracle(synthetic_track(), num_envs=2)
+    with pytest.raises(AssertionError, match="Must reset environment."):
+        env.step(np.zeros((2, 2), np.float32))
+
+
+@pytest.mark.parametrize("cars,occ,mode", [(1, True, ro.RESET_RANDOM), (2, False, ro.RESET_RANDOM_BALL),
+                                           (4, False, ro.RESET_GRID)])
+def test_c_oracle_is_bit_identical_to_numpy_oracle(cars, occ, mode):
+    t = load_track("treitlstrasse_v2")
+    cfg = ro.OracleConfig(num_envs=40, cars_per_env=cars, auto_reset=True, render_occupancy=occ,
+                          time_limit_steps=17, remap_actions=(cars == 1))
+    a = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg)
+    b = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=3)
+    oa, ob = a.reset(mode=mode, seed=5), b.reset(mode=mode, seed=5)
+    dones = 0
+    for k in range(30):
+        act = ro.random_actions(3, k, 40 * cars)
+        assert np.array_equal(act, b.random_actions(3, k))
+        oa, ob = a.step(act, repeat=3), b.step(act, repeat=3)
+        for key in oa:
+            assert np.array_equal(oa[key], ob[key]), (key, k)
+        dones += int(oa["done"].sum())
+    assert dones > 0
+
+
+def test_c_oracle_max_speed_task_matches():
+    t = load_track("columbia")
+    cfg = ro.OracleConfig(num_envs=16, task=ro.TASK_MAX_SPEED)
+    a = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg)
+    b = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg)
+    a.reset(mode=1, seed=2), b.reset(mode=1, seed=2)
+    for k in range(10):
+        act = ro.random_actions(9, k, 16)
+        oa, ob = a.step(act, repeat=2), b.step(act, repeat=2)
+        assert np.array_equal(oa["reward"], ob["reward"]) and np.all(oa["done"] == 0)
+
+
+def test_two_cars_see_and_hit_each_other():
+    t = synthetic_track()
+    env = make_oracle(t, num_envs=1, cars_per_env=2)
+    env.reset(mode=ro.RESET_GRID)
+    # car 1 starts 1.2 m behind car 0 on the straight: its forward beams return car 0's rear (< wall distance)
+    solo = make_oracle(t, num_envs=1, cars_per_env=1)
+    solo.reset(mode=ro.RESET_GRID)
+    solo.x[:], solo.y[:], solo.theta[:] = env.x[1], env.y[1], env.theta[1]
+    solo.st[:], solo.ct[:] = ro.sincos32(solo.theta)
+    alone = solo.raycast()[0]
+    both = env.raycast()[1]
+    assert np.all(both <= alone) and (both < alone - 0.5).sum() > 10
+    gap = float(np.hypot(env.x[0] - env.x[1], env.y[0] - env.y[1]))
+    assert abs(both[538:542].min() - (gap - 0.25 - 0.10)) < 0.06       # sensor 0.25 ahead, rear overhang 0.10
+    # drive car 1 into car 0
+    hit = False
+    for _ in range(300):
+        out = env.step(np.array([[-1.0, 0.0], [1.0, 0.0]], np.float32))
+        if out["opponent_collision"].any():
+            hit = True
+            break
+    assert hit and out["opponent_collision"].tolist() == [1, 1] and out["done"].all()
+
+
+def test_auto_reset_uses_fresh_philox_counter_per_episode():
+    t = load_track("austria")
+    env = make_oracle(t, num_envs=8, auto_reset=True)
+    env.reset(mode=ro.RESET_RANDOM, seed=1)
+    starts = [env.x.copy()]
+    for k in range(3):
+        env.done[:] = 1                       # force every env to finish
+        env._reset_envs(np.arange(8))
+        starts.append(env.x.copy())
+    assert all(not np.array_equal(starts[0], s) for s in starts[1:])
+    assert np.array_equal(env.episode, np.full(8, 4, np.uint32))
+
+
+def test_sharding_independence_of_rng_streams():
+    t = load_track("austria")
+    full = make_oracle(t, num_envs=12, auto_reset=True)
+    part = make_oracle(t, num_envs=4, auto_reset=True, first_env=8)
+    a, b = full.reset(mode=1, seed=9), part.reset(mode=1, seed=9)
+    assert np.array_equal(a["pose"][8:], b["pose"])
+    assert np.array_equal(ro.random_actions(5, 3, 12)[8:], ro.random_actions(5, 3, 4, first_car=8))

@@ -1,0 +1,50 @@
+"""The three statements of the env spec constants agree: racing_dreamer_amd/spec.py (host),
+csrc/racecar_spec.h (device), oracle/ (checker, NumPy and C)."""
+import os
+import re
+
+import numpy as np
+
+from oracle import racecar_oracle as ro
+from racing_dreamer_amd import spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _defines(path, prefix=""):
+    out = {}
+    for m in re.finditer(r"#define\s+" + prefix + r"(\w+)\s+(-?[0-9.eE+-]+)f?\b", open(path).read()):
+        out[m.group(1)] = float(m.group(2))
+    return out
+
+
+def test_constants_agree():
+    dev = _defines(os.path.join(ROOT, "racing_dreamer_amd", "csrc", "racecar_spec.h"), "RCS_")
+    c = _defines(os.path.join(ROOT, "oracle", "racecar_oracle.c"))
+    f = np.float32
+    triples = [
+        ("DT", spec.DT, ro.DT, c["DT"]), ("MAX_RANGE", spec.MAX_RANGE, ro.MAX_RANGE, c["MAX_RANGE"]),
+        ("LIDAR_X", spec.LIDAR_X, ro.LIDAR_X, c["LIDAR_X"]), ("WHEELBASE", spec.WHEELBASE, ro.WHEELBASE, c["WHEELBASE"]),
+        ("MAX_STEER", spec.MAX_STEER, ro.MAX_STEER, c["MAX_STEER"]), ("MAX_VEL", spec.MAX_VEL, ro.MAX_VEL, c["MAX_VEL"]),
+        ("ACCEL_MAX", spec.ACCEL_MAX, ro.ACCEL_MAX, c["ACCEL_MAX"]),
+        ("STEER_STEP", spec.STEER_RATE * spec.DT, ro.STEER_STEP, c["STEER_STEP"]),
+        ("BOX_CX", (spec.X_FRONT + spec.X_REAR) / 2, ro.BOX_CX, c["BOX_CX"]),
+        ("BOX_HL", (spec.X_FRONT - spec.X_REAR) / 2, ro.BOX_HL, c["BOX_HL"]),
+        ("BOX_HW", spec.HALF_W, ro.BOX_HW, c["BOX_HW"]),
+        ("PROGRESS_REWARD", spec.PROGRESS_REWARD, ro.PROGRESS_REWARD, c["PROGRESS_REWARD"]),
+        ("PATCH_CELLS", spec.PATCH_WINDOW_CELLS / spec.PATCH, ro.PATCH_CELLS, c["PATCH_CELLS"]),
+        ("PATCH_WINDOW", spec.PATCH_CROP_HALF, ro.PATCH_WINDOW, c["PATCH_WINDOW"]),
+    ]
+    for name, host, ora, cval in triples:
+        assert f(host) == f(ora) == f(cval) == f(dev[name]), name
+    assert spec.N_CHECKPOINTS == ro.N_CHECKPOINTS == int(c["N_CP"]) == int(dev["N_CHECKPOINTS"])
+    assert spec.BALL_GAP_BINS == ro.BALL_GAP_BINS == int(c["BALL_GAP"]) == int(dev["BALL_GAP_BINS"])
+    assert spec.GRID_LEAD_BINS == ro.GRID_LEAD_BINS == int(c["GRID_LEAD"]) == int(dev["GRID_LEAD_BINS"])
+    assert spec.N_BEAMS == ro.N_BEAMS == 1080 and spec.N_FOOTPRINT == int(dev["N_FOOTPRINT"]) == 34
+    assert f(dev["PI"]) == ro.PI and f(dev["TWO_PI"]) == ro.TWO_PI
+
+
+def test_tables_agree():
+    cb, sb = ro.beam_table()
+    assert np.array_equal(np.stack([cb, sb], 1), spec.beam_table())
+    assert np.array_equal(ro.footprint_table(), spec.footprint_table())

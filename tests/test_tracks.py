@@ -1,0 +1,95 @@
+"""Track assets and the offline track compiler (restating docs/maps/costmaps/generate-costmap.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from racing_dreamer_amd import track_assets as ta
+from racing_dreamer_amd import track_compiler as tc
+
+REF_MAPS = "/root/reference/docs/maps/maps"
+
+
+def test_assets_present_and_sane():
+    names = ta.available_tracks()
+    for n in ("columbia", "austria", "barcelona", "treitlstrasse_v2"):       # the tracks BASELINE.json names
+        assert n in names
+    for n in names:
+        t = ta.load_track(n)
+        assert t.resolution == 0.05 and t.pitch % 2 == 1 and t.pitch * 32 >= t.width
+        assert t.bitmap_bytes <= 160 * 1024                                  # must fit the LDS of one CU
+        assert t.progress.shape == (t.height, t.width) and t.progress.max() == 1.0
+        drv, occ = t.drivable, t.occ
+        assert not (drv & occ).any()
+        assert np.all(t.progress[drv] >= 0) and np.all(t.progress[~drv] == -1)
+        # every spawn pose is drivable, clear of walls and ordered by progress
+        cl = t.centerline
+        ix = np.floor((cl[:, 0] - t.origin[0]) / 0.05).astype(int)
+        iy = np.floor((cl[:, 1] - t.origin[1]) / 0.05).astype(int)
+        assert drv[iy, ix].all() and t.edt_m[iy, ix].min() >= 0.2
+        assert np.all(np.diff(cl[:, 3]) > 0)
+
+
+def test_pack_unpack_roundtrip():
+    rng = np.random.default_rng(0)
+    m = rng.uniform(size=(37, 101)) < 0.3
+    w = ta.pack_words(m, 5)
+    assert w.shape == (37, 5) and w.dtype == np.uint32
+    assert np.array_equal(ta.unpack_words(w, 101), m)
+    assert ((w[3, 70 >> 5] >> (70 & 31)) & 1) == int(m[3, 70])              # bit i of word j = cell 32 j + i
+
+
+def test_bfs_matches_naive_dilation_restatement():
+    """The frontier BFS equals the reference's formulation: one 3x3 binary dilation per distance unit
+    (generate-costmap.py:196-208), checked on a small maze with scipy's dilation."""
+    from scipy import ndimage
+    rng = np.random.default_rng(1)
+    free = np.ones((40, 60), bool)
+    free[0, :] = free[-1, :] = free[:, 0] = free[:, -1] = False
+    free[10:30, 20:40] = False
+    free[rng.uniform(size=free.shape) < 0.04] = False
+    sc, sr = 30, 35
+    free[sr, sc - 3:sc + 3] = True
+    steps, finish, drivable, n = tc.bfs_from_start(free, sc, sr)
+    # naive restatement
+    binary = free.copy()
+    fl = np.zeros_like(free)
+    for row, st in ((sr, +1), (sr - 1, -1)):
+        while binary[row, sc - 1]:
+            binary[row, sc - 1] = False
+            fl[row, sc - 1] = True
+            row += st
+    mask = np.zeros_like(free)
+    mask[sr, sc] = True
+    dist = np.zeros(free.shape)
+    cur = 0.0
+    while True:
+        cur += 1.0
+        dil = ndimage.binary_dilation(mask, structure=np.ones((3, 3), bool))
+        new = binary & (mask ^ dil)
+        if not new.any():
+            break
+        dist[new] = cur
+        mask |= new
+    dist[fl] = cur
+    assert n == int(cur) and np.array_equal(finish, fl) and np.array_equal(drivable, mask | fl)
+    assert np.array_equal(np.where(steps < 0, 0, steps), dist.astype(int) * (mask | fl))
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MAPS), reason="reference maps only exist in the build container")
+def test_committed_assets_reproduce_from_the_reference_maps():
+    t = tc.compile_track("treitlstrasse_v2", REF_MAPS)
+    a = ta.load_track("treitlstrasse_v2")
+    assert np.array_equal(t.occ, a.occ) and np.array_equal(t.drivable, a.drivable)
+    assert t.max_steps == a.max_steps and np.array_equal(t.centerline, a.centerline)
+    # start pixel: world (0, 0) with the reference's width-flip quirk (generate-costmap.py:49-52)
+    assert tuple(t.start_px) == (1000, 999)
+    assert tc.start_pixel((350, 435), [-10.70654, -14.020793, 0.0], 0.05) == (214, 153)
+
+
+def test_synthetic_track_progress_is_a_loop():
+    t = ta.synthetic_track()
+    cl = t.centerline
+    assert len(cl) > 100
+    d = np.hypot(*(np.roll(cl[:, :2], -1, axis=0) - cl[:, :2]).T)
+    assert d.max() < 0.3                                                     # closed, evenly spaced (0.1 m bins)
