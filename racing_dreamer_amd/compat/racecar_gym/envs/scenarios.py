@@ -1,0 +1,88 @@
+"""Scenario objects built from the reference's scenario YAML files
+(dreamer/scenarios/max_progress/columbia.yml:1-10, baselines/scenarios/max_progress/columbia.yml:1-34):
+world.name, agents[].id, vehicle.sensors, task.{task_name, params}."""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Dict, List
+
+import yaml
+
+from racing_dreamer_amd.track_assets import Track, load_track
+
+from ..core.gridmaps import GridMap, full_frame, full_frame_origin
+
+DEFAULT_SENSORS = ["lidar", "pose", "velocity"]
+
+
+@dataclass
+class AgentSpec:
+    id: str
+    sensors: List[str]
+    task_name: str
+    task_params: Dict
+    color: str = "blue"
+
+
+class World:
+    """What the callers reach through `scenario.world`: `_maps['occupancy']` (dreamer/wrappers.py:376) and
+    `_config.name` (dreamer/evaluations/run_evaluation.py:48)."""
+
+    def __init__(self, track: Track):
+        self.track = track
+        self._config = SimpleNamespace(name=track.name)
+        origin = full_frame_origin(track)
+        self._maps = {
+            "occupancy": GridMap(full_frame(track, track.drivable), origin, track.resolution),
+            "progress": GridMap(full_frame(track, track.progress, fill=-1.0), origin, track.resolution),
+            "obstacle": GridMap(full_frame(track, track.edt_m), origin, track.resolution),
+        }
+
+
+def _parse(path: str):
+    with open(path) as f:
+        spec = yaml.safe_load(f)
+    world_name = spec["world"]["name"]
+    agents = []
+    for a in spec["agents"]:
+        task = a.get("task", {}) or {}
+        agents.append(AgentSpec(id=str(a["id"]), sensors=list(a.get("vehicle", {}).get("sensors", DEFAULT_SENSORS)),
+                                task_name=task.get("task_name", "maximize_progress"),
+                                task_params=dict(task.get("params", {}) or {}),
+                                color=a.get("vehicle", {}).get("color", "blue")))
+    return world_name, agents
+
+
+@dataclass
+class MultiAgentScenario:
+    world: World
+    agents: List[AgentSpec]
+    rendering: bool = False
+    path: str = ""
+
+    @staticmethod
+    def from_spec(path: str, rendering: bool = False) -> "MultiAgentScenario":
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        world_name, agents = _parse(path)
+        return MultiAgentScenario(World(load_track(world_name)), agents, rendering, path)
+
+
+@dataclass
+class SingleAgentScenario:
+    world: World
+    agent: AgentSpec
+    rendering: bool = False
+    path: str = ""
+
+    @staticmethod
+    def from_spec(path: str, rendering: bool = False) -> "SingleAgentScenario":
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        world_name, agents = _parse(path)
+        return SingleAgentScenario(World(load_track(world_name)), agents[0], rendering, path)
+
+    def as_multi(self) -> MultiAgentScenario:
+        return MultiAgentScenario(self.world, [self.agent], self.rendering, self.path)

@@ -52,6 +52,9 @@ class Dict:
     def __getitem__(self, k):
         return self.spaces[k]
 
+    def __contains__(self, x):          # gym.Space.__contains__ = "x is a valid sample of this space"
+        return isinstance(x, dict) and set(x) == set(self.spaces)
+
 
 def _flatten_space(space):
     if isinstance(space, Box):

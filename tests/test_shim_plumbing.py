@@ -1,0 +1,98 @@
+"""BASELINE.json configs[0]: 1 env, columbia, obs_type=lidar, CPU step() - plumbing, no GPU.
+
+The REFERENCE's own wrapper stack (dreamer/wrappers.py, order of dreamer/dream.py:103-140) runs unchanged
+on top of this repo's racecar_gym shim; the device backend is replaced by the CPU oracle because the build
+container has no GPU (tests/oracle_backend.py).  Needs /root/reference, so it only runs in the build
+container; the same shim is exercised against the real HIP backend by tests/test_gpu_shim.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference checkout")
+
+
+@pytest.fixture()
+def ref_wrappers(monkeypatch):
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import make_golden
+    saved = {k: sys.modules.get(k) for k in ("gym", "gym.spaces", "gym.wrappers", "racecar_gym", "racecar_gym.envs",
+                                             "racecar_gym.envs.multi_agent_race", "wrappers")}
+    make_golden.install_stubs()                      # gym names only
+    for k in [m for m in sys.modules if m == "racecar_gym" or m.startswith("racecar_gym.")]:
+        del sys.modules[k]                           # the shim provides racecar_gym, not the stub
+    from racing_dreamer_amd import compat
+    compat.install()
+    import racecar_gym.envs.multi_agent_race as mar
+    from oracle_backend import OracleBackend
+    monkeypatch.setattr(mar, "_BACKEND", OracleBackend)
+    monkeypatch.chdir(os.path.join(REF, "dreamer"))  # RaceCarBaseEnv loads "scenarios/{task}/{track}.yml"
+    sys.path.insert(0, os.path.join(REF, "dreamer"))
+    sys.modules.pop("wrappers", None)
+    import wrappers as W
+    W.envs.clear()
+    yield W
+    sys.path.remove(os.path.join(REF, "dreamer"))
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
+def test_reference_dreamer_wrapper_stack_runs_on_the_shim(ref_wrappers):
+    W = ref_wrappers
+    from agents.gap_follower import GapFollower
+    episodes = []
+    env = W.RaceCarBaseEnv(track="columbia", task="max_progress")
+    env = W.RaceCarWrapper(env, agent_id="A")
+    env = W.ActionRepeat(env, 4)
+    env = W.ReduceActionSpace(env, low=[0.005, -1.0], high=[1.0, 1.0])
+    env = W.OccupancyMapObs(env)
+    env = W.FixedResetMode(env, mode="random")
+    env = W.TimeLimit(env, 60)
+    env = W.Collect(env, [lambda eps: episodes.append(eps)], 32)
+    assert env.agent_ids == ["A"] and env.n_agents == 1
+    with pytest.raises(AssertionError, match="Must reset environment."):
+        env.step({"A": np.zeros(2)})
+    ftg = GapFollower()
+    obs = env.reset()
+    assert obs["A"]["lidar"].shape == (1080,) and obs["A"]["speed"] == 0.0
+    assert obs["A"]["lidar_occupancy"].shape == (64, 64, 1) and not obs["A"]["lidar_occupancy"].any()
+    done, steps, total = False, 0, 0.0
+    while not done:
+        act = np.clip(np.array([-0.9, ftg.action(obs["A"])[-1]]), -1, 1)      # dream.py:213-215 prefill agent
+        obs, rew, dones, info = env.step({"A": act})
+        done = any(dones.values())
+        total += rew["A"]
+        steps += 1
+        assert set(info["A"]) >= {"pose", "velocity", "lap", "progress", "time", "wrong_way", "wall_collision"}
+    assert 1 <= steps <= 60
+    ep = episodes[0][0]
+    assert sorted(ep) == sorted(["lidar", "pose", "velocity", "speed", "lidar_occupancy", "action", "reward",
+                                 "discount", "progress", "time"])
+    assert ep["lidar"].shape == (steps + 1, 1080) and ep["lidar"].dtype == np.float32
+    assert ep["lidar_occupancy"].shape == (steps + 1, 64, 64, 1) and ep["lidar_occupancy"].dtype == np.uint8
+    assert ep["progress"][0] == -1.0 and ep["discount"][-1] == 0.0 and np.all(ep["discount"][:-1] == 1.0)
+    assert abs(ep["reward"].sum() - total) < 1e-4
+    assert ep["lidar"].max() <= 15.0 and ep["lidar"][1:].min() >= 0.0
+    assert 0 < ep["lidar_occupancy"][1:].mean() < 1
+    assert ep["time"][1] == pytest.approx(0.04) and ep["speed"][1] > 0      # 4 sub-steps of dt = 0.01
+
+
+def test_reference_multi_agent_scenario_and_grid_reset(ref_wrappers):
+    W = ref_wrappers
+    os.chdir(os.path.join(REF, "baselines"))                                # 4-agent scenario A..D
+    env = W.RaceCarWrapper(W.RaceCarBaseEnv(track="columbia", task="max_progress"), agent_id="A")
+    assert env.agent_ids == ["A", "B", "C", "D"]
+    assert "acceleration" in env.observation_space["A"].spaces and "speed" in env.observation_space["A"].spaces
+    low, high = env.action_space["A"].low, env.action_space["A"].high
+    assert low.tolist() == [-1.0, -1.0] and high.tolist() == [1.0, 1.0]
+    obs = env.reset(mode="grid")
+    xs = [obs[a]["pose"][:2] for a in env.agent_ids]
+    gaps = [np.hypot(*(xs[i] - xs[i + 1])) for i in range(3)]
+    assert all(0.8 < g < 2.5 for g in gaps)                                 # ~1.2 m of arc apart, never overlapping
+    obs, rew, done, info = env.step({a: np.array([0.5, 0.0]) for a in env.agent_ids})
+    assert set(rew) == set(done) == {"A", "B", "C", "D"}
