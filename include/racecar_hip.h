@@ -148,6 +148,11 @@ int rc_step(rc_env *env, const float *actions_dev, int32_t repeat);
 /* Same, actions in host memory (copied with the stream). */
 int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat);
 
+/* Teleport: overwrite every car's pose from host memory, float32 [n, 3] = x, y, yaw (|yaw| <= pi), keep the
+ * rest of the state, and recompute the observation (LiDAR, patch).  The analogue of setting the base pose of
+ * the vehicle body in the reference's simulator; used by evaluation tooling and by the raycast parity tests. */
+int rc_set_pose(rc_env *env, const float *xyyaw_host);
+
 /* Fill RC_F_ACTION_IN with U(-1,1)^2 from Philox4x32-10 keyed by (seed, step, global car id). */
 int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step);
 

@@ -178,6 +178,18 @@ class BatchedRaceEnv:
         self._exit()
         return self.views
 
+    def set_pose(self, xyyaw) -> Dict[str, torch.Tensor]:
+        """Teleport every car: float32 [num_envs, cars_per_env, 3] = x, y, yaw; recomputes the observation."""
+        a = np.ascontiguousarray(np.asarray(xyyaw, np.float32).reshape(self.n_cars, 3))
+        self._enter()
+        L.check(self._lib.rc_set_pose(self._h, a.ctypes.data))
+        self._exit()
+        return self.views
+
+    def set_raycast_variant(self, variant: int) -> None:
+        """0 = plain traversal, 1 = free-rectangle skipping, 2 = skipping + sign-mask arithmetic (default)."""
+        L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
+
     def fill_random_actions(self, seed: int, step: int) -> None:
         L.check(self._lib.rc_fill_random_actions(self._h, C.c_uint64(seed), C.c_uint32(step)))
 

@@ -159,6 +159,20 @@ struct KernelTimer {
         if (_rc) return _rc;                            \
     } while (0)
 
+// Persistent workgroups: as many as stay resident (2 x 1024 threads = 32 waves/CU is the hardware maximum).
+void set_launch_geometry(rc_env *env) {
+    RcLaunchInfo &li = env->launch;
+    auto blocks_for = [&](size_t lds, long long items, int threads) {
+        int wg_per_cu = (int)((160 * 1024) / lds);
+        wg_per_cu = wg_per_cu > 2 ? 2 : (wg_per_cu < 1 ? 1 : wg_per_cu);
+        return (int)std::min<long long>((items + threads - 1) / threads, (long long)li.n_cu * wg_per_cu);
+    };
+    const long long rays = (long long)env->n_cars * RC_N_BEAMS;
+    const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 4);
+    li.ray_blocks = blocks_for(li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes, rays, li.ray_threads);
+    li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
+}
+
 int observe(rc_env *env) {
     TIMED(env, RC_K_RAYCAST, rck_launch_raycast(env->params, env->launch, env->stream));
     if (env->params.render_patch)
@@ -382,10 +396,45 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     for (int iy = 0; iy < h; ++iy) { setbit(0, iy); setbit(w - 1, iy); }
     std::vector<float> beams(RC_N_BEAMS * 2), foot(RCS_N_FOOTPRINT * 2);
     make_tables(beams.data(), foot.data());
+    // Free-block table for the skipping traversal: exact chessboard distance transform of the stop cells
+    // (two raster passes), then the minimum over each block.  A block value v >= 1 certifies that every
+    // cell within Chebyshev distance v - 1 of any cell of the block is free.
+    std::vector<int32_t> dist((size_t)h * w);
+    for (int iy = 0; iy < h; ++iy)
+        for (int ix = 0; ix < w; ++ix)
+            dist[(size_t)iy * w + ix] = ((ray[(size_t)iy * pitch + (ix >> 5)] >> (ix & 31)) & 1u) ? 0 : (1 << 20);
+    auto relax = [&](int iy, int ix, int oy, int ox) {
+        const int y = iy + oy, x = ix + ox;
+        if (y < 0 || y >= h || x < 0 || x >= w) return;
+        int32_t &d = dist[(size_t)iy * w + ix];
+        const int32_t c = dist[(size_t)y * w + x] + 1;
+        if (c < d) d = c;
+    };
+    for (int iy = 0; iy < h; ++iy)
+        for (int ix = 0; ix < w; ++ix) { relax(iy, ix, -1, -1); relax(iy, ix, -1, 0); relax(iy, ix, -1, 1); relax(iy, ix, 0, -1); }
+    for (int iy = h - 1; iy >= 0; --iy)
+        for (int ix = w - 1; ix >= 0; --ix) { relax(iy, ix, 1, 1); relax(iy, ix, 1, 0); relax(iy, ix, 1, -1); relax(iy, ix, 0, 1); }
+    int blk_shift = 2;
+    auto blk_dim = [&](int n) { return (n + (1 << blk_shift) - 1) >> blk_shift; };
+    if (bm_bytes + align_up((size_t)blk_dim(h) * blk_dim(w), 64) > 160 * 1024) blk_shift = 3;
+    const int blk_w = blk_dim(w), blk_h = blk_dim(h), bs = 1 << blk_shift;
+    const size_t blk_bytes = align_up((size_t)blk_w * blk_h, 64);
+    std::vector<uint8_t> blocks(blk_bytes, 0);
+    for (int by = 0; by < blk_h; ++by)
+        for (int bx = 0; bx < blk_w; ++bx) {
+            int32_t m = 255;
+            for (int oy = 0; oy < bs; ++oy)
+                for (int ox = 0; ox < bs; ++ox) {
+                    const int y = by * bs + oy, x = bx * bs + ox;
+                    const int32_t d = (y < h && x < w) ? dist[(size_t)y * w + x] : 0;
+                    if (d < m) m = d;
+                }
+            blocks[(size_t)by * blk_w + bx] = (uint8_t)m;
+        }
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
     const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
-    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes;
+    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
     if (env->track_mem) { HIP_TRY(hipFree(env->track_mem)); env->track_mem = nullptr; }
     HIP_TRY(hipMalloc(&env->track_mem, total));
@@ -397,6 +446,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(hipMemcpy(m, centerline, (size_t)n_centerline * 16, hipMemcpyHostToDevice)); t.centerline = (const float *)m; m += cl_bytes;
     HIP_TRY(hipMemcpy(m, beams.data(), beams.size() * 4, hipMemcpyHostToDevice)); t.beams = (const float *)m; m += beam_bytes;
     HIP_TRY(hipMemcpy(m, foot.data(), foot.size() * 4, hipMemcpyHostToDevice)); t.footprint = (const float *)m; m += foot_bytes;
+    HIP_TRY(hipMemcpy(m, blocks.data(), blk_bytes, hipMemcpyHostToDevice)); t.free_blocks = (const uint8_t *)m; m += blk_bytes;
+    t.blk_w = blk_w; t.blk_h = blk_h; t.blk_shift = blk_shift; t.blk_bytes = (int32_t)blk_bytes;
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
@@ -404,18 +455,13 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
     RcLaunchInfo &li = env->launch;
     li.lds_bytes = bm_bytes;
+    li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
+    li.raycast_variant = li.lds_bytes_skip ? 2 : 0;
     li.ray_threads = 1024;
     li.patch_threads = 1024;
-    int wg_per_cu = (int)((160 * 1024) / bm_bytes);
-    if (wg_per_cu > 2) wg_per_cu = 2;           // 2 x 1024 threads = 32 waves/CU, the hardware maximum
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    const long long rays = (long long)env->n_cars * RC_N_BEAMS;
-    const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 4);
-    const int max_blocks = li.n_cu * wg_per_cu;
-    li.ray_blocks = (int)std::min<long long>((rays + li.ray_threads - 1) / li.ray_threads, max_blocks);
-    li.patch_blocks = (int)std::min<long long>((quads + li.patch_threads - 1) / li.patch_threads, max_blocks);
-    HIP_TRY(rck_set_lds_limits(li.lds_bytes));
+    HIP_TRY(rck_set_lds_limits(std::max(li.lds_bytes, li.lds_bytes_skip)));
     env->has_track = true;
+    set_launch_geometry(env);
     env->was_reset = false;
     return RC_OK;
 }
@@ -457,6 +503,20 @@ int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat) {
     HIP_TRY(hipMemcpyAsync(env->actions_in, actions_host, (size_t)env->n_cars * 8, hipMemcpyHostToDevice, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
     return rc_step(env, nullptr, repeat);
+}
+
+int rc_set_pose(rc_env *env, const float *xyyaw_host) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!xyyaw_host) return fail(RC_ERR_INVALID, "xyyaw_host is NULL");
+    if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_set_pose");
+    if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    // stage through the lidar section of the arena: it is rewritten by the observation pass right after
+    float *staging = env->params.out.lidar;
+    HIP_TRY(hipMemcpyAsync(staging, xyyaw_host, (size_t)env->n_cars * 12, hipMemcpyHostToDevice, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    HIP_TRY(rck_launch_set_pose(env->params, staging, env->stream));
+    return observe(env);
 }
 
 int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step) {
@@ -533,8 +593,12 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (variant != 0) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (variant < 0 || variant > 2) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
+    if (variant != 0 && env->launch.lds_bytes_skip == 0)
+        return fail(RC_ERR_INVALID, "variants 1/2 need bitmap + free-block table in the 160 KiB LDS; this track is too large");
     env->launch.raycast_variant = variant;
+    set_launch_geometry(env);
     return RC_OK;
 }
 

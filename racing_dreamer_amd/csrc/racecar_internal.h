@@ -11,6 +11,9 @@ struct RcTrackDev {
     const float *centerline;     // [n_centerline][4] = x, y, heading, progress
     const float *beams;          // [1080][2] = cos, sin of the beam angle in the sensor frame
     const float *footprint;      // [34][2] body-frame perimeter points
+    const uint8_t *free_blocks;  // [blk_h][blk_w]: per (1<<blk_shift)^2-cell block, min over its cells of the
+                                 // Chebyshev distance to the nearest occupied/ring cell (0 = block not free)
+    int32_t blk_w, blk_h, blk_shift, blk_bytes;
     int32_t h, w, pitch, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
 };
@@ -49,14 +52,16 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t n_cu;
     int32_t ray_blocks, ray_threads;
     int32_t patch_blocks, patch_threads;
-    size_t lds_bytes;
-    int32_t raycast_variant;
+    size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
+    size_t lds_bytes_skip;       // bitmap + free-block table (raycast variant 1); 0 if it does not fit
+    int32_t raycast_variant;     // 0 = plain traversal, 1 = free-rectangle skipping (identical results)
 };
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
 hipError_t rck_set_lds_limits(size_t lds_bytes);
 hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s);
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);
+hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s);
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
 hipError_t rck_launch_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t seed_lo,

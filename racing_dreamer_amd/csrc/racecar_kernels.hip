@@ -398,11 +398,164 @@ __device__ __forceinline__ float cast_ray_dda(const uint32_t *bits, const RcTrac
     }
 }
 
-template <int A>
+// Same traversal, but whole certified-free rectangles are crossed in one iteration.
+//
+// `blk` holds, per (1 << shift)^2-cell block, v = min over the block's cells of the Chebyshev distance
+// to the nearest stop cell (0 if the block contains one).  For v >= 1 every cell of the rectangle
+// [block - (v-1), block + (v-1)] is free, so the cell-by-cell traversal would walk through it without a
+// hit; we jump straight to the crossing that leaves it.  Because the reference traversal derives every
+// boundary time from integer boundary coordinates (t = (b - g) * 1/d), the state after that crossing is
+// a pure function of the ray: the exit axis is decided by the same comparison (tx < ty, ties -> y), and
+// the number of other-axis boundaries crossed before it is the count of j with t_other(j) <= t_exit
+// (y before x on ties) resp. < t_exit - found from an fp32 estimate and corrected with the exact
+// comparisons, so the visited-cell sequence outside free rectangles, the hit cell and the returned range
+// are bit-identical to cast_ray_dda (checked against the CPU oracle in tests/test_gpu_parity.py).
+// With v == 0 the rectangle is the current cell and the iteration is exactly one traversal step.
+__device__ __forceinline__ float cast_ray_skip(const uint32_t *bits, const uint8_t *blk, const RcTrackDev &t,
+                                               float gx, float gy, float dx, float dy) {
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    if ((unsigned)ix >= (unsigned)t.w || (unsigned)iy >= (unsigned)t.h) return 0.0f;
+    if (bit_at(bits, t.pitch, ix, iy)) return 0.0f;
+    const bool hx = dx != 0.0f, hy = dy != 0.0f, px = dx > 0.0f, py = dy > 0.0f;
+    const float idx = hx ? 1.0f / dx : 0.0f;
+    const float idy = hy ? 1.0f / dy : 0.0f;
+    const int sx = px ? 1 : -1, sy = py ? 1 : -1;
+    const float sxf = (float)sx, syf = (float)sy;
+    const int shift = t.blk_shift, bs = 1 << shift, bmask = ~(bs - 1);
+    const int wm1 = t.w - 1, hm1 = t.h - 1;
+    for (int it = 0; it < 4096; ++it) {          // a ray crosses < 430 cells; the cap only bounds a logic error
+        const int v = blk[(iy >> shift) * t.blk_w + (ix >> shift)];
+        const int r = v - 1;
+        const int x0 = v ? (ix & bmask) - r : ix, x1 = v ? (ix & bmask) + bs + r : ix + 1;
+        const int y0 = v ? (iy & bmask) - r : iy, y1 = v ? (iy & bmask) + bs + r : iy + 1;
+        const int xe = px ? x1 : x0, ye = py ? y1 : y0;                 // boundaries that leave the rectangle
+        const float txe = hx ? ((float)xe - gx) * idx : INFINITY;
+        const float tye = hy ? ((float)ye - gy) * idy : INFINITY;
+        const bool xexit = txe < tye;
+        const float tt = xexit ? txe : tye;
+        if (tt >= t.tmax) return RCS_MAX_RANGE;
+        if (xexit) {
+            int m = 0;
+            if (hy && v) {
+                const float b0 = (float)(iy + (py ? 1 : 0));            // first y boundary ahead
+                m = ((int)floorf(gy + tt * dy) - iy) * sy;
+                m = m < 0 ? 0 : m;
+                for (int g = 0; g < 8 && ((b0 + (float)m * syf) - gy) * idy <= tt; ++g) ++m;
+                for (int g = 0; g < 8 && m > 0 && ((b0 + (float)(m - 1) * syf) - gy) * idy > tt; ++g) --m;
+            }
+            iy += m * sy;
+            ix = px ? x1 : x0 - 1;
+        } else {
+            int m = 0;
+            if (hx && v) {
+                const float b0 = (float)(ix + (px ? 1 : 0));
+                m = ((int)floorf(gx + tt * dx) - ix) * sx;
+                m = m < 0 ? 0 : m;
+                for (int g = 0; g < 8 && ((b0 + (float)m * sxf) - gx) * idx < tt; ++g) ++m;
+                for (int g = 0; g < 8 && m > 0 && ((b0 + (float)(m - 1) * sxf) - gx) * idx >= tt; ++g) --m;
+            }
+            ix += m * sx;
+            iy = py ? y1 : y0 - 1;
+        }
+        if (bit_at(bits, t.pitch, ix, iy)) {
+            const bool ring = ix == 0 || iy == 0 || ix == wm1 || iy == hm1;
+            return ring ? RCS_MAX_RANGE : tt * t.res;
+        }
+    }
+    return RCS_MAX_RANGE;
+}
+
+// Variant 2: the same free-rectangle skipping, written for the gfx950 VALU.  Measured on MI355X
+// (tools/ubench/valu_issue.hip): plain fp32/int ops issue at ~2.5 cycles per wave64 instruction, but a
+// v_cmp + v_cndmask pair costs ~4.3 cycles per instruction and packed fp32 buys nothing - so selections
+// are done with sign masks (asint(a - b) >> 31), v_min/v_max and v_bfi instead of compare/select, the
+// tie rule "y before x" is folded into a one-ulp nudge of the exit time, and the loop is split in two
+// phases (A: certified rectangles, B: single-cell steps inside blocks that contain walls) so that the
+// lanes of a wave run the same phase together.  A direction component that is exactly zero gets the
+// reciprocal 3e38 (finite) with a positive step, which makes its boundary times huge but never NaN/inf;
+// the cell sequence is unchanged.  Results are bit-identical to cast_ray_dda.
+__device__ __forceinline__ int sign_mask(float a) { return __float_as_int(a) >> 31; }             // -1 if a < 0
+__device__ __forceinline__ int bfi(int mask, int a, int b) { return (mask & a) | (~mask & b); }    // v_bfi_b32
+__device__ __forceinline__ float bfi(int mask, float a, float b) {
+    return __int_as_float(bfi(mask, __float_as_int(a), __float_as_int(b)));
+}
+
+__device__ __forceinline__ float cast_ray_fast(const uint32_t *bits, const uint8_t *blk, const RcTrackDev &t,
+                                               float gx, float gy, float dx, float dy) {
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    if ((unsigned)ix >= (unsigned)t.w || (unsigned)iy >= (unsigned)t.h) return 0.0f;
+    if (bit_at(bits, t.pitch, ix, iy)) return 0.0f;
+    const float idx = dx != 0.0f ? 1.0f / dx : 3.0e38f;
+    const float idy = dy != 0.0f ? 1.0f / dy : 3.0e38f;
+    const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;       // 1: boundary ahead is the upper one
+    const int sx = 2 * pxi - 1, sy = 2 * pyi - 1;
+    const float sxf = (float)sx, syf = (float)sy;
+    const int nx = pxi - 1, ny = pyi - 1;                                  // -1 for a negative direction
+    const int shift = t.blk_shift, bs = 1 << shift, bmask = ~(bs - 1);
+    const int kx = pxi << shift, ky = pyi << shift;
+    const int blk_w = t.blk_w, pitch = t.pitch;
+    const float tmax = t.tmax;
+    float tt = 0.0f;
+    int v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
+    bool alive = true;
+    for (int guard = 0; guard < 1024 && alive; ++guard) {
+        // ---- phase A: cross certified-free rectangles
+        while (alive && v != 0) {
+            const int r = v - 1;
+            const int xe = (ix & bmask) + kx + ((r ^ nx) - nx);            // boundary that leaves the rectangle
+            const int ye = (iy & bmask) + ky + ((r ^ ny) - ny);
+            const float txe = ((float)xe - gx) * idx;
+            const float tye = ((float)ye - gy) * idy;
+            const int mx = sign_mask(txe - tye);                           // -1: leaves through the x side
+            tt = fminf(txe, tye) + 0.0f;                                   // + 0.0f: canonical +0
+            if (tt >= tmax) return RCS_MAX_RANGE;
+            // the other axis: how many of its boundaries are crossed before the exit crossing
+            const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx), oid = bfi(mx, idy, idx), osf = bfi(mx, syf, sxf);
+            const int oi = bfi(mx, iy, ix), os = bfi(mx, sy, sx), opi = bfi(mx, pyi, pxi);
+            const int me = __mul24((int)floorf(og + tt * od) - oi, os);    // fp32 estimate, exact within +-1
+            const int m0 = max(me - 1, 0);
+            const float b0 = (float)(oi + opi + __mul24(m0, os));
+            const float t2 = __int_as_float(__float_as_int(tt) - mx);      // x exit: y wins ties -> count t <= tt
+            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
+            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
+            const int on = oi + __mul24(m0 + c0 + c1, os);
+            ix = bfi(mx, xe + nx, on);
+            iy = bfi(mx, on, ye + ny);
+            const uint32_t w = bits[__mul24(iy, pitch) + (ix >> 5)];
+            if ((w >> (ix & 31)) & 1u) { alive = false; break; }
+            v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
+        }
+        // ---- phase B: single-cell steps while inside blocks that contain walls
+        while (alive && v == 0) {
+            const float tx = ((float)(ix + pxi) - gx) * idx;
+            const float ty = ((float)(iy + pyi) - gy) * idy;
+            const int mx = sign_mask(tx - ty);
+            tt = fminf(tx, ty);
+            if (tt >= tmax) return RCS_MAX_RANGE;
+            ix += sx & mx;
+            iy += sy & ~mx;
+            const uint32_t w = bits[__mul24(iy, pitch) + (ix >> 5)];
+            if ((w >> (ix & 31)) & 1u) { alive = false; break; }
+            v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
+        }
+    }
+    if (alive) return RCS_MAX_RANGE;                                        // guard tripped (cannot happen)
+    const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
+    return ring ? RCS_MAX_RANGE : tt * t.res;
+}
+
+template <int A, int VARIANT>
 __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_rays) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
-    stage_bitmap(lds_words, t.ray_words, t.h * t.pitch);
+    const int nwords = t.h * t.pitch;
+    const uint8_t *lds_blk = reinterpret_cast<const uint8_t *>(lds_words + ((nwords + 15) & ~15));
+    if (VARIANT != 0) {
+        uint4 *d4 = reinterpret_cast<uint4 *>(lds_words + ((nwords + 15) & ~15));
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(t.free_blocks);
+        for (int i = threadIdx.x; i < (t.blk_bytes >> 4); i += blockDim.x) d4[i] = s4[i];
+    }
+    stage_bitmap(lds_words, t.ray_words, nwords);
     for (int base = blockIdx.x * blockDim.x; base < total_rays; base += gridDim.x * blockDim.x) {
         const int g = base + threadIdx.x;
         if (g >= total_rays) break;
@@ -416,7 +569,9 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = cast_ray_dda(lds_words, t, gx, gy, dx, dy);
+        float rng = VARIANT == 2   ? cast_ray_fast(lds_words, lds_blk, t, gx, gy, dx, dy)
+                    : VARIANT == 1 ? cast_ray_skip(lds_words, lds_blk, t, gx, gy, dx, dy)
+                                   : cast_ray_dda(lds_words, t, gx, gy, dx, dy);
         if (A > 1) {
             const int env = car / A;
 #pragma unroll
@@ -472,6 +627,19 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_qu
     }
 }
 
+__global__ __launch_bounds__(256) void rc_set_pose_kernel(RcParams p, const float *__restrict__ xyyaw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_cars) return;
+    const float x = xyyaw[3 * i], y = xyyaw[3 * i + 1], th = xyyaw[3 * i + 2];
+    float sn, cs;
+    sincos32(th, sn, cs);
+    p.st.x[i] = x; p.st.y[i] = y; p.st.theta[i] = th; p.st.st[i] = sn; p.st.ct[i] = cs;
+    p.st.fresh[i] = 0;
+    p.out.fresh[i] = 0;
+    float *pose = p.out.pose + 6 * i;
+    pose[0] = x; pose[1] = y; pose[5] = th;
+}
+
 __global__ __launch_bounds__(256) void rc_random_actions_kernel(float *__restrict__ actions, int n_cars,
                                                                  uint32_t first_car, uint32_t seed_lo,
                                                                  uint32_t seed_hi, uint32_t step) {
@@ -492,10 +660,18 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     hipError_t e;
     const int b = (int)lds_bytes;
 #define SET(k) e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, b); if (e != hipSuccess) return e;
-    SET(rc_raycast_kernel<1>)
-    SET(rc_raycast_kernel<2>)
-    SET(rc_raycast_kernel<3>)
-    SET(rc_raycast_kernel<4>)
+    SET((rc_raycast_kernel<1, 0>))
+    SET((rc_raycast_kernel<2, 0>))
+    SET((rc_raycast_kernel<3, 0>))
+    SET((rc_raycast_kernel<4, 0>))
+    SET((rc_raycast_kernel<1, 1>))
+    SET((rc_raycast_kernel<2, 1>))
+    SET((rc_raycast_kernel<3, 1>))
+    SET((rc_raycast_kernel<4, 1>))
+    SET((rc_raycast_kernel<1, 2>))
+    SET((rc_raycast_kernel<2, 2>))
+    SET((rc_raycast_kernel<3, 2>))
+    SET((rc_raycast_kernel<4, 2>))
     SET(rc_patch_kernel)
 #undef SET
     return hipSuccess;
@@ -523,13 +699,25 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
-    DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes, s>>>(p, total));
+    if (li.raycast_variant == 2) {
+        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 2><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
+    } else if (li.raycast_variant == 1) {
+        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 1><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
+    } else {
+        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 0><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes, s>>>(p, total));
+    }
     return hipGetLastError();
 }
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_PATCH * (RC_PATCH / 4);
     hipLaunchKernelGGL(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s) {
+    const int threads = 256, blocks = (p.n_cars + threads - 1) / threads;
+    rc_set_pose_kernel<<<dim3(blocks), dim3(threads), 0, s>>>(p, xyyaw_dev);
     return hipGetLastError();
 }
 
