@@ -465,17 +465,40 @@ __device__ __forceinline__ float cast_ray_skip(const uint32_t *bits, const uint8
     return RCS_MAX_RANGE;
 }
 
-// Variant 2: the same free-rectangle skipping, written for the gfx950 VALU.  Measured on MI355X
-// (tools/ubench/valu_issue.hip): plain fp32/int ops issue at ~2.5 cycles per wave64 instruction, but a
-// v_cmp + v_cndmask pair costs ~4.3 cycles per instruction and packed fp32 buys nothing - so selections
-// are done with sign masks (asint(a - b) >> 31), v_min/v_max and v_bfi instead of compare/select, the
-// tie rule "y before x" is folded into a one-ulp nudge of the exit time, and the loop is split in two
-// phases (A: certified rectangles, B: single-cell steps inside blocks that contain walls) so that the
-// lanes of a wave run the same phase together.  A direction component that is exactly zero gets the
-// reciprocal 3e38 (finite) with a positive step, which makes its boundary times huge but never NaN/inf;
-// the cell sequence is unchanged.  Results are bit-identical to cast_ray_dda.
-__device__ __forceinline__ int sign_mask(float a) { return __float_as_int(a) >> 31; }             // -1 if a < 0
-__device__ __forceinline__ int bfi(int mask, int a, int b) { return (mask & a) | (~mask & b); }    // v_bfi_b32
+// Variant 2: free-rectangle skipping tuned to the gfx950 VALU issue costs measured on MI355X
+// (tools/ubench/valu_issue{2,3}.hip; cycles per wave64 instruction per SIMD, 8 waves resident):
+//   ~2.4  v_add/sub/mul/fma_f32, v_add/sub_u32, v_and/or/xor, shifts
+//   ~4.3  v_cmp, v_cvt, v_floor, v_min/max, v_bfi, v_bfe, v_add3, v_mad_u32_u24, v_mul_i32_i24, e64 v_cndmask
+//   ~16   v_cndmask_b32 e32 reading VCC (what hipcc emits for most `?:`), ~8 v_rcp_f32; SALU ~4.2, overlapping
+// The kernel is VALU-issue bound, so the loop is written to minimise instructions:
+//  * one body for both kinds of iteration: with block value v == 0 the "rectangle" is the current cell
+//    and the iteration is exactly one traversal step;
+//  * selections use sign masks and v_bfi (kept opaque to LLVM by one-instruction asm, otherwise they are
+//    folded back into compare + select);
+//  * the other-axis cell after the exit crossing is floor(g + t * d) whenever that position is at least
+//    1e-3 cell away from a cell boundary: the fp32 boundary times the reference traversal compares
+//    deviate from the real ones by < 2e-4 cell, so there the count of crossed boundaries is unambiguous
+//    under either tie rule; within 1e-3 of a boundary (corner grazing, <1 % of iterations) the exact
+//    comparisons of the reference are evaluated;
+//  * a certified block (v >= 1) needs no occupancy test, so most iterations read LDS once.
+// A direction component that is exactly zero gets the reciprocal 3e38 (finite) and a positive step: its
+// boundary times are huge but never NaN/inf and the cell sequence is unchanged.  Bit-identical to
+// cast_ray_dda (tests/test_gpu_parity.py::test_raycast_variants_from_arbitrary_poses).
+__device__ __forceinline__ int sign_mask(float a) {            // -1 if the sign bit is set, else 0
+    int r;
+    asm("v_ashrrev_i32 %0, 31, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ int nonzero_mask(int a) {           // -1 if a != 0 (0 <= a < 2^31), else 0
+    int r;
+    asm("v_sub_u32 %0, 0, %1\n\tv_ashrrev_i32 %0, 31, %0" : "=v"(r) : "v"(a));
+    return r;
+}
+__device__ __forceinline__ int bfi(int mask, int a, int b) {   // (mask & a) | (~mask & b)
+    int r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ float bfi(int mask, float a, float b) {
     return __int_as_float(bfi(mask, __float_as_int(a), __float_as_int(b)));
 }
@@ -483,65 +506,63 @@ __device__ __forceinline__ float bfi(int mask, float a, float b) {
 __device__ __forceinline__ float cast_ray_fast(const uint32_t *bits, const uint8_t *blk, const RcTrackDev &t,
                                                float gx, float gy, float dx, float dy) {
     int ix = (int)floorf(gx), iy = (int)floorf(gy);
-    if ((unsigned)ix >= (unsigned)t.w || (unsigned)iy >= (unsigned)t.h) return 0.0f;
-    if (bit_at(bits, t.pitch, ix, iy)) return 0.0f;
+    bool alive = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+    if (alive) alive = bit_at(bits, t.pitch, ix, iy) == 0;
+    const bool started = alive;                                           // false: the sensor sits in a stop cell
     const float idx = dx != 0.0f ? 1.0f / dx : 3.0e38f;
     const float idy = dy != 0.0f ? 1.0f / dy : 3.0e38f;
-    const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;       // 1: boundary ahead is the upper one
-    const int sx = 2 * pxi - 1, sy = 2 * pyi - 1;
-    const float sxf = (float)sx, syf = (float)sy;
-    const int nx = pxi - 1, ny = pyi - 1;                                  // -1 for a negative direction
+    const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;      // 1: the boundary ahead is the upper one
+    const int nx = pxi - 1, ny = pyi - 1;                                 // -1 for a negative direction
     const int shift = t.blk_shift, bs = 1 << shift, bmask = ~(bs - 1);
     const int kx = pxi << shift, ky = pyi << shift;
     const int blk_w = t.blk_w, pitch = t.pitch;
     const float tmax = t.tmax;
     float tt = 0.0f;
-    int v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
-    bool alive = true;
-    for (int guard = 0; guard < 1024 && alive; ++guard) {
-        // ---- phase A: cross certified-free rectangles
-        while (alive && v != 0) {
+    int v = 0;
+    if (alive) v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
+    for (int guard = 0; guard < 2048 && __builtin_amdgcn_ballot_w64(alive) != 0; ++guard) {
+        if (alive) {
+            // boundary that leaves the certified rectangle (v >= 1) or the current cell (v == 0)
+            const int vm = nonzero_mask(v);
             const int r = v - 1;
-            const int xe = (ix & bmask) + kx + ((r ^ nx) - nx);            // boundary that leaves the rectangle
-            const int ye = (iy & bmask) + ky + ((r ^ ny) - ny);
+            const int xe = bfi(vm, (ix & bmask) + kx + ((r ^ nx) - nx), ix + pxi);
+            const int ye = bfi(vm, (iy & bmask) + ky + ((r ^ ny) - ny), iy + pyi);
             const float txe = ((float)xe - gx) * idx;
             const float tye = ((float)ye - gy) * idy;
-            const int mx = sign_mask(txe - tye);                           // -1: leaves through the x side
-            tt = fminf(txe, tye) + 0.0f;                                   // + 0.0f: canonical +0
-            if (tt >= tmax) return RCS_MAX_RANGE;
-            // the other axis: how many of its boundaries are crossed before the exit crossing
-            const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx), oid = bfi(mx, idy, idx), osf = bfi(mx, syf, sxf);
-            const int oi = bfi(mx, iy, ix), os = bfi(mx, sy, sx), opi = bfi(mx, pyi, pxi);
-            const int me = __mul24((int)floorf(og + tt * od) - oi, os);    // fp32 estimate, exact within +-1
-            const int m0 = max(me - 1, 0);
-            const float b0 = (float)(oi + opi + __mul24(m0, os));
-            const float t2 = __int_as_float(__float_as_int(tt) - mx);      // x exit: y wins ties -> count t <= tt
-            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
-            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-            const int on = oi + __mul24(m0 + c0 + c1, os);
+            const int mx = sign_mask(txe - tye);                          // -1: leaves through the x side
+            tt = fminf(txe, tye);
+            // cell on the other axis after that crossing
+            const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
+            const float pe = og + tt * od;
+            const float fl = floorf(pe);
+            int on = (int)fl;
+            if (fabsf((pe - fl) - 0.5f) > 0.499f) {                       // within 1e-3 of a boundary: exact count
+                const float oid = bfi(mx, idy, idx);
+                const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
+                const float osf = (float)os;
+                const float tc = tt + 0.0f;                               // canonical +0
+                const int m0 = max(__mul24(on - oi, os) - 1, 0);
+                const float b0 = (float)(oi + opi + __mul24(m0, os));
+                const float t2 = __int_as_float(__float_as_int(tc) - mx);   // x exit: y wins ties -> count t <= tt
+                const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
+                const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
+                on = oi + __mul24(m0 + c0 + c1, os);
+            }
             ix = bfi(mx, xe + nx, on);
             iy = bfi(mx, on, ye + ny);
-            const uint32_t w = bits[__mul24(iy, pitch) + (ix >> 5)];
-            if ((w >> (ix & 31)) & 1u) { alive = false; break; }
-            v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
-        }
-        // ---- phase B: single-cell steps while inside blocks that contain walls
-        while (alive && v == 0) {
-            const float tx = ((float)(ix + pxi) - gx) * idx;
-            const float ty = ((float)(iy + pyi) - gy) * idy;
-            const int mx = sign_mask(tx - ty);
-            tt = fminf(tx, ty);
-            if (tt >= tmax) return RCS_MAX_RANGE;
-            ix += sx & mx;
-            iy += sy & ~mx;
-            const uint32_t w = bits[__mul24(iy, pitch) + (ix >> 5)];
-            if ((w >> (ix & 31)) & 1u) { alive = false; break; }
-            v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
+            alive = tt < tmax;
+            if (alive) {
+                v = blk[__mul24(iy >> shift, blk_w) + (ix >> shift)];
+                if (v == 0) {                                             // not certified: test the cell itself
+                    const uint32_t w = bits[__mul24(iy, pitch) + (ix >> 5)];
+                    alive = ((w >> (ix & 31)) & 1u) == 0;
+                }
+            }
         }
     }
-    if (alive) return RCS_MAX_RANGE;                                        // guard tripped (cannot happen)
+    if (!started) return 0.0f;
     const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
-    return ring ? RCS_MAX_RANGE : tt * t.res;
+    return (!(tt < tmax) || ring || alive) ? RCS_MAX_RANGE : tt * t.res;
 }
 
 template <int A, int VARIANT>
