@@ -39,7 +39,14 @@ def parse_args():
     ap.add_argument("--track", default="austria")
     ap.add_argument("--obs-type", default="lidar", choices=["lidar", "lidar_occupancy"])
     ap.add_argument("--repeat", type=int, default=1, help="action repeat (sub-steps per step)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the trajectory all-gather")
+    ap.add_argument("--gather", default="summary", choices=["summary", "full", "none"],
+                    help="N>1: what the per-step RCCL all-gather carries. summary = the transition record without "
+                         "the LiDAR row (pose, velocity, speed, action, reward, discount, progress, time: 76 B/car; "
+                         "the scans stay sharded in each rank's HBM); full = the whole 4 396 B/car record (xGMI-bound: "
+                         "DESIGN.md §6); none = no collective")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--raycast-variant", type=int, default=None)
@@ -64,7 +71,7 @@ def main():
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
-    distributed = world > 1
+    distributed = world > 1 or (args.force_gather and "RANK" in os.environ)
     torch.cuda.set_device(local_rank)
     if distributed:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -81,13 +88,15 @@ def main():
         from racing_dreamer_amd import _lib as L
         L.check(env._lib.rc_set_raycast_variant(env._h, args.raycast_variant))
     env.reset(mode="random", seed=0)
-    gather = TrajectoryGather(env.slab) if (distributed and not args.no_gather) else None
+    gather_mode = "none" if (args.no_gather or not distributed) else args.gather
+    gather_src = {"none": None, "full": env.slab, "summary": env.summary_slab}[gather_mode]
+    gather = TrajectoryGather(gather_src) if gather_src is not None else None
 
-    def one_step(k):
+    def one_step(k, repeat=None):
         env.fill_random_actions(seed=1, step=k)
-        env.step(None)
+        env.step(None, repeat=repeat)
         if gather is not None:
-            gather.launch(env.slab)
+            gather.launch(gather_src)
 
     def barrier():
         torch.cuda.synchronize()
@@ -114,10 +123,23 @@ def main():
     env.set_profiling(False)
     ktimes = env.kernel_times()
 
+    # secondary figure: the reference's own setting, action_repeat 4 with the scan once per agent step
+    # (dreamer/dream.py:55) - a quarter of the steps, same barriers
+    r4_steps = max(args.steps // 4, 5)
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(r4_steps):
+        one_step(args.warmup + args.steps + k, repeat=4)
+    if gather is not None:
+        gather.wait()
+    env.sync()
+    barrier()
+    dt4 = time.perf_counter() - t1
+
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt, dt4], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, dt4 = float(tmax[0].item()), float(tmax[1].item())
 
     total_envs = args.envs * world
     env_steps = total_envs * args.steps * args.repeat
@@ -143,7 +165,10 @@ def main():
                             f"auto-reset, action_repeat {args.repeat}",
                 "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
                 "track": args.track, "obs_type": args.obs_type, "action_repeat": args.repeat,
-                "parallelism": f"env-sharded x{world}" + ("" if gather is None else " + overlapped RCCL all-gather of the trajectory slab every step"),
+                "parallelism": f"env-sharded x{world}" + ("" if gather is None else
+                                f" + overlapped RCCL all-gather of the {gather_mode} trajectory record every step "
+                                f"({gather_src.numel()} B per GPU per step)"),
+                "gather": gather_mode,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "rc_raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -155,7 +180,9 @@ def main():
                         "of the grid traversal, not by HBM (SURVEY.md §8d); see DESIGN.md §5",
             },
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
-            "agent_steps_per_s_at_repeat4": None,
+            "action_repeat_4": {"env_steps_per_s": total_envs * r4_steps * 4 / dt4,
+                                "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
+                                "note": "same workload with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55)"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)

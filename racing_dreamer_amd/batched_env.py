@@ -111,6 +111,11 @@ class BatchedRaceEnv:
         ptr, nb = C.c_void_p(), C.c_size_t()
         L.check(self._lib.rc_trajectory_slab(self._h, C.byref(ptr), C.byref(nb)))
         self.slab = self._arena_view[ptr.value - base:ptr.value - base + nb.value]
+        # the record without the bulky observations: pose .. time (76 B per car), contiguous in the arena
+        p0, n0, p1, n1 = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+        L.check(self._lib.rc_get(self._h, L.F_POSE, C.byref(p0), C.byref(n0)))
+        L.check(self._lib.rc_get(self._h, L.F_TIME, C.byref(p1), C.byref(n1)))
+        self.summary_slab = self._arena_view[p0.value - base:p1.value - base + n1.value]
         if profiling:
             self.set_profiling(True)
 
