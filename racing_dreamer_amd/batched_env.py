@@ -192,7 +192,8 @@ class BatchedRaceEnv:
         return self.views
 
     def set_raycast_variant(self, variant: int) -> None:
-        """0 = plain traversal, 1 = free-rectangle skipping, 2 = skipping + sign-mask arithmetic (default)."""
+        """0 = plain traversal, 1 = free-rectangle skipping, 2 = tuned skipping, 3 = tuned + packed block table
+        (default where the table fits the LDS).  All variants return identical results."""
         L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
 
     def fill_random_actions(self, seed: int, step: int) -> None:

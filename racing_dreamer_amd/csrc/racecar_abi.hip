@@ -169,7 +169,7 @@ void set_launch_geometry(rc_env *env) {
     };
     const long long rays = (long long)env->n_cars * RC_N_BEAMS;
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 4);
-    li.ray_blocks = blocks_for(li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes, rays, li.ray_threads);
+    li.ray_blocks = blocks_for(li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
 }
 
@@ -431,10 +431,28 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
                 }
             blocks[(size_t)by * blk_w + bx] = (uint8_t)m;
         }
+    // packed table for variant 3: one uint32 per 4x4 block = [value << 16 | 16 occupancy bits]
+    const int pk_w = (w + 3) >> 2, pk_h = (h + 3) >> 2;
+    const size_t packed_bytes = align_up((size_t)pk_w * pk_h * 4, 64);
+    std::vector<uint32_t> packed(packed_bytes / 4, 0u);
+    for (int by = 0; by < pk_h; ++by)
+        for (int bx = 0; bx < pk_w; ++bx) {
+            uint32_t occ16 = 0;
+            int32_t m = 255;
+            for (int oy = 0; oy < 4; ++oy)
+                for (int ox = 0; ox < 4; ++ox) {
+                    const int y = by * 4 + oy, x = bx * 4 + ox;
+                    const bool in = y < h && x < w;
+                    const int32_t d = in ? dist[(size_t)y * w + x] : 0;
+                    if (d < m) m = d;
+                    if (!in || d == 0) occ16 |= 1u << (oy * 4 + ox);
+                }
+            packed[(size_t)by * pk_w + bx] = ((uint32_t)m << 16) | occ16;
+        }
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
     const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
-    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes;
+    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
     if (env->track_mem) { HIP_TRY(hipFree(env->track_mem)); env->track_mem = nullptr; }
     HIP_TRY(hipMalloc(&env->track_mem, total));
@@ -448,6 +466,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(hipMemcpy(m, foot.data(), foot.size() * 4, hipMemcpyHostToDevice)); t.footprint = (const float *)m; m += foot_bytes;
     HIP_TRY(hipMemcpy(m, blocks.data(), blk_bytes, hipMemcpyHostToDevice)); t.free_blocks = (const uint8_t *)m; m += blk_bytes;
     t.blk_w = blk_w; t.blk_h = blk_h; t.blk_shift = blk_shift; t.blk_bytes = (int32_t)blk_bytes;
+    HIP_TRY(hipMemcpy(m, packed.data(), packed_bytes, hipMemcpyHostToDevice)); t.packed_blocks = (const uint32_t *)m; m += packed_bytes;
+    t.packed_bytes = (int32_t)packed_bytes;
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
@@ -456,10 +476,11 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     RcLaunchInfo &li = env->launch;
     li.lds_bytes = bm_bytes;
     li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
-    li.raycast_variant = li.lds_bytes_skip ? 2 : 0;
+    li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
+    li.raycast_variant = li.lds_bytes_packed ? 3 : (li.lds_bytes_skip ? 2 : 0);
     li.ray_threads = 1024;
     li.patch_threads = 1024;
-    HIP_TRY(rck_set_lds_limits(std::max(li.lds_bytes, li.lds_bytes_skip)));
+    HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
     env->has_track = true;
     set_launch_geometry(env);
     env->was_reset = false;
@@ -593,9 +614,11 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (variant < 0 || variant > 2) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (variant < 0 || variant > 3) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
-    if (variant != 0 && env->launch.lds_bytes_skip == 0)
+    if (variant == 3 && env->launch.lds_bytes_packed == 0)
+        return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");
+    if ((variant == 1 || variant == 2) && env->launch.lds_bytes_skip == 0)
         return fail(RC_ERR_INVALID, "variants 1/2 need bitmap + free-block table in the 160 KiB LDS; this track is too large");
     env->launch.raycast_variant = variant;
     set_launch_geometry(env);

@@ -13,7 +13,9 @@ struct RcTrackDev {
     const float *footprint;      // [34][2] body-frame perimeter points
     const uint8_t *free_blocks;  // [blk_h][blk_w]: per (1<<blk_shift)^2-cell block, min over its cells of the
                                  // Chebyshev distance to the nearest occupied/ring cell (0 = block not free)
-    int32_t blk_w, blk_h, blk_shift, blk_bytes;
+    const uint32_t *packed_blocks; // [blk_h][blk_w] for 4x4 blocks: bits 0-15 occupancy of the block's cells
+                                 // (bit (iy&3)*4 + (ix&3), sentinel ring included), bits 16-23 the value above
+    int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes;
     int32_t h, w, pitch, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
 };
@@ -53,8 +55,9 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t ray_blocks, ray_threads;
     int32_t patch_blocks, patch_threads;
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
-    size_t lds_bytes_skip;       // bitmap + free-block table (raycast variant 1); 0 if it does not fit
-    int32_t raycast_variant;     // 0 = plain traversal, 1 = free-rectangle skipping (identical results)
+    size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
+    size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8
+    int32_t raycast_variant;     // 0 plain, 1 skipping, 2 skipping tuned, 3 tuned + packed table (identical results)
 };
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`

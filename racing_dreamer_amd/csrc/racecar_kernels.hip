@@ -565,18 +565,85 @@ __device__ __forceinline__ float cast_ray_fast(const uint32_t *bits, const uint8
     return (!(tt < tmax) || ring || alive) ? RCS_MAX_RANGE : tt * t.res;
 }
 
+// Variant 3: variant 2 reading ONE table.  For 4x4 blocks a uint32 per block holds both the certified
+// value (bits 16-23) and the occupancy of its 16 cells (bits 0-15), so an iteration is one LDS read and the
+// cell test is branch-free: a certified block has no occupancy bits, hence `(word >> cell) & 1` is the hit
+// flag for every block.  The row-major bitmap is not needed by the scan at all (LDS: 4 B per 16 cells).
+__device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTrackDev &t, float gx, float gy,
+                                                 float dx, float dy) {
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    bool alive = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+    const int blk_w = t.blk_w;
+    uint32_t word = 0;
+    if (alive) {
+        word = pk[__mul24(iy >> 2, blk_w) + (ix >> 2)];
+        alive = ((word >> (((iy & 3) << 2) | (ix & 3))) & 1u) == 0;
+    }
+    const bool started = alive;                                           // false: the sensor sits in a stop cell
+    const float idx = dx != 0.0f ? 1.0f / dx : 3.0e38f;
+    const float idy = dy != 0.0f ? 1.0f / dy : 3.0e38f;
+    const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;      // 1: the boundary ahead is the upper one
+    const int nx = pxi - 1, ny = pyi - 1;                                 // -1 for a negative direction
+    const int kx = pxi << 2, ky = pyi << 2;
+    const float tmax = t.tmax;
+    float tt = 0.0f;
+    for (int guard = 0; guard < 2048 && __builtin_amdgcn_ballot_w64(alive) != 0; ++guard) {
+        if (alive) {
+            const int v = (int)(word >> 16);
+            const int vm = nonzero_mask(v);
+            const int r = v - 1;
+            const int xe = bfi(vm, (ix & ~3) + kx + ((r ^ nx) - nx), ix + pxi);
+            const int ye = bfi(vm, (iy & ~3) + ky + ((r ^ ny) - ny), iy + pyi);
+            const float txe = ((float)xe - gx) * idx;
+            const float tye = ((float)ye - gy) * idy;
+            const int mx = sign_mask(txe - tye);                          // -1: leaves through the x side
+            tt = fminf(txe, tye);
+            const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
+            const float pe = og + tt * od;
+            const float fl = floorf(pe);
+            int on = (int)fl;
+            if (fabsf((pe - fl) - 0.5f) > 0.499f) {                       // within 1e-3 of a boundary: exact count
+                const float oid = bfi(mx, idy, idx);
+                const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
+                const float osf = (float)os;
+                const float tc = tt + 0.0f;                               // canonical +0
+                const int m0 = max(__mul24(on - oi, os) - 1, 0);
+                const float b0 = (float)(oi + opi + __mul24(m0, os));
+                const float t2 = __int_as_float(__float_as_int(tc) - mx);   // x exit: y wins ties -> count t <= tt
+                const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
+                const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
+                on = oi + __mul24(m0 + c0 + c1, os);
+            }
+            ix = bfi(mx, xe + nx, on);
+            iy = bfi(mx, on, ye + ny);
+            alive = tt < tmax;
+            if (alive) {
+                word = pk[__mul24(iy >> 2, blk_w) + (ix >> 2)];
+                alive = ((word >> (((iy & 3) << 2) | (ix & 3))) & 1u) == 0;
+            }
+        }
+    }
+    if (!started) return 0.0f;
+    const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
+    return (!(tt < tmax) || ring || alive) ? RCS_MAX_RANGE : tt * t.res;
+}
+
 template <int A, int VARIANT>
 __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_rays) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
     const int nwords = t.h * t.pitch;
     const uint8_t *lds_blk = reinterpret_cast<const uint8_t *>(lds_words + ((nwords + 15) & ~15));
-    if (VARIANT != 0) {
-        uint4 *d4 = reinterpret_cast<uint4 *>(lds_words + ((nwords + 15) & ~15));
-        const uint4 *s4 = reinterpret_cast<const uint4 *>(t.free_blocks);
-        for (int i = threadIdx.x; i < (t.blk_bytes >> 4); i += blockDim.x) d4[i] = s4[i];
+    if (VARIANT == 3) {
+        stage_bitmap(lds_words, t.packed_blocks, t.packed_bytes >> 2);
+    } else {
+        if (VARIANT != 0) {
+            uint4 *d4 = reinterpret_cast<uint4 *>(lds_words + ((nwords + 15) & ~15));
+            const uint4 *s4 = reinterpret_cast<const uint4 *>(t.free_blocks);
+            for (int i = threadIdx.x; i < (t.blk_bytes >> 4); i += blockDim.x) d4[i] = s4[i];
+        }
+        stage_bitmap(lds_words, t.ray_words, nwords);
     }
-    stage_bitmap(lds_words, t.ray_words, nwords);
     for (int base = blockIdx.x * blockDim.x; base < total_rays; base += gridDim.x * blockDim.x) {
         const int g = base + threadIdx.x;
         if (g >= total_rays) break;
@@ -590,7 +657,8 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 2   ? cast_ray_fast(lds_words, lds_blk, t, gx, gy, dx, dy)
+        float rng = VARIANT == 3   ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
+                    : VARIANT == 2 ? cast_ray_fast(lds_words, lds_blk, t, gx, gy, dx, dy)
                     : VARIANT == 1 ? cast_ray_skip(lds_words, lds_blk, t, gx, gy, dx, dy)
                                    : cast_ray_dda(lds_words, t, gx, gy, dx, dy);
         if (A > 1) {
@@ -693,6 +761,10 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<2, 2>))
     SET((rc_raycast_kernel<3, 2>))
     SET((rc_raycast_kernel<4, 2>))
+    SET((rc_raycast_kernel<1, 3>))
+    SET((rc_raycast_kernel<2, 3>))
+    SET((rc_raycast_kernel<3, 3>))
+    SET((rc_raycast_kernel<4, 3>))
     SET(rc_patch_kernel)
 #undef SET
     return hipSuccess;
@@ -720,7 +792,9 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
-    if (li.raycast_variant == 2) {
+    if (li.raycast_variant == 3) {
+        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 3><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_packed, s>>>(p, total));
+    } else if (li.raycast_variant == 2) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 2><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
     } else if (li.raycast_variant == 1) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 1><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
