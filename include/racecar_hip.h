@@ -92,7 +92,7 @@ typedef enum rc_field {
 } rc_field;
 
 /* Kernels, for rc_kernel_time(). */
-enum { RC_K_DYNAMICS = 0, RC_K_RAYCAST = 1, RC_K_PATCH = 2, RC_K_RESET = 3, RC_K_ACTIONS = 4, RC_K_COUNT = 5 };
+enum { RC_K_DYNAMICS = 0, RC_K_RAYCAST = 1, RC_K_PATCH = 2, RC_K_RESET = 3, RC_K_ACTIONS = 4, RC_K_FTG = 5, RC_K_COUNT = 6 };
 
 typedef struct rc_config {
     uint32_t struct_size;          /* = sizeof(rc_config), for ABI evolution                   */
@@ -155,6 +155,13 @@ int rc_set_pose(rc_env *env, const float *xyyaw_host);
 
 /* Fill RC_F_ACTION_IN with U(-1,1)^2 from Philox4x32-10 keyed by (seed, step, global car id). */
 int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step);
+
+/* Batched follow-the-gap agent on the device (the prefill / baseline agent of dreamer/dream.py:211-216, whose
+ * host form is agents.gap_follower.GapFollower): from the current LiDAR scan of every car, clip to 3 m,
+ * 5-beam smoothing over the forward 202.5 deg, safety bubble of +-60 beams around the closest return, steer to
+ * the centre of the widest run of beams whose smoothed range exceeds 1 m.  Writes (motor, steering) into RC_F_ACTION_IN: steering in [-1, 1],
+ * motor = motor_corner if |steering| > 0.35 else motor_straight (values in the caller's action convention). */
+int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner);
 
 int rc_get(rc_env *env, int32_t field, void **dev_ptr, size_t *bytes);
 int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes);

@@ -34,6 +34,7 @@
 #define MAX_STEER 0.42f
 #define MAX_VEL 5.0f
 #define ACCEL_MAX 4.0f
+#define DRAG 0.8f
 #define STEER_STEP 0.032f
 #define BOX_CX 0.175f
 #define BOX_HL 0.275f
@@ -256,10 +257,9 @@ void oc_step_range(const oc_track *t, const oc_cfg *c, oc_state *s, const float 
                 for (int a = 0; a < A; ++a) {
                     const int i = e * A + a;
                     const float m = motor[a];
-                    const float v_t = m >= 0.0f ? MAX_VEL : 0.0f;
-                    const float dv_max = (fabsf(m) * ACCEL_MAX) * DT;
-                    const float dv = clampf(v_t - s->v[i], -dv_max, dv_max);
-                    const float v = s->v[i] + dv;
+                    const float force = fabsf(m) * ACCEL_MAX;
+                    const float acc = (m >= 0.0f ? force : -force) - DRAG * s->v[i];
+                    const float v = clampf(s->v[i] + acc * DT, 0.0f, MAX_VEL);
                     const float dd = clampf(steer[a] * MAX_STEER - s->delta[i], -STEER_STEP, STEER_STEP);
                     const float dl = s->delta[i] + dd;
                     float sd, cd;
@@ -273,7 +273,7 @@ void oc_step_range(const oc_track *t, const oc_cfg *c, oc_state *s, const float 
                     s->theta[i] = th;
                     sincos32(th, &s->st[i], &s->ct[i]);
                     s->v[i] = v; s->delta[i] = dl; s->omega[i] = om;
-                    s->accel[i] = dv * INV_DT;
+                    s->accel[i] = acc;
                 }
                 s->steps[e] += 1;
                 for (int a = 0; a < A; ++a) {

@@ -57,6 +57,7 @@ WHEELBASE = f32(0.3302)
 MAX_STEER = f32(0.42)
 MAX_VEL = f32(5.0)
 ACCEL_MAX = f32(4.0)             # max_force 0.5 * 8.0
+DRAG = f32(0.8)                  # 1/s: ACCEL_MAX / MAX_VEL, so full throttle settles at max_velocity
 STEER_STEP = f32(0.032)          # 3.2 rad/s * dt
 INV_DT = f32(100.0)
 X_REAR, X_FRONT, HALF_W = -0.10, 0.45, 0.15
@@ -169,6 +170,34 @@ def random_actions(seed, step, n_cars, first_car=0):
     r0, r1, _, _ = philox4x32(car, u32(step), u32(1), u32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
     u = np.stack([(r >> u32(8)).astype(f32) * f32(2.0 ** -24) for r in (r0, r1)], axis=1)
     return (u * f32(2.0) - f32(1.0)).astype(f32)
+
+
+def follow_the_gap(lidar, motor_straight=0.6, motor_corner=0.3):
+    """Batched follow-the-gap (fp32 spec of racing_dreamer_amd's rc_follow_the_gap; interface of
+    agents.gap_follower.GapFollower used by dreamer/dream.py:211-216): float32 [n, 2] = (motor, steering)."""
+    lidar = np.asarray(lidar, f32).reshape(-1, N_BEAMS)
+    lo, n, bubble = 135, 810, 60
+    r = np.where(lidar[:, lo:lo + n] > f32(3.0), f32(3.0), lidar[:, lo:lo + n]).astype(f32)
+    pad = np.zeros((len(r), n + 4), f32)
+    pad[:, 2:-2] = r
+    sm = ((((pad[:, 0:n] + pad[:, 1:n + 1]) + pad[:, 2:n + 2]) + pad[:, 3:n + 3]) + pad[:, 4:n + 4]) * f32(0.2)
+    closest = sm.argmin(axis=1)                              # first minimum
+    idx = np.arange(n)[None, :]
+    gap = (sm > f32(1.0)) & ((idx < closest[:, None] - bubble) | (idx > closest[:, None] + bubble))
+    out = np.zeros((len(r), 2), f32)
+    for c in range(len(r)):
+        g = np.concatenate([[0], gap[c].astype(np.int8), [0]])
+        edges = np.diff(g)
+        starts, ends = np.nonzero(edges == 1)[0], np.nonzero(edges == -1)[0]
+        if len(starts) == 0:
+            continue
+        k = int((ends - starts).argmax())                    # first longest run
+        centre = f32(lo) + f32(2 * starts[k] + (ends[k] - starts[k]) - 1) * f32(0.5)
+        angle = f32(2.35619449019234492885) - centre * f32(0.00436737625568553)
+        steering = clamp32(angle / MAX_STEER, f32(-1.0), f32(1.0))
+        out[c, 0] = motor_corner if abs(steering) > f32(0.35) else motor_straight
+        out[c, 1] = steering
+    return out
 
 
 # ----------------------------------------------------------------------------- the env
@@ -284,10 +313,9 @@ class OracleRaceEnv:
             c = envs * A + a
             m, s = motor[:, a], steer[:, a]
             v, delta, theta = self.v[c], self.delta[c], self.theta[c]
-            v_t = np.where(m >= f32(0.0), MAX_VEL, f32(0.0))
-            dv_max = (np.abs(m) * ACCEL_MAX) * DT
-            dv = clamp32(v_t - v, -dv_max, dv_max)
-            v = v + dv
+            force = np.abs(m) * ACCEL_MAX
+            acc = np.where(m >= f32(0.0), force, -force) - DRAG * v
+            v = clamp32(v + acc * DT, f32(0.0), MAX_VEL)
             dd = clamp32(s * MAX_STEER - delta, -STEER_STEP, STEER_STEP)
             delta = delta + dd
             sd, cd = sincos32(delta)
@@ -300,7 +328,7 @@ class OracleRaceEnv:
             self.theta[c] = theta
             self.st[c], self.ct[c] = sincos32(theta)
             self.v[c], self.delta[c], self.omega[c] = v, delta, omega
-            self.accel[c] = dv * INV_DT
+            self.accel[c] = acc.astype(f32)
         self.steps[envs] += 1
         # --- collisions (H5)
         for a in range(A):

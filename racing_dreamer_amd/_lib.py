@@ -21,9 +21,9 @@ RC_MAX_CARS = 4
  F_PROGRESS, F_LAP, F_CHECKPOINT, F_DONE, F_TRUNCATED, F_WALL_COLLISION, F_OPPONENT_COLLISION, F_WRONG_WAY,
  F_FRESH, F_ACCELERATION, F_STEERING_ANGLE, F_ACTION_IN, F_COUNT) = range(23)
 
-K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_COUNT = range(6)
+K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_FTG, K_COUNT = range(7)
 KERNEL_NAMES = {K_DYNAMICS: "rc_dynamics_kernel", K_RAYCAST: "rc_raycast_kernel", K_PATCH: "rc_patch_kernel",
-                K_RESET: "rc_reset_kernel", K_ACTIONS: "rc_random_actions_kernel"}
+                K_RESET: "rc_reset_kernel", K_ACTIONS: "rc_random_actions_kernel", K_FTG: "rc_ftg_kernel"}
 
 
 class RcConfig(C.Structure):
@@ -50,6 +50,7 @@ SYMBOLS = {
     "rc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rc_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rc_set_pose": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_follow_the_gap": (C.c_int, [C.c_void_p, C.c_float, C.c_float]),
     "rc_fill_random_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "rc_get": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
     "rc_copy_out": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),

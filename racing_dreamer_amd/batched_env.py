@@ -196,6 +196,14 @@ class BatchedRaceEnv:
         (default where the table fits the LDS).  All variants return identical results."""
         L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
 
+    def follow_the_gap(self, motor_straight: float = 0.6, motor_corner: float = 0.3) -> torch.Tensor:
+        """Batched follow-the-gap agent (dreamer/dream.py:211-216 prefill): fills and returns `action_in`
+        from the current LiDAR scans; pass None to step() to apply it."""
+        self._enter()
+        L.check(self._lib.rc_follow_the_gap(self._h, motor_straight, motor_corner))
+        self._exit()
+        return self.views["action_in"]
+
     def fill_random_actions(self, seed: int, step: int) -> None:
         L.check(self._lib.rc_fill_random_actions(self._h, C.c_uint64(seed), C.c_uint32(step)))
 

@@ -1,18 +1,21 @@
 """Follow-the-gap prefill agent with the interface dreamer/dream.py:213-215 uses:
 ``GapFollower().action(obs) -> (motor, steering)`` from ``obs['lidar']`` (1080 beams, 270 deg).
 
-Host-side NumPy restatement of the reference's own follow-the-gap node
-(ros_agent/agents/follow_the_gap/src/agent.py:128-193,200-234): clip far ranges, smooth, zero a safety
-bubble around the closest return, steer at the centre of the widest remaining gap, slow down in
-proportion to the steering angle.  Steering is returned normalised to [-1, 1] (max 0.42 rad).
+The class the reference imports lives in the external racecar_gym repository (`agents/gap_follower.py`, not
+under /root/reference), so this is the classic follow-the-gap law written from its description: clip far
+ranges, smooth, zero a safety bubble around the closest return, steer at the centre of the widest run of
+beams longer than `gap_range`, slow down when steering hard.  (The reference's own ROS node, ros_agent/agents/follow_the_gap/src/agent.py,
+is a more elaborate disparity-extender + PID variant for the real car.)  Steering is returned normalised to
+[-1, 1] (max 0.42 rad).  The batched device version is BatchedRaceEnv.follow_the_gap().
 """
 import numpy as np
 
 
 class GapFollower:
-    def __init__(self, max_range: float = 3.0, bubble_radius: int = 60, smooth: int = 5, fov_deg: float = 270.0,
+    def __init__(self, max_range: float = 3.0, bubble_radius: int = 60, smooth: int = 5, gap_range: float = 1.0,
+                 fov_deg: float = 270.0,
                  max_steering: float = 0.42, straights_speed: float = 0.6, corners_speed: float = 0.3):
-        self.max_range, self.bubble, self.smooth = max_range, bubble_radius, smooth
+        self.max_range, self.bubble, self.smooth, self.gap_range = max_range, bubble_radius, smooth, gap_range
         self.fov = np.radians(fov_deg)
         self.max_steering = max_steering
         self.straights_speed, self.corners_speed = straights_speed, corners_speed
@@ -24,7 +27,7 @@ class GapFollower:
         r = np.convolve(np.clip(lidar[lo:hi], 0, self.max_range), np.ones(self.smooth) / self.smooth, "same")
         closest = int(r.argmin())
         r[max(0, closest - self.bubble):closest + self.bubble + 1] = 0.0
-        free = np.concatenate([[0], (r > 0).astype(np.int8), [0]])
+        free = np.concatenate([[0], (r > self.gap_range).astype(np.int8), [0]])
         edges = np.diff(free)
         starts, ends = np.nonzero(edges == 1)[0], np.nonzero(edges == -1)[0]
         if len(starts) == 0:

@@ -540,6 +540,13 @@ int rc_set_pose(rc_env *env, const float *xyyaw_host) {
     return observe(env);
 }
 
+int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+    TIMED(env, RC_K_FTG, rck_launch_ftg(env->params, env->actions_in, motor_straight, motor_corner, env->stream));
+    return RC_OK;
+}
+
 int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     const uint32_t first_car = env->params.first_env * (uint32_t)env->cfg.cars_per_env;

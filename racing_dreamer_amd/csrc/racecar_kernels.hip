@@ -206,10 +206,9 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, const floa
             for (int a = 0; a < A; ++a) {
                 Car &c = car[a];
                 const float m = motor[a];
-                const float v_t = m >= 0.0f ? RCS_MAX_VEL : 0.0f;
-                const float dv_max = (fabsf(m) * RCS_ACCEL_MAX) * RCS_DT;
-                const float dv = clampf(v_t - c.v, -dv_max, dv_max);
-                c.v = c.v + dv;
+                const float force = fabsf(m) * RCS_ACCEL_MAX;
+                const float acc = (m >= 0.0f ? force : -force) - RCS_DRAG * c.v;
+                c.v = clampf(c.v + acc * RCS_DT, 0.0f, RCS_MAX_VEL);
                 const float dd = clampf(steer[a] * RCS_MAX_STEER - c.dl, -RCS_STEER_STEP, RCS_STEER_STEP);
                 c.dl = c.dl + dd;
                 float sd, cd;
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, const floa
                 th = th < -RCS_PI ? th + RCS_TWO_PI : th;
                 c.th = th;
                 sincos32(th, c.st, c.ct);
-                c.ac = dv * RCS_INV_DT;
+                c.ac = acc;
             }
             steps += 1;
             // --- collisions (H5)
@@ -716,6 +715,114 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_qu
     }
 }
 
+// Follow-the-gap on the device: one wave per car, lane l owns the 13 consecutive beams FTG_LO + 13 l ...
+// Wave-level steps use shuffles only: (value, index) arg-min for the closest return, and an ordered
+// tree reduction of run summaries (leading / trailing / best run of gap beams) for the widest gap.
+#define FTG_LO 135
+#define FTG_N 810
+#define FTG_PER_LANE 13
+#define FTG_BUBBLE 60
+#define FTG_GAP_RANGE 1.0f      // a beam belongs to a gap if its smoothed range exceeds this [m]
+
+struct RunSummary { int len, pre, suf, best, bstart, all; };
+
+__device__ __forceinline__ RunSummary run_combine(const RunSummary &a, const RunSummary &b, int a_end) {
+    // a covers [.., a_end), b starts at a_end; ties keep the earlier run
+    RunSummary r;
+    r.len = a.len + b.len;
+    r.all = a.all & b.all;
+    r.pre = a.all ? a.len + b.pre : a.pre;
+    r.suf = b.all ? b.len + a.suf : b.suf;
+    const int cross = a.suf + b.pre, cstart = a_end - a.suf;
+    r.best = a.best; r.bstart = a.bstart;
+    if (cross > r.best) { r.best = cross; r.bstart = cstart; }
+    if (b.best > r.best) { r.best = b.best; r.bstart = b.bstart; }
+    return r;
+}
+
+__global__ __launch_bounds__(256) void rc_ftg_kernel(RcParams p, float *__restrict__ actions, float motor_straight,
+                                                      float motor_corner) {
+    const int lane = threadIdx.x & 63;
+    const int car = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (car >= p.n_cars) return;
+    const float *scan = p.out.lidar + (size_t)car * RC_N_BEAMS;
+    const int e0 = lane * FTG_PER_LANE;                              // first element (relative to FTG_LO)
+    float r[FTG_PER_LANE + 4];
+#pragma unroll
+    for (int k = 0; k < FTG_PER_LANE + 4; ++k) {                     // own beams plus a halo of 2 on each side
+        const int e = e0 + k - 2;
+        float v = 0.0f;                                              // zero padding outside the arc
+        if (e >= 0 && e < FTG_N) {
+            v = scan[FTG_LO + e];
+            v = v > 3.0f ? 3.0f : v;
+        }
+        r[k] = v;
+    }
+    float sm[FTG_PER_LANE];
+    float best_v = INFINITY;
+    int best_i = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < FTG_PER_LANE; ++k) {
+        const int e = e0 + k;
+        sm[k] = ((((r[k] + r[k + 1]) + r[k + 2]) + r[k + 3]) + r[k + 4]) * 0.2f;
+        if (e < FTG_N && sm[k] < best_v) { best_v = sm[k]; best_i = e; }
+    }
+    // closest return: wave arg-min, first index wins ties
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best_v, off);
+        const int oi = __shfl_xor(best_i, off);
+        if (ov < best_v || (ov == best_v && oi < best_i)) { best_v = ov; best_i = oi; }
+    }
+    const int closest = best_i;
+    // gap beams: positive after the bubble; summarise this lane's 13 beams
+    RunSummary s;
+    s.len = 0; s.pre = 0; s.suf = 0; s.best = 0; s.bstart = e0; s.all = 1;
+    int run = 0;
+#pragma unroll
+    for (int k = 0; k < FTG_PER_LANE; ++k) {
+        const int e = e0 + k;
+        const bool inside = e < FTG_N;
+        const bool gap = inside && sm[k] > FTG_GAP_RANGE && (e < closest - FTG_BUBBLE || e > closest + FTG_BUBBLE);
+        if (inside) {
+            s.len += 1;
+            if (gap) {
+                run += 1;
+                if (run > s.best) { s.best = run; s.bstart = e - run + 1; }
+            } else {
+                if (s.all) s.pre = run;
+                s.all = 0;
+                run = 0;
+            }
+        }
+    }
+    if (s.all) s.pre = run;
+    s.suf = run;
+    // ordered tree reduction: lane i absorbs lane i + off
+    int my_end = e0 + s.len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        RunSummary o;
+        o.len = __shfl_down(s.len, off); o.pre = __shfl_down(s.pre, off); o.suf = __shfl_down(s.suf, off);
+        o.best = __shfl_down(s.best, off); o.bstart = __shfl_down(s.bstart, off); o.all = __shfl_down(s.all, off);
+        if ((lane & (2 * off - 1)) == 0 && lane + off < 64) {
+            s = run_combine(s, o, my_end);
+            my_end += o.len;
+        }
+    }
+    if (lane == 0) {
+        float motor = 0.0f, steering = 0.0f;
+        if (s.best > 0) {
+            const float centre = (float)FTG_LO + ((float)(2 * s.bstart + s.best - 1)) * 0.5f;
+            const float angle = 2.35619449019234492885f - centre * 0.00436737625568553f;   // 135 deg - i * 270/1079 deg
+            steering = clampf(angle / RCS_MAX_STEER, -1.0f, 1.0f);
+            motor = fabsf(steering) > 0.35f ? motor_corner : motor_straight;
+        }
+        actions[2 * car] = motor;
+        actions[2 * car + 1] = steering;
+    }
+}
+
 __global__ __launch_bounds__(256) void rc_set_pose_kernel(RcParams p, const float *__restrict__ xyyaw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n_cars) return;
@@ -807,6 +914,12 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_PATCH * (RC_PATCH / 4);
     hipLaunchKernelGGL(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_ftg(const RcParams &p, float *actions, float motor_straight, float motor_corner, hipStream_t s) {
+    const int threads = 256, blocks = (p.n_cars + 3) / 4;
+    rc_ftg_kernel<<<dim3(blocks), dim3(threads), 0, s>>>(p, actions, motor_straight, motor_corner);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 #define RCS_MAX_STEER 0.42f       // ros_agent/models/dreamer/racing_dreamer.py:14
 #define RCS_MAX_VEL 5.0f          // ros_agent/models/dreamer/racing_dreamer.py:16
 #define RCS_ACCEL_MAX 4.0f        // max_force 0.5 (racing_dreamer.py:15) * 8 m/s^2 per unit force
+#define RCS_DRAG 0.8f             // 1/s = ACCEL_MAX / MAX_VEL: full throttle settles at max_velocity
 #define RCS_STEER_STEP 0.032f     // 3.2 rad/s * dt
 #define RCS_BOX_CX 0.175f         // car rectangle centre ahead of the rear axle
 #define RCS_BOX_HL 0.275f         // half length

@@ -26,6 +26,7 @@ MAX_FORCE = 0.5               # ros_agent/models/dreamer/racing_dreamer.py:15
 MAX_VEL = 5.0                 # ros_agent/models/dreamer/racing_dreamer.py:16
 FORCE_TO_ACCEL = 8.0          # m/s^2 per unit motor force                          (free)
 ACCEL_MAX = MAX_FORCE * FORCE_TO_ACCEL
+DRAG = ACCEL_MAX / MAX_VEL     # 1/s linear resistance: throttle m settles at m * MAX_VEL       (free)
 STEER_RATE = 3.2              # rad/s steering slew limit                           (free)
 X_REAR, X_FRONT, HALF_W = -0.10, 0.45, 0.15   # footprint in the body frame [m]    (free)
 FOOTPRINT_LONG_PTS, FOOTPRINT_SHORT_PTS = 12, 5

@@ -78,7 +78,7 @@ def test_bicycle_known_answer_circle_arc():
     env.reset()
     env.v[:] = 2.0
     env.delta[:] = 0.3
-    act = np.array([[0.0, 0.3 / 0.42]], np.float32)      # motor 0 keeps |dv| <= 0, steering holds delta
+    act = np.array([[0.4, 0.3 / 0.42]], np.float32)      # throttle 0.4 holds 2 m/s, steering holds delta
     env.v[:] = 2.0
     r = 0.3302 / np.tan(0.3)
     x0, y0, th0 = float(env.x[0]), float(env.y[0]), float(env.theta[0])
@@ -94,18 +94,21 @@ def test_bicycle_known_answer_circle_arc():
 
 
 def test_longitudinal_model_limits():
+    """dv/dt = |m| * 4 - 0.8 v (throttle) resp. -|m| * 4 - 0.8 v (brake): throttle m settles at 5 m m/s."""
     env = _box_env(size=2000)
     env.centerline[0, :2] = (5.0, 50.0)
     env.reset()
-    full = np.array([[1.0, 0.0]], np.float32)
+    out = None
     for k in range(200):
-        out = env.step(full)
-    assert out["speed"][0] == np.float32(5.0)             # saturates at max_velocity after 1.25 s
-    assert abs(out["pose"][0, 0] - (5.0 + 0.5 * 4 * 1.25 ** 2 + 5.0 * 0.75)) < 0.05
-    brake = np.array([[-1.0, 0.0]], np.float32)
-    for k in range(130):
-        out = env.step(brake)
-    assert out["speed"][0] == 0.0                         # negative motor = brake to standstill, never reverse
+        out = env.step(np.array([[1.0, 0.0]], np.float32))
+    assert abs(out["speed"][0] - 5.0 * (1 - np.exp(-0.8 * 2.0))) < 0.02        # 2 s of full throttle
+    assert abs(out["pose"][0, 0] - (5.0 + 5.0 * (2.0 - (1 - np.exp(-1.6)) / 0.8))) < 0.06
+    for k in range(1000):
+        out = env.step(np.array([[0.5, 0.0]], np.float32))
+    assert abs(out["speed"][0] - 2.5) < 0.02 and out["speed"][0] <= 5.0             # half throttle -> 2.5 m/s
+    for k in range(150):
+        out = env.step(np.array([[-1.0, 0.0]], np.float32))
+    assert out["speed"][0] == 0.0                          # negative motor = brake to standstill, never reverse
 
 
 def test_progress_lap_and_reward_over_a_scripted_lap():
