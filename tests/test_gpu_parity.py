@@ -301,3 +301,29 @@ def test_follow_the_gap_kernel_matches_oracle_and_drives():
     assert crashes <= n // 50                                 # random actions crash every env within ~100 steps
     assert float((out["progress_total"] - prog0).mean()) > 0.05 or crashes > 0
     env.close()
+
+
+def test_full_size_two_cars_32768_envs_match_oracle():
+    """BASELINE.json configs[3] size: 32 768 envs x 2 cars, treitlstrasse_v2, random_ball resets, inter-car
+    raycast + collision, against the C oracle."""
+    import os
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    from racing_dreamer_amd import spec
+    n = 32768
+    t = load_track("treitlstrasse_v2")
+    env = BatchedRaceEnv(t, n, 2, auto_reset=True)
+    cfg = ro.OracleConfig(num_envs=n, cars_per_env=2, auto_reset=True)
+    ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg,
+                              threads=len(os.sched_getaffinity(0)))
+    dv = env.reset(mode="random_ball", seed=5)
+    ov = ora.reset(mode=spec.RESET_RANDOM_BALL, seed=5)
+    for k in range(4):
+        env.fill_random_actions(seed=8, step=k)
+        dv = env.step(None, repeat=8)
+        ov = ora.step(ora.random_actions(8, k), repeat=8)
+    compare_outputs(dv, ov, n, 2, "32768 x 2 cars")
+    assert int(ov["opponent_collision"].sum()) > 0            # the inter-car path was exercised
+    env.close()
