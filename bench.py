@@ -110,7 +110,9 @@ def main():
         gather.wait()
     env.sync()
     env.reset_kernel_times()
-    env.set_profiling(True)          # HIP events around every kernel, on the stream they run on
+    from racing_dreamer_amd import _lib as L
+    # HIP events around the dominant kernels, recorded on the stream they run on
+    env.set_profiling(True, kernels=[L.K_RAYCAST, L.K_PATCH, L.K_DYNAMICS])
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):

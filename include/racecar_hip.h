@@ -172,7 +172,8 @@ int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes);
 int rc_sync(rc_env *env);
 void *rc_stream(rc_env *env);      /* the hipStream_t the handle launches on */
 
-/* Per-kernel timing with HIP events recorded on the handle's stream. */
+/* Per-kernel timing with HIP events recorded on the handle's stream.  enabled: 0 = off, 1 = every kernel,
+ * otherwise a bit mask (1 << RC_K_*) of the kernels to time (fewer events in a timed region). */
 int rc_set_profiling(rc_env *env, int32_t enabled);
 int rc_kernel_time(rc_env *env, int32_t kernel, double *total_ms, uint64_t *launches);
 int rc_reset_kernel_times(rc_env *env);

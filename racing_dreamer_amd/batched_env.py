@@ -208,8 +208,15 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_fill_random_actions(self._h, C.c_uint64(seed), C.c_uint32(step)))
 
     # ------------------------------------------------------------------ profiling
-    def set_profiling(self, on: bool) -> None:
-        L.check(self._lib.rc_set_profiling(self._h, int(on)))
+    def set_profiling(self, on, kernels=None) -> None:
+        """HIP-event timing of the kernels: on/off, or only the listed kernel ids (L.K_*)."""
+        mask = int(bool(on))
+        if on and kernels is not None:
+            mask = 0
+            for k in kernels:
+                mask |= 1 << k
+            mask |= 1 << 31 if mask == 1 else 0      # keep a single-kernel mask distinct from "1 = all"
+        L.check(self._lib.rc_set_profiling(self._h, mask))
 
     def reset_kernel_times(self) -> None:
         L.check(self._lib.rc_reset_kernel_times(self._h))

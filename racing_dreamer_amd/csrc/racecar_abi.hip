@@ -95,7 +95,7 @@ struct rc_env {
     bool has_track = false;
     bool was_reset = false;
     // profiling
-    bool profiling = false;
+    uint32_t profiling = 0;        // bit k set: time kernel k with HIP events
     std::vector<EventPair> pending;
     std::vector<EventPair> free_events;
     double k_ms[RC_K_COUNT] = {0};
@@ -124,7 +124,7 @@ struct KernelTimer {
     bool on = false;
     int begin(rc_env *e, int kernel) {
         env = e;
-        if (!e->profiling) return RC_OK;
+        if (!((e->profiling >> kernel) & 1u)) return RC_OK;
         if (e->pending.size() >= 4096) {
             int rc = drain_events(e);
             if (rc) return rc;
@@ -597,7 +597,7 @@ int rc_set_profiling(rc_env *env, int32_t enabled) {
         int rc = drain_events(env);
         if (rc) return rc;
     }
-    env->profiling = enabled != 0;
+    env->profiling = enabled == 1 ? 0xffffffffu : (uint32_t)enabled;
     return RC_OK;
 }
 

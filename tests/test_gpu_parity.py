@@ -325,5 +325,14 @@ def test_full_size_two_cars_32768_envs_match_oracle():
         dv = env.step(None, repeat=8)
         ov = ora.step(ora.random_actions(8, k), repeat=8)
     compare_outputs(dv, ov, n, 2, "32768 x 2 cars")
-    assert int(ov["opponent_collision"].sum()) > 0            # the inter-car path was exercised
+    # rear car at full throttle, front car braking: the pairs collide within ~1 s
+    act = np.tile(np.array([[-1.0, 0.0], [1.0, 0.0]], np.float32), (n, 1))
+    a_t = torch.from_numpy(act).cuda()
+    hits = 0
+    for k in range(14):
+        dv = env.step(a_t, repeat=8)
+        ov = ora.step(act, repeat=8)
+        hits += int(ov["opponent_collision"].sum())
+    compare_outputs(dv, ov, n, 2, "32768 x 2 cars, scripted")
+    assert hits > n                                            # the inter-car collision path was exercised
     env.close()
