@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only for functional tests on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--raycast-variant", type=int, default=None)
@@ -72,9 +74,13 @@ def main():
             print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
             sys.exit(2)
     distributed = world > 1 or (args.force_gather and "RANK" in os.environ)
-    torch.cuda.set_device(local_rank)
+    dev = local_rank % max(torch.cuda.device_count(), 1)      # ranks > GPUs only in --backend gloo functional tests
+    torch.cuda.set_device(dev)
     if distributed:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist.init_process_group("gloo")
 
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
     from racing_dreamer_amd.distributed import TrajectoryGather, shard_envs
@@ -83,7 +89,7 @@ def main():
     track = load_track(args.track)
     shard = shard_envs(args.envs * world, rank, world)
     env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
-                         device=local_rank, first_env=shard.first_env, auto_reset=True, profiling=False)
+                         device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
     if args.raycast_variant is not None:
         from racing_dreamer_amd import _lib as L
         L.check(env._lib.rc_set_raycast_variant(env._h, args.raycast_variant))
@@ -139,7 +145,7 @@ def main():
     dt4 = time.perf_counter() - t1
 
     if distributed:
-        tmax = torch.tensor([dt, dt4], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt, dt4], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt, dt4 = float(tmax[0].item()), float(tmax[1].item())
 

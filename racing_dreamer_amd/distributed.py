@@ -59,6 +59,13 @@ class TrajectoryGather:
     def launch(self, slab: torch.Tensor) -> None:
         self.wait()
         self.staging.copy_(slab.reshape(-1), non_blocking=True)
+        if dist.get_backend(self.group) == "gloo" and self.staging.is_cuda:
+            # gloo has no device all-gather: stage through the host (functional tests only)
+            host = self.staging.cpu()
+            out = torch.empty(self.world * host.numel(), dtype=host.dtype)
+            dist.all_gather_into_tensor(out, host, group=self.group)
+            self.gathered.copy_(out)
+            return
         self._work = dist.all_gather_into_tensor(self.gathered, self.staging, group=self.group, async_op=True)
 
     def wait(self) -> torch.Tensor:

@@ -1,0 +1,52 @@
+"""bench.py contract on a real GPU: one JSON line with the required keys; the N > 1 path end to end with two
+ranks sharing the one GPU of the test box (gloo backend - RCCL itself needs one GPU per rank)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_single_gpu_contract():
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--envs", "4096", "--track",
+                        "columbia", "--cpu-envs", "256"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
+    assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["value"] > 1e6 and d["config"]["workload"].startswith("4096 envs")
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 8
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_bench_two_ranks_functional():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "6", "--warmup",
+           "2", "--envs", "2048", "--backend", "gloo", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["scaling"] == "weak"
+    assert d["config"]["gather"] == "summary" and "cpu_baseline" not in d
