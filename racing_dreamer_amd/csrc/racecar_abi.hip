@@ -38,10 +38,6 @@ int fail(int code, const char *fmt, ...) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct FieldInfo {
-    size_t elem_bytes;   // bytes per car
-};
-
 // bytes per car of every rc_field, in arena order
 const size_t kFieldBytes[RC_F_COUNT] = {
     RC_N_BEAMS * 4, 24, 24, 4, 8, 4, 4, 4, 4, RC_PATCH * RC_PATCH,   // LIDAR .. OCCUPANCY

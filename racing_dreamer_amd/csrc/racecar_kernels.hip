@@ -572,10 +572,11 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
                                                  float dx, float dy) {
     int ix = (int)floorf(gx), iy = (int)floorf(gy);
     bool alive = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
-    const int blk_w = t.blk_w;
+    const int row_bytes = t.blk_w * 4;
+    const char *pkb = reinterpret_cast<const char *>(pk);
     uint32_t word = 0;
     if (alive) {
-        word = pk[__mul24(iy >> 2, blk_w) + (ix >> 2)];
+        word = *reinterpret_cast<const uint32_t *>(pkb + __mul24(iy >> 2, row_bytes) + (ix & ~3));
         alive = ((word >> (((iy & 3) << 2) | (ix & 3))) & 1u) == 0;
     }
     const bool started = alive;                                           // false: the sensor sits in a stop cell
@@ -586,41 +587,38 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
     const int kx = pxi << 2, ky = pyi << 2;
     const float tmax = t.tmax;
     float tt = 0.0f;
-    for (int guard = 0; guard < 2048 && __builtin_amdgcn_ballot_w64(alive) != 0; ++guard) {
-        if (alive) {
-            const int v = (int)(word >> 16);
-            const int vm = nonzero_mask(v);
-            const int r = v - 1;
-            const int xe = bfi(vm, (ix & ~3) + kx + ((r ^ nx) - nx), ix + pxi);
-            const int ye = bfi(vm, (iy & ~3) + ky + ((r ^ ny) - ny), iy + pyi);
-            const float txe = ((float)xe - gx) * idx;
-            const float tye = ((float)ye - gy) * idy;
-            const int mx = sign_mask(txe - tye);                          // -1: leaves through the x side
-            tt = fminf(txe, tye);
-            const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
-            const float pe = og + tt * od;
-            const float fl = floorf(pe);
-            int on = (int)fl;
-            if (fabsf((pe - fl) - 0.5f) > 0.499f) {                       // within 1e-3 of a boundary: exact count
-                const float oid = bfi(mx, idy, idx);
-                const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
-                const float osf = (float)os;
-                const float tc = tt + 0.0f;                               // canonical +0
-                const int m0 = max(__mul24(on - oi, os) - 1, 0);
-                const float b0 = (float)(oi + opi + __mul24(m0, os));
-                const float t2 = __int_as_float(__float_as_int(tc) - mx);   // x exit: y wins ties -> count t <= tt
-                const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
-                const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-                on = oi + __mul24(m0 + c0 + c1, os);
-            }
-            ix = bfi(mx, xe + nx, on);
-            iy = bfi(mx, on, ye + ny);
-            alive = tt < tmax;
-            if (alive) {
-                word = pk[__mul24(iy >> 2, blk_w) + (ix >> 2)];
-                alive = ((word >> (((iy & 3) << 2) | (ix & 3))) & 1u) == 0;
-            }
+    int guard = 0;
+    while (alive) {
+        const int v = (int)(word >> 16);
+        const int vm = nonzero_mask(v);
+        const int r = v - 1;
+        const int xe = bfi(vm, (ix & ~3) + kx + ((r ^ nx) - nx), ix + pxi);
+        const int ye = bfi(vm, (iy & ~3) + ky + ((r ^ ny) - ny), iy + pyi);
+        const float txe = ((float)xe - gx) * idx;
+        const float tye = ((float)ye - gy) * idy;
+        const int mx = sign_mask(txe - tye);                              // -1: leaves through the x side
+        tt = fminf(txe, tye);
+        const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
+        const float pe = og + tt * od;
+        const float fl = floorf(pe);
+        int on = (int)fl;
+        if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
+            const float oid = bfi(mx, idy, idx);
+            const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
+            const float osf = (float)os;
+            const float tc = tt + 0.0f;                                   // canonical +0
+            const int m0 = max(__mul24(on - oi, os) - 1, 0);
+            const float b0 = (float)(oi + opi + __mul24(m0, os));
+            const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
+            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
+            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
+            on = oi + __mul24(m0 + c0 + c1, os);
         }
+        ix = bfi(mx, xe + nx, on);
+        iy = bfi(mx, on, ye + ny);
+        if (!(tt < tmax) || ++guard > 2048) break;                        // the guard only bounds a logic error
+        word = *reinterpret_cast<const uint32_t *>(pkb + __mul24(iy >> 2, row_bytes) + (ix & ~3));
+        alive = ((word >> (((iy & 3) << 2) | (ix & 3))) & 1u) == 0;
     }
     if (!started) return 0.0f;
     const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
