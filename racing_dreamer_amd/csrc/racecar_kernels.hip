@@ -641,11 +641,11 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         }
         stage_bitmap(lds_words, t.ray_words, nwords);
     }
-    for (int base = blockIdx.x * blockDim.x; base < total_rays; base += gridDim.x * blockDim.x) {
-        const int g = base + threadIdx.x;
-        if (g >= total_rays) break;
-        const int car = g / RC_N_BEAMS;
-        const int beam = g - car * RC_N_BEAMS;
+    for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_rays; base += gridDim.x * blockDim.x) {
+        const unsigned g = base + threadIdx.x;          // unsigned indices: 32-bit offsets from scalar bases
+        if (g >= (unsigned)total_rays) break;
+        const unsigned car = g / RC_N_BEAMS;
+        const unsigned beam = g - car * RC_N_BEAMS;
         const float ct = p.st.ct[car], st = p.st.st[car];
         const float lx = p.st.x[car] + RCS_LIDAR_X * ct;
         const float ly = p.st.y[car] + RCS_LIDAR_X * st;
@@ -659,10 +659,10 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
                     : VARIANT == 1 ? cast_ray_skip(lds_words, lds_blk, t, gx, gy, dx, dy)
                                    : cast_ray_dda(lds_words, t, gx, gy, dx, dy);
         if (A > 1) {
-            const int env = car / A;
+            const unsigned env = car / A;
 #pragma unroll
-            for (int o = 0; o < A; ++o) {
-                const int oc = env * A + o;
+            for (unsigned o = 0; o < (unsigned)A; ++o) {
+                const unsigned oc = env * A + o;
                 if (oc != car) {
                     const float tc = ray_vs_car(lx, ly, dx, dy, p.st.x[oc], p.st.y[oc], p.st.ct[oc], p.st.st[oc]);
                     rng = tc < rng ? tc : rng;
