@@ -99,6 +99,7 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_create(C.byref(cfg), C.byref(self._h)))
         self._load_track(self.track)
         self.views: Dict[str, torch.Tensor] = {}
+        self._host_layout = {}
         base = self._arena_view.data_ptr()
         for name, (fid, dtype, tail) in _FIELD_VIEWS.items():
             if fid == L.F_OCCUPANCY and obs_type != "lidar_occupancy":
@@ -108,6 +109,7 @@ class BatchedRaceEnv:
             off = ptr.value - base
             t = self._arena_view[off:off + nb.value].view(dtype)
             self.views[name] = t.view(self.num_envs, self.cars_per_env, *tail)
+            self._host_layout[name] = (off, nb.value, str(dtype).replace("torch.", ""), tail)
         ptr, nb = C.c_void_p(), C.c_size_t()
         L.check(self._lib.rc_trajectory_slab(self._h, C.byref(ptr), C.byref(nb)))
         self.slab = self._arena_view[ptr.value - base:ptr.value - base + nb.value]
@@ -228,6 +230,16 @@ class BatchedRaceEnv:
             L.check(self._lib.rc_kernel_time(self._h, k, C.byref(ms), C.byref(n)))
             out[name] = {"total_ms": ms.value, "launches": int(n.value),
                          "avg_ms": ms.value / n.value if n.value else 0.0}
+        return out
+
+    def host_snapshot(self) -> Dict[str, np.ndarray]:
+        """Every output field on the host from ONE device-to-host copy of the arena (for small batches, e.g. the
+        single-env shim): dict of NumPy views [num_envs, cars_per_env, ...] into one host buffer."""
+        self.sync()
+        buf = self._arena_view.cpu().numpy()
+        out = {}
+        for name, (off, nb, dtype, tail) in self._host_layout.items():
+            out[name] = buf[off:off + nb].view(dtype).reshape(self.num_envs, self.cars_per_env, *tail)
         return out
 
     def host(self, name: str) -> np.ndarray:

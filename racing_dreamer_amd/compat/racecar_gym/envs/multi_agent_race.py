@@ -73,10 +73,13 @@ class MultiAgentRaceEnv:
     # ------------------------------------------------------------------ helpers
     def _fetch(self):
         env = self._env
-        env.sync()
-        h = {k: env.views[k][0].cpu().numpy() for k in
-             ("lidar", "pose", "velocity", "acceleration", "reward", "done", "progress", "lap", "time", "wrong_way",
-              "wall_collision", "opponent_collision", "checkpoint")}
+        if hasattr(env, "host_snapshot"):            # one device-to-host copy of the whole (4.5 KB per car) arena
+            h = {k: v[0] for k, v in env.host_snapshot().items()}
+        else:
+            env.sync()
+            h = {k: env.views[k][0].cpu().numpy() for k in
+                 ("lidar", "pose", "velocity", "acceleration", "reward", "done", "progress", "lap", "time",
+                  "wrong_way", "wall_collision", "opponent_collision", "checkpoint")}
         obs, state = {}, {}
         for i, a in enumerate(self._scenario.agents):
             acc = np.zeros(6)

@@ -83,3 +83,26 @@ def test_registered_host_task_and_changing_track(tmp_path):
     env.reset(mode="grid")
     assert env.scenario.world._config.name == "treitlstrasse_v2"
     env.close()
+
+
+def test_shim_single_env_step_rate(tmp_path):
+    """The B = 1 compatibility path is for drop-in use, not throughput - but it should still be far above the
+    reference's ~270 sim-steps/s per worker."""
+    import time
+    from racing_dreamer_amd import compat
+    compat.install()
+    from racecar_gym.envs.multi_agent_race import MultiAgentRaceEnv, MultiAgentScenario
+    env = MultiAgentRaceEnv(MultiAgentScenario.from_spec(_scenario(
+        tmp_path, "columbia", params=dict(laps=10, time_limit=180.0, terminate_on_collision=False, collision_reward=0.0))))
+    env.reset(mode="grid")
+    act = {"A": {"motor": 0.3, "steering": 0.05}}
+    for _ in range(20):
+        env.step(act)
+    t0 = time.perf_counter()
+    n = 300
+    for _ in range(n):
+        obs, rew, done, info = env.step(act)
+    rate = n / (time.perf_counter() - t0)
+    print(f"shim single-env rate: {rate:.0f} steps/s")
+    assert rate > 1000
+    env.close()
