@@ -1,0 +1,103 @@
+"""C-ABI / host API behaviour on a real GPU: error codes and messages, arena layout, handle lifecycle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_error_paths_are_reported_not_raised_as_crashes():
+    import torch
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv("columbia", 8, 1)
+    zero = torch.zeros(8, 1, 2, device="cuda")
+    with pytest.raises(L.RacecarHipError, match="Must reset environment."):      # dreamer/wrappers.py:148
+        env.step(zero)
+    with pytest.raises(L.RacecarHipError, match="Must reset environment."):
+        env.set_pose(np.zeros((8, 3), np.float32))
+    with pytest.raises(ValueError, match="reset mode"):
+        env.reset(mode="somewhere")
+    with pytest.raises(L.RacecarHipError, match="first rc_reset must reset every env"):
+        env.reset(mask=np.ones(8, np.uint8))
+    env.reset()
+    with pytest.raises(ValueError, match="actions must hold"):
+        env.step(torch.zeros(7, 2, device="cuda"))
+    with pytest.raises(L.RacecarHipError, match="repeat must be >= 1"):
+        env.step(zero, repeat=0)
+    with pytest.raises(L.RacecarHipError, match="unknown raycast variant"):
+        env.set_raycast_variant(9)
+    with pytest.raises(KeyError):
+        env.views["lidar_occupancy"]                       # not enabled for obs_type=lidar
+    ptr, nb = C.c_void_p(), C.c_size_t()
+    assert env._lib.rc_get(env._h, L.F_OCCUPANCY, C.byref(ptr), C.byref(nb)) == -1
+    assert b"not enabled" in env._lib.rc_last_error()
+    env.step(zero)                                         # still usable after the errors
+    env.close()
+    env.close()                                            # idempotent
+    with pytest.raises(ValueError, match="obs_type"):
+        BatchedRaceEnv("columbia", 8, 1, obs_type="camera")
+    with pytest.raises(L.RacecarHipError, match="cars_per_env"):
+        BatchedRaceEnv("columbia", 8, 5)
+    with pytest.raises(FileNotFoundError):
+        BatchedRaceEnv("nowhere", 8, 1)
+
+
+def test_large_map_falls_back_to_coarser_tables():
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv("gbr", 4, 1)      # 130 KB bitmap: the packed 4x4 table (247 KB) cannot fit the LDS,
+    env.reset()                            # bitmap + an 8x8 block table (145 KB) can
+    with pytest.raises(L.RacecarHipError, match="too large"):
+        env.set_raycast_variant(3)
+    for v in (0, 1, 2):
+        env.set_raycast_variant(v)
+        env.step(None)
+    env.close()
+
+
+def test_slab_layout_and_zero_copy_views():
+    """The trajectory slab is the leading part of the arena in record order; parsing the slab bytes the way a
+    remote rank does (distributed.slab_field_views) gives the same tensors as the env's own views."""
+    import torch
+    from racing_dreamer_amd import spec
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.distributed import slab_field_views
+    for obs_type in ("lidar", "lidar_occupancy"):
+        env = BatchedRaceEnv("austria", 96, 2, obs_type=obs_type, auto_reset=True)
+        env.reset(mode="random_ball", seed=3)
+        env.fill_random_actions(1, 0)
+        out = env.step(None, repeat=4)
+        torch.cuda.synchronize()
+        n = 96 * 2
+        rec = 4 * spec.RECORD_FLOATS + (4096 if obs_type == "lidar_occupancy" else 0)
+        assert rec * n <= env.slab.numel() <= rec * n + 64 * 10           # 4 396 B (8 492 B) per car + alignment
+        parsed = slab_field_views(env.slab, n, obs_type == "lidar_occupancy")
+        for name, t in parsed.items():
+            assert torch.equal(t.reshape(-1), out[name].reshape(-1)), name
+        assert env.summary_slab.data_ptr() == out["pose"].data_ptr()
+        assert env.summary_slab.numel() >= 76 * n
+        host = env.host_snapshot()
+        for name in ("lidar", "reward", "done", "lap"):
+            assert np.array_equal(host[name], out[name].cpu().numpy()), name
+        env.close()
+
+
+def test_two_handles_are_independent():
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    a = BatchedRaceEnv("columbia", 16, 1, auto_reset=True)
+    b = BatchedRaceEnv("treitlstrasse_v2", 16, 1, auto_reset=True)
+    ra, rb = a.reset(mode="random", seed=1), b.reset(mode="random", seed=1)
+    torch.cuda.synchronize()
+    la = ra["lidar"].clone()
+    for k in range(5):
+        b.fill_random_actions(2, k)
+        b.step(None)
+    torch.cuda.synchronize()
+    assert torch.equal(a.views["lidar"], la)               # stepping b does not touch a
+    a.close()
+    b.fill_random_actions(2, 9)
+    b.step(None)                                           # b survives a's destruction
+    b.close()
