@@ -61,6 +61,10 @@ typedef enum rc_status {
 enum { RC_TASK_MAX_PROGRESS = 0, RC_TASK_MAX_SPEED = 1 };           /* scenario yml task_name; tasks.py:4-22 */
 enum { RC_RESET_GRID = 0, RC_RESET_RANDOM = 1, RC_RESET_RANDOM_BALL = 2 };  /* dream.py:105-108,120 */
 enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1 };              /* dream.py obs_type */
+/* what RC_F_LIDAR holds: metres, or the caller-side scaling fused into the scan's store */
+enum { RC_LIDAR_METRES = 0,
+       RC_LIDAR_DREAMER = 1,      /* range / 15 - 0.5              tools.preprocess, dreamer/tools.py:274          */
+       RC_LIDAR_UNIT = 2 };       /* (range - 0) * (1 / (15 - 0))  NormalizeObservations, single_agent.py:92-99   */
 
 /* Output / state fields, for rc_get() and rc_copy_out().  n = num_envs * cars_per_env. */
 typedef enum rc_field {
@@ -112,6 +116,7 @@ typedef struct rc_config {
     float    action_high[2];
     int32_t  time_limit_steps;     /* TimeLimit duration in rc_step calls; 0 = off (wrappers.py:137-158) */
     int32_t  auto_reset;           /* 1: finished envs are reset inside rc_step (batched rollouts) */
+    int32_t  lidar_transform;      /* RC_LIDAR_*: scaling applied when the scan is stored                  */
     void    *external_arena;       /* optional caller-owned device memory for the output arena */
     size_t   external_arena_bytes; /*   must be >= rc_arena_bytes(cfg)                         */
     void    *stream;               /* optional hipStream_t to run on; NULL = library creates one */

@@ -32,7 +32,8 @@ class RcConfig(C.Structure):
         ("first_env", C.c_int64), ("obs_type", C.c_int32), ("task", C.c_int32), ("laps", C.c_int32),
         ("time_limit", C.c_float), ("terminate_on_collision", C.c_int32), ("collision_reward", C.c_float),
         ("remap_actions", C.c_int32), ("action_low", C.c_float * 2), ("action_high", C.c_float * 2),
-        ("time_limit_steps", C.c_int32), ("auto_reset", C.c_int32), ("external_arena", C.c_void_p),
+        ("time_limit_steps", C.c_int32), ("auto_reset", C.c_int32), ("lidar_transform", C.c_int32),
+        ("external_arena", C.c_void_p),
         ("external_arena_bytes", C.c_size_t), ("stream", C.c_void_p),
     ]
 

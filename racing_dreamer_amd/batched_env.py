@@ -51,6 +51,8 @@ _FIELD_VIEWS = {
 }
 
 OBS_TYPES = {"lidar": 0, "lidar_occupancy": 1}
+# scaling fused into the scan's store: metres | dreamer (x/15 - 0.5, tools.py:274) | unit (x/15, single_agent.py:92-99)
+LIDAR_TRANSFORMS = {"metres": 0, "dreamer": 1, "unit": 2}
 TASKS = {"maximize_progress": spec.TASK_MAX_PROGRESS, "max_progress": spec.TASK_MAX_PROGRESS,
          "max_speed": spec.TASK_MAX_SPEED}
 
@@ -61,7 +63,8 @@ class BatchedRaceEnv:
                  task: str = "maximize_progress", laps: int = 10, time_limit: float = 180.0,
                  terminate_on_collision: bool = True, collision_reward: float = -1.0,
                  remap_actions: bool = False, action_low=spec.ACTION_LOW, action_high=spec.ACTION_HIGH,
-                 time_limit_steps: int = 0, auto_reset: bool = False, profiling: bool = False):
+                 time_limit_steps: int = 0, auto_reset: bool = False, profiling: bool = False,
+                 lidar_transform: str = "metres"):
         if obs_type not in OBS_TYPES:
             raise ValueError(f"obs_type must be one of {sorted(OBS_TYPES)}, got {obs_type!r}")
         if task not in TASKS:
@@ -85,6 +88,9 @@ class BatchedRaceEnv:
         cfg.action_low[:] = [float(v) for v in action_low]
         cfg.action_high[:] = [float(v) for v in action_high]
         cfg.time_limit_steps, cfg.auto_reset = int(time_limit_steps), int(auto_reset)
+        if lidar_transform not in LIDAR_TRANSFORMS:
+            raise ValueError(f"lidar_transform must be one of {sorted(LIDAR_TRANSFORMS)}, got {lidar_transform!r}")
+        cfg.lidar_transform = LIDAR_TRANSFORMS[lidar_transform]
         nbytes = self._lib.rc_arena_bytes(C.byref(cfg))
         with torch.cuda.device(self.device):
             self.arena = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)

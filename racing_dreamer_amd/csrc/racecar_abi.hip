@@ -187,6 +187,8 @@ int check_cfg(const rc_config *cfg) {
         return fail(RC_ERR_INVALID, "num_envs * cars_per_env * 1080 must fit int32");
     if (cfg->obs_type != RC_OBS_LIDAR && cfg->obs_type != RC_OBS_LIDAR_OCCUPANCY)
         return fail(RC_ERR_INVALID, "unknown obs_type %d", cfg->obs_type);
+    if (cfg->lidar_transform < RC_LIDAR_METRES || cfg->lidar_transform > RC_LIDAR_UNIT)
+        return fail(RC_ERR_INVALID, "unknown lidar_transform %d", cfg->lidar_transform);
     if (cfg->task != RC_TASK_MAX_PROGRESS && cfg->task != RC_TASK_MAX_SPEED)
         return fail(RC_ERR_INVALID, "unknown task %d", cfg->task);
     return RC_OK;
@@ -344,6 +346,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     p.time_limit_steps = cfg->time_limit_steps;
     p.auto_reset = cfg->auto_reset;
     p.render_patch = occ ? 1 : 0;
+    p.lidar_transform = cfg->lidar_transform;
     p.time_limit = cfg->time_limit;
     p.collision_reward = cfg->collision_reward;
     p.act_lo0 = cfg->action_low[0];

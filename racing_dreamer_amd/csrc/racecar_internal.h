@@ -44,6 +44,7 @@ struct RcParams {
     int32_t num_envs, cars_per_env, n_cars;
     uint32_t first_env;
     int32_t task, laps, terminate_on_collision, remap_actions, time_limit_steps, auto_reset, render_patch;
+    int32_t lidar_transform;
     float time_limit, collision_reward;
     float act_lo0, act_lo1, act_hi0, act_hi1;
     int32_t reset_mode;

@@ -669,6 +669,8 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
                 }
             }
         }
+        if (p.lidar_transform == 1) rng = rng / RCS_MAX_RANGE - 0.5f;                 // dreamer/tools.py:274
+        else if (p.lidar_transform == 2) rng = rng * (1.0f / RCS_MAX_RANGE);          // single_agent.py:92-99
         p.out.lidar[g] = rng;
     }
 }

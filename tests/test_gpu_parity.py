@@ -336,3 +336,26 @@ def test_full_size_two_cars_32768_envs_match_oracle():
     compare_outputs(dv, ov, n, 2, "32768 x 2 cars, scripted")
     assert hits > n                                            # the inter-car collision path was exercised
     env.close()
+
+
+def test_fused_lidar_scaling_matches_the_callers_formulas():
+    """lidar_transform fuses tools.preprocess (x / 15 - 0.5, dreamer/tools.py:274) or NormalizeObservations
+    ((x - low) * 1/(high - low), single_agent.py:92-99, pinned by golden G8) into the scan's store."""
+    import torch
+    from oracle import wrappers_port as wp
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    raw = BatchedRaceEnv("austria", 128, 1)
+    raw.reset(mode="random", seed=2)
+    torch.cuda.synchronize()
+    r = raw.views["lidar"].cpu().numpy()
+    for name, fn in (("dreamer", lambda x: (x / np.float32(15.0) - np.float32(0.5)).astype(np.float32)),
+                     ("unit", lambda x: (x * np.float32(1.0 / 15.0)).astype(np.float32))):
+        env = BatchedRaceEnv("austria", 128, 1, lidar_transform=name)
+        env.reset(mode="random", seed=2)
+        torch.cuda.synchronize()
+        got = env.views["lidar"].cpu().numpy()
+        assert np.array_equal(got, fn(r)), name
+        env.close()
+    assert np.allclose(wp.preprocess_lidar(r.astype(np.float64)), r / np.float32(15.0) - np.float32(0.5), atol=1e-7)
+    assert np.allclose(wp.normalize_obs(r.astype(np.float64), 0.0, 15.0), r * np.float32(1.0 / 15.0), atol=1e-7)
+    raw.close()
