@@ -616,7 +616,9 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
         }
         ix = bfi(mx, xe + nx, on);
         iy = bfi(mx, on, ye + ny);
-        if (!(tt < tmax) || ++guard > 2048) break;                        // the guard only bounds a logic error
+        // No range test here: boundary times only grow, so a ray that passes 15 m is still "no return" when
+        // it finally stops (at a wall or at the sentinel ring) - decided once, after the loop.
+        if (++guard > 4096) break;                                        // bounds a logic error only
         word = *reinterpret_cast<const uint32_t *>(pkb + __mul24(iy >> 2, row_bytes) + (ix & ~3));
         alive = ((word >> (((iy & 3) << 2) | (ix & 3))) & 1u) == 0;
     }
