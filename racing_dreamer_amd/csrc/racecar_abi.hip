@@ -164,7 +164,7 @@ void set_launch_geometry(rc_env *env) {
         return (int)std::min<long long>((items + threads - 1) / threads, (long long)li.n_cu * wg_per_cu);
     };
     const long long rays = (long long)env->n_cars * RC_N_BEAMS;
-    const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 4);
+    const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
     li.ray_blocks = blocks_for(li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
 }

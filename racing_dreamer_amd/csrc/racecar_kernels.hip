@@ -693,39 +693,60 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
 // heading = +col, 3.125 cells per pixel, 1 = drivable.  Direct inverse map of the reference's
 // crop -> rotate -> centre-crop -> resize chain: centred on the north-west corner of the car's cell,
 // one nearest-cell tap per pixel, taps outside the reference's 220-cell crop window read 0.
-// One lane renders 4 adjacent pixels of a row and stores them as one 32-bit word.
-__global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_quads) {
+// One lane renders 16 adjacent pixels of a row (a quarter row) and stores them as one 16-byte vector; the
+// tap is branch-free: a rejected tap reads cell (0, 0) and its result is masked.
+__device__ __forceinline__ uint32_t select64u(bool cond, uint32_t a, uint32_t b) {
+    uint32_t r;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(cond);
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
     stage_bitmap(lds_words, t.drv_words, t.h * t.pitch);
-    uint32_t *out32 = reinterpret_cast<uint32_t *>(p.out.patch);
-    for (int base = blockIdx.x * blockDim.x; base < total_quads; base += gridDim.x * blockDim.x) {
-        const int q = base + threadIdx.x;
-        if (q >= total_quads) break;
-        const int car = q >> 10;              // 64 rows * 16 quads
-        const int row = (q >> 4) & 63;
-        const int c0 = (q & 15) * 4;
-        uint32_t word = 0;
-        if (!p.st.fresh[car]) {               // reset observation is all zeros, dreamer/wrappers.py:413
+    uint4 *out128 = reinterpret_cast<uint4 *>(p.out.patch);
+    const int wm1 = t.w - 1, hm1 = t.h - 1, pitch4 = t.pitch * 4;
+    const char *lds_bytes = reinterpret_cast<const char *>(lds_words);
+    for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
+        const unsigned q = base + threadIdx.x;
+        if (q >= (unsigned)total_items) break;
+        const unsigned car = q >> 8;             // 64 rows * 4 quarter rows
+        const unsigned row = (q >> 2) & 63u;
+        const unsigned c0 = (q & 3u) * 16u;
+        uint32_t words[4] = {0u, 0u, 0u, 0u};
+        if (!p.st.fresh[car]) {                  // reset observation is all zeros, dreamer/wrappers.py:413
             const float ct = p.st.ct[car], st = p.st.st[car];
             int icx, icy;
             cell_of(t, p.st.x[car], p.st.y[car], icx, icy);
+            icy += 1;
             const float v = -(((float)row + (0.5f - 32.0f)) * RCS_PATCH_CELLS);
             const float vst = v * st, vct = v * ct;
+            float u = ((float)c0 + (0.5f - 32.0f)) * RCS_PATCH_CELLS;     // exact; + 3.125 per pixel stays exact
+            // a tap at cell offset (fx, fy) counts iff it is inside the reference's [-110, 110) crop window AND
+            // inside the grid: one unsigned range test per axis on the offset itself
+            int lox = max(-110, -icx), hix = min(109, wm1 - icx);
+            int loy = max(-110, -icy), hiy = min(109, hm1 - icy);
+            if (hix < lox) { lox = 0x40000000; hix = lox; }                // empty range: nothing passes
+            if (hiy < loy) { loy = 0x40000000; hiy = loy; }
+            const unsigned spanx = (unsigned)(hix - lox), spany = (unsigned)(hiy - loy);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float u = ((float)(c0 + k) + (0.5f - 32.0f)) * RCS_PATCH_CELLS;
+            for (int k = 0; k < 16; ++k) {
                 const float ox = u * ct - vst;
                 const float oy = u * st + vct;
-                const bool inwin = ox >= -RCS_PATCH_WINDOW && ox < RCS_PATCH_WINDOW && oy >= -RCS_PATCH_WINDOW &&
-                                   oy < RCS_PATCH_WINDOW;
-                const int ix = icx + (int)floorf(ox), iy = (icy + 1) + (int)floorf(oy);
-                const bool ok = inwin && (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
-                const uint32_t bit = ok ? (uint32_t)bit_at(lds_words, t.pitch, ix, iy) : 0u;
-                word |= bit << (8 * k);
+                const int fx = (int)floorf(ox), fy = (int)floorf(oy);
+                const int ix = icx + fx, iy = icy + fy;
+                const bool ok = (unsigned)(fx - lox) <= spanx && (unsigned)(fy - loy) <= spany;
+                const uint32_t m = select64u(ok, 0xffffffffu, 0u);       // cell (0, 0) stands in for rejected taps
+                const int ixc = ix & (int)m, iyc = iy & (int)m;
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(lds_bytes + __mul24(iyc, pitch4) + ((ixc >> 3) & ~3));
+                const uint32_t bit = (w >> (ixc & 31)) & m & 1u;
+                words[k >> 2] |= bit << (8 * (k & 3));
+                u += RCS_PATCH_CELLS;
             }
         }
-        out32[q] = word;
+        out128[q] = make_uint4(words[0], words[1], words[2], words[3]);
     }
 }
 
@@ -926,7 +947,7 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 }
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
-    const int total = p.n_cars * RC_PATCH * (RC_PATCH / 4);
+    const int total = p.n_cars * RC_PATCH * (RC_PATCH / 16);
     hipLaunchKernelGGL(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
     return hipGetLastError();
 }
