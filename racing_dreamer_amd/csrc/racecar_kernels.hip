@@ -330,6 +330,12 @@ __device__ __forceinline__ float ray_vs_car(float lx, float ly, float dx, float 
                                             float st2) {
     const float cx = ox + RCS_BOX_CX * ct2, cy = oy + RCS_BOX_CX * st2;
     const float rx = lx - cx, ry = ly - cy;
+    // Conservative early out (most rays, usually whole waves): the rectangle lies inside the circle of radius
+    // 0.3133 m around its centre, so a ray whose line passes that centre by more than 0.32 m, or whose centre
+    // projection is more than 0.32 m behind the sensor or beyond range, cannot produce a return in the exact
+    // slab test below (margins are 1000x the fp32 rounding of these quantities).
+    const float along = -(rx * dx + ry * dy);
+    if (fabsf(rx * dy - ry * dx) > 0.32f || along < -0.32f || along > RCS_MAX_RANGE + 0.32f) return INFINITY;
     const float px = rx * ct2 + ry * st2;
     const float py = ry * ct2 - rx * st2;
     const float ex = dx * ct2 + dy * st2;
