@@ -37,6 +37,8 @@ def parse_args():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--cars", type=int, default=1)
     ap.add_argument("--track", default="austria")
+    ap.add_argument("--mixed-tracks", action="store_true",
+                    help="BASELINE.json configs[4]: rank r runs track [columbia, austria, barcelona][r mod 3]")
     ap.add_argument("--obs-type", default="lidar", choices=["lidar", "lidar_occupancy"])
     ap.add_argument("--repeat", type=int, default=1, help="action repeat (sub-steps per step)")
     ap.add_argument("--gather", default="summary", choices=["summary", "full", "none"],
@@ -86,7 +88,8 @@ def main():
     from racing_dreamer_amd.distributed import TrajectoryGather, shard_envs
     from racing_dreamer_amd.track_assets import load_track
 
-    track = load_track(args.track)
+    track_name = ["columbia", "austria", "barcelona"][rank % 3] if args.mixed_tracks else args.track
+    track = load_track(track_name)
     shard = shard_envs(args.envs * world, rank, world)
     env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
                          device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
@@ -161,18 +164,20 @@ def main():
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             with open(tp) as f:
-                traffic = json.load(f).get(f"{args.track}:{shard.num_envs}x{args.cars}:{args.obs_type}")
+                traffic = json.load(f).get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
         out = {
             "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"{args.envs} envs/GPU x {args.cars} car, track {args.track}, obs_type={args.obs_type}, "
+                "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
+                            f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
                             f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
                             f"auto-reset, action_repeat {args.repeat}",
                 "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
-                "track": args.track, "obs_type": args.obs_type, "action_repeat": args.repeat,
+                "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
+                "obs_type": args.obs_type, "action_repeat": args.repeat,
                 "parallelism": f"env-sharded x{world}" + ("" if gather is None else
                                 f" + overlapped RCCL all-gather of the {gather_mode} trajectory record every step "
                                 f"({gather_src.numel()} B per GPU per step)"),

@@ -359,3 +359,29 @@ def test_fused_lidar_scaling_matches_the_callers_formulas():
     assert np.allclose(wp.preprocess_lidar(r.astype(np.float64)), r / np.float32(15.0) - np.float32(0.5), atol=1e-7)
     assert np.allclose(wp.normalize_obs(r.astype(np.float64), 0.0, 15.0), r * np.float32(1.0 / 15.0), atol=1e-7)
     raw.close()
+
+
+def test_mixed_track_shards_like_config_4():
+    """BASELINE.json configs[4] in miniature: rank r of an 8-rank job owns envs [r B, (r+1) B) on track
+    [columbia, austria, barcelona][r mod 3].  Each shard (run here one after the other on the one GPU) must equal
+    the oracle run with the same global env offset."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.distributed import shard_envs
+    from racing_dreamer_amd.track_assets import load_track
+    from racing_dreamer_amd import spec
+    per_rank, world = 192, 8
+    for rank in (0, 1, 2, 5, 7):
+        sh = shard_envs(per_rank * world, rank, world)
+        name = ["columbia", "austria", "barcelona"][rank % 3]
+        t = load_track(name)
+        env = BatchedRaceEnv(t, sh.num_envs, 1, auto_reset=True, first_env=sh.first_env)
+        ora = make_oracle(t, num_envs=sh.num_envs, auto_reset=True, first_env=sh.first_env)
+        dv = env.reset(mode="random", seed=13)
+        ov = ora.reset(mode=spec.RESET_RANDOM, seed=13)
+        for k in range(6):
+            env.fill_random_actions(seed=1, step=k)
+            dv = env.step(None, repeat=4)
+            ov = ora.step(ro.random_actions(1, k, sh.num_envs, first_car=sh.first_env), repeat=4)
+        compare_outputs(dv, ov, sh.num_envs, 1, f"rank {rank} on {name}")
+        env.close()
