@@ -165,7 +165,7 @@ void set_launch_geometry(rc_env *env) {
     };
     const long long rays = (long long)env->n_cars * RC_N_BEAMS;
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
-    li.ray_blocks = blocks_for(li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
+    li.ray_blocks = blocks_for(li.raycast_variant == 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
 }
 
@@ -467,6 +467,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.blk_w = blk_w; t.blk_h = blk_h; t.blk_shift = blk_shift; t.blk_bytes = (int32_t)blk_bytes;
     HIP_TRY(hipMemcpy(m, packed.data(), packed_bytes, hipMemcpyHostToDevice)); t.packed_blocks = (const uint32_t *)m; m += packed_bytes;
     t.packed_bytes = (int32_t)packed_bytes;
+    t.packed_w = pk_w;
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
@@ -476,7 +477,10 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.lds_bytes = bm_bytes;
     li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
     li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
-    li.raycast_variant = li.lds_bytes_packed ? 3 : (li.lds_bytes_skip ? 2 : 0);
+    // default: the packed table in LDS when two workgroups per CU fit (<= 80 KiB), else the same kernel reading
+    // the table through L1/L2 (measured: austria 0.97 ms LDS vs 1.09 ms global; barcelona 1.29 ms global vs
+    // 1.75 ms for the LDS bitmap + u8 table at one workgroup per CU; gbr 1.24 vs 2.4 ms)
+    li.raycast_variant = (li.lds_bytes_packed && li.lds_bytes_packed <= 80 * 1024) ? 3 : 4;
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
@@ -620,7 +624,7 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (variant < 0 || variant > 3) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (variant < 0 || variant > 4) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
     if (variant == 3 && env->launch.lds_bytes_packed == 0)
         return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");

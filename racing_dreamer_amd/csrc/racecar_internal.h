@@ -15,7 +15,7 @@ struct RcTrackDev {
                                  // Chebyshev distance to the nearest occupied/ring cell (0 = block not free)
     const uint32_t *packed_blocks; // [blk_h][blk_w] for 4x4 blocks: bits 0-15 occupancy of the block's cells
                                  // (bit (iy&3)*4 + (ix&3), sentinel ring included), bits 16-23 the value above
-    int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes;
+    int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes, packed_w;   // packed_w: uint32 per packed row
     int32_t h, w, pitch, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
 };
@@ -58,7 +58,8 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
     size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8
-    int32_t raycast_variant;     // 0 plain, 1 skipping, 2 skipping tuned, 3 tuned + packed table (identical results)
+    int32_t raycast_variant;     // 0 plain, 1 skipping, 2 skipping tuned, 3 tuned + packed table in LDS,
+                                 // 4 packed table read from global memory (identical results)
 };
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`

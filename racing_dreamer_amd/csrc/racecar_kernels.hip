@@ -586,7 +586,7 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
                                                  float dx, float dy) {
     int ix = (int)floorf(gx), iy = (int)floorf(gy);
     bool alive = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
-    const int row_bytes = t.blk_w * 4;
+    const int row_bytes = t.packed_w * 4;
     const char *pkb = reinterpret_cast<const char *>(pk);
     uint32_t word = 0;
     if (alive) {
@@ -651,7 +651,9 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
     const RcTrackDev &t = p.trk;
     const int nwords = t.h * t.pitch;
     const uint8_t *lds_blk = reinterpret_cast<const uint8_t *>(lds_words + ((nwords + 15) & ~15));
-    if (VARIANT == 3) {
+    if (VARIANT == 4) {
+        // packed table read from global memory (L2 / L1): no LDS, any map size
+    } else if (VARIANT == 3) {
         stage_bitmap(lds_words, t.packed_blocks, t.packed_bytes >> 2);
     } else {
         if (VARIANT != 0) {
@@ -674,7 +676,8 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 3   ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
+        float rng = VARIANT == 4   ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
+                    : VARIANT == 3 ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
                     : VARIANT == 2 ? cast_ray_fast(lds_words, lds_blk, t, gx, gy, dx, dy)
                     : VARIANT == 1 ? cast_ray_skip(lds_words, lds_blk, t, gx, gy, dx, dy)
                                    : cast_ray_dda(lds_words, t, gx, gy, dx, dy);
@@ -913,6 +916,10 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<2, 3>))
     SET((rc_raycast_kernel<3, 3>))
     SET((rc_raycast_kernel<4, 3>))
+    SET((rc_raycast_kernel<1, 4>))
+    SET((rc_raycast_kernel<2, 4>))
+    SET((rc_raycast_kernel<3, 4>))
+    SET((rc_raycast_kernel<4, 4>))
     SET(rc_patch_kernel)
 #undef SET
     return hipSuccess;
@@ -940,7 +947,9 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
-    if (li.raycast_variant == 3) {
+    if (li.raycast_variant == 4) {
+        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 4><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
+    } else if (li.raycast_variant == 3) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 3><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_packed, s>>>(p, total));
     } else if (li.raycast_variant == 2) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 2><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
