@@ -165,7 +165,7 @@ void set_launch_geometry(rc_env *env) {
     };
     const long long rays = (long long)env->n_cars * RC_N_BEAMS;
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
-    li.ray_blocks = blocks_for(li.raycast_variant == 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
+    li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
 }
 
@@ -448,10 +448,16 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
                 }
             packed[(size_t)by * pk_w + bx] = ((uint32_t)m << 16) | occ16;
         }
+    // per-cell table for variant 5
+    const int cell_pitch = (w + 3) & ~3;
+    const size_t cell_bytes = align_up((size_t)cell_pitch * h, 64);
+    std::vector<uint8_t> cells(cell_bytes, 0);
+    for (int iy = 0; iy < h; ++iy)
+        for (int ix = 0; ix < w; ++ix) cells[(size_t)iy * cell_pitch + ix] = (uint8_t)std::min<int32_t>(dist[(size_t)iy * w + ix], 255);
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
     const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
-    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes;
+    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
     if (env->track_mem) { HIP_TRY(hipFree(env->track_mem)); env->track_mem = nullptr; }
     HIP_TRY(hipMalloc(&env->track_mem, total));
@@ -468,6 +474,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(hipMemcpy(m, packed.data(), packed_bytes, hipMemcpyHostToDevice)); t.packed_blocks = (const uint32_t *)m; m += packed_bytes;
     t.packed_bytes = (int32_t)packed_bytes;
     t.packed_w = pk_w;
+    HIP_TRY(hipMemcpy(m, cells.data(), cell_bytes, hipMemcpyHostToDevice)); t.cell_dist = (const uint8_t *)m; m += cell_bytes;
+    t.cell_pitch = cell_pitch;
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
@@ -477,10 +485,10 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.lds_bytes = bm_bytes;
     li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
     li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
-    // default: the packed table in LDS when two workgroups per CU fit (<= 80 KiB), else the same kernel reading
-    // the table through L1/L2 (measured: austria 0.97 ms LDS vs 1.09 ms global; barcelona 1.29 ms global vs
-    // 1.75 ms for the LDS bitmap + u8 table at one workgroup per CU; gbr 1.24 vs 2.4 ms)
-    li.raycast_variant = (li.lds_bytes_packed && li.lds_bytes_packed <= 80 * 1024) ? 3 : 4;
+    // default: per-cell certificates read through L1/L2 (variant 5).  Measured at 65 536 cars: austria 0.80 ms
+    // against 0.97 ms for the packed 4x4 table in LDS (variant 3) and 1.09 ms for the same table in global
+    // memory (variant 4); barcelona 0.93 ms against 1.29 (v4) / 1.75 ms (v2); columbia 0.78 ms against 1.08 (v3).
+    li.raycast_variant = 5;
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
@@ -624,7 +632,7 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (variant < 0 || variant > 4) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (variant < 0 || variant > 5) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
     if (variant == 3 && env->launch.lds_bytes_packed == 0)
         return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");

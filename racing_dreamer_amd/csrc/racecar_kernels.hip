@@ -645,14 +645,70 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
     return select64(!(tt < tmax) || ring || alive, RCS_MAX_RANGE, tt * t.res);
 }
 
+// Variant 5: per-CELL certificates.  A byte per cell holds the chessboard distance D to the nearest stop
+// cell (0 = stop cell); the square of half-width D - 1 around the current cell is free.  No block arithmetic,
+// no blend between "rectangle" and "cell", no bit extraction (hit <=> D == 0): ~30 VALU per trip and ~12 %
+// fewer trips than 4x4 blocks.  The table (1 B per cell: 0.25-1 MB) lives in global memory and is served by
+// L1/L2; the kernel uses no LDS.
+__device__ __forceinline__ float cast_ray_cells(const uint8_t *cd, const RcTrackDev &t, float gx, float gy,
+                                                float dx, float dy) {
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    const int cpitch = t.cell_pitch;
+    int D = 0;
+    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) D = cd[__mul24(iy, cpitch) + ix];
+    const bool started = D != 0;                                          // false: the sensor sits in a stop cell
+    const float idx = select64(dx != 0.0f, 1.0f / dx, 3.0e38f);
+    const float idy = select64(dy != 0.0f, 1.0f / dy, 3.0e38f);
+    const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;      // 1: the boundary ahead is the upper one
+    int nx = pxi - 1, ny = pyi - 1;                                       // -1 for a negative direction
+    asm("" : "+v"(nx));                                                   // see cast_ray_packed
+    asm("" : "+v"(ny));
+    const int cx = pxi - nx, cy = pyi - ny;                               // xe = ix + cx + ((D - 1) ^ nx)
+    const float tmax = t.tmax;
+    float tt = 0.0f;
+    int guard = 0;
+    while (D != 0) {
+        const int r = D - 1;
+        const int xe = ix + cx + (r ^ nx);                                // boundary that leaves the free square
+        const int ye = iy + cy + (r ^ ny);
+        const float txe = ((float)xe - gx) * idx;
+        const float tye = ((float)ye - gy) * idy;
+        const int mx = sign_mask(txe - tye);                              // -1: leaves through the x side
+        tt = fminf(txe, tye);
+        const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
+        const float pe = og + tt * od;
+        const float fl = floorf(pe);
+        int on = (int)fl;
+        if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
+            const float oid = bfi(mx, idy, idx);
+            const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
+            const float osf = (float)os;
+            const float tc = tt + 0.0f;                                   // canonical +0
+            const int m0 = max(__mul24(on - oi, os) - 1, 0);
+            const float b0 = (float)(oi + opi + __mul24(m0, os));
+            const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
+            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
+            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
+            on = oi + __mul24(m0 + c0 + c1, os);
+        }
+        ix = bfi(mx, xe + nx, on);
+        iy = bfi(mx, on, ye + ny);
+        if (++guard > 4096) break;                                        // bounds a logic error only
+        D = cd[__mul24(iy, cpitch) + ix];
+    }
+    if (!started) return 0.0f;
+    const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
+    return select64(!(tt < tmax) || ring || D != 0, RCS_MAX_RANGE, tt * t.res);
+}
+
 template <int A, int VARIANT>
 __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_rays) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
     const int nwords = t.h * t.pitch;
     const uint8_t *lds_blk = reinterpret_cast<const uint8_t *>(lds_words + ((nwords + 15) & ~15));
-    if (VARIANT == 4) {
-        // packed table read from global memory (L2 / L1): no LDS, any map size
+    if (VARIANT >= 4) {
+        // tables read from global memory (L2 / L1): no LDS, any map size
     } else if (VARIANT == 3) {
         stage_bitmap(lds_words, t.packed_blocks, t.packed_bytes >> 2);
     } else {
@@ -676,7 +732,8 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 4   ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
+        float rng = VARIANT == 5   ? cast_ray_cells(t.cell_dist, t, gx, gy, dx, dy)
+                    : VARIANT == 4 ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
                     : VARIANT == 3 ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
                     : VARIANT == 2 ? cast_ray_fast(lds_words, lds_blk, t, gx, gy, dx, dy)
                     : VARIANT == 1 ? cast_ray_skip(lds_words, lds_blk, t, gx, gy, dx, dy)
@@ -920,6 +977,10 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<2, 4>))
     SET((rc_raycast_kernel<3, 4>))
     SET((rc_raycast_kernel<4, 4>))
+    SET((rc_raycast_kernel<1, 5>))
+    SET((rc_raycast_kernel<2, 5>))
+    SET((rc_raycast_kernel<3, 5>))
+    SET((rc_raycast_kernel<4, 5>))
     SET(rc_patch_kernel)
 #undef SET
     return hipSuccess;
@@ -947,7 +1008,9 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
-    if (li.raycast_variant == 4) {
+    if (li.raycast_variant == 5) {
+        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 5><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
+    } else if (li.raycast_variant == 4) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 4><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
     } else if (li.raycast_variant == 3) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 3><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_packed, s>>>(p, total));

@@ -51,7 +51,7 @@ def test_large_map_falls_back_to_coarser_tables():
     env.reset()                            # bitmap + an 8x8 block table (145 KB) can
     with pytest.raises(L.RacecarHipError, match="too large"):
         env.set_raycast_variant(3)
-    for v in (0, 1, 2, 4):
+    for v in (0, 1, 2, 4, 5):
         env.set_raycast_variant(v)
         env.step(None)
     env.close()
