@@ -454,10 +454,50 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     std::vector<uint8_t> cells(cell_bytes, 0);
     for (int iy = 0; iy < h; ++iy)
         for (int ix = 0; ix < w; ++ix) cells[(size_t)iy * cell_pitch + ix] = (uint8_t)std::min<int32_t>(dist[(size_t)iy * w + ix], 255);
+    // per-cell, per-quadrant free rectangles for variant 6.  A ray in cell (ix, iy) heading into quadrant
+    // (sx, sy) only ever visits cells with (x - ix) * sx >= 0 and (y - iy) * sy >= 0, so the certificate can be a
+    // rectangle with the current cell at its corner: it reaches as far as the walls AHEAD allow, where the
+    // symmetric square of variant 5 is limited by the nearest wall in any direction (a wall-grazing ray crawls).
+    // Among the free rectangles (width = min over its rows of the free run towards sx) the one with the largest
+    // expected exit distance for rays at 22.5 and 67.5 degrees inside the quadrant is kept.  The choice only
+    // affects speed: any free rectangle gives the same result (see cast_ray_skip).
+    const size_t quad_plane_bytes = align_up((size_t)cell_pitch * h * 2, 64);
+    std::vector<uint16_t> quads(quad_plane_bytes / 2 * 4, 0);
+    {
+        std::vector<uint8_t> run((size_t)h * w);
+        const float a1 = 1.0f / 0.92387953f, b1 = 1.0f / 0.38268343f, a2 = b1, b2 = a1;
+        for (int q = 0; q < 4; ++q) {
+            const int sx = (q & 1) ? 1 : -1, sy = (q & 2) ? 1 : -1;
+            for (int iy = 0; iy < h; ++iy) {                      // free run length towards sx, capped at 255
+                int r = 0;
+                for (int k = 0; k < w; ++k) {
+                    const int ix = sx > 0 ? w - 1 - k : k;
+                    r = dist[(size_t)iy * w + ix] ? std::min(r + 1, 255) : 0;
+                    run[(size_t)iy * w + ix] = (uint8_t)r;
+                }
+            }
+            uint16_t *plane = quads.data() + (size_t)q * (quad_plane_bytes / 2);
+            for (int iy = 0; iy < h; ++iy)
+                for (int ix = 0; ix < w; ++ix) {
+                    if (!dist[(size_t)iy * w + ix]) continue;
+                    int cur = 255, bw = 1, bh = 1;
+                    float best = -1.0f;
+                    for (int n = 1; n <= 255; ++n) {
+                        const int y = iy + (n - 1) * sy;
+                        if (y < 0 || y >= h) break;
+                        cur = std::min<int>(cur, run[(size_t)y * w + ix]);
+                        if (cur == 0 || (float)cur * (a1 + a2) <= best) break;
+                        const float sc = std::min((float)cur * a1, (float)n * b1) + std::min((float)cur * a2, (float)n * b2);
+                        if (sc > best) { best = sc; bw = cur; bh = n; }
+                    }
+                    plane[(size_t)iy * cell_pitch + ix] = (uint16_t)(bw | (bh << 8));
+                }
+        }
+    }
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
     const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
-    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes;
+    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes + 4 * quad_plane_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
     if (env->track_mem) { HIP_TRY(hipFree(env->track_mem)); env->track_mem = nullptr; }
     HIP_TRY(hipMalloc(&env->track_mem, total));
@@ -476,6 +516,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.packed_w = pk_w;
     HIP_TRY(hipMemcpy(m, cells.data(), cell_bytes, hipMemcpyHostToDevice)); t.cell_dist = (const uint8_t *)m; m += cell_bytes;
     t.cell_pitch = cell_pitch;
+    HIP_TRY(hipMemcpy(m, quads.data(), 4 * quad_plane_bytes, hipMemcpyHostToDevice)); t.quad_rect = (const uint16_t *)m; m += 4 * quad_plane_bytes;
+    t.quad_plane_bytes = (int32_t)quad_plane_bytes;
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
@@ -485,10 +527,10 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.lds_bytes = bm_bytes;
     li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
     li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
-    // default: per-cell certificates read through L1/L2 (variant 5).  Measured at 65 536 cars: austria 0.80 ms
-    // against 0.97 ms for the packed 4x4 table in LDS (variant 3) and 1.09 ms for the same table in global
-    // memory (variant 4); barcelona 0.93 ms against 1.29 (v4) / 1.75 ms (v2); columbia 0.78 ms against 1.08 (v3).
-    li.raycast_variant = 5;
+    // default: per-cell, per-quadrant free rectangles read through L1/L2 (variant 6).  Measured at 65 536 cars:
+    // austria 0.44 ms against 0.79 ms for the symmetric per-cell squares (variant 5), 0.97 ms for the packed 4x4
+    // table in LDS (variant 3); barcelona 0.46 against 0.92 (v5); gbr 0.51 against 0.86; columbia 0.52 against 0.78.
+    li.raycast_variant = 6;
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
@@ -632,7 +674,7 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (variant < 0 || variant > 5) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (variant < 0 || variant > 6) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
     if (variant == 3 && env->launch.lds_bytes_packed == 0)
         return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");

@@ -15,6 +15,10 @@ struct RcTrackDev {
                                  // Chebyshev distance to the nearest occupied/ring cell (0 = block not free)
     const uint8_t *cell_dist;    // [h][cell_pitch]: per cell, chessboard distance to the nearest stop cell (0 = stop, capped 255)
     int32_t cell_pitch;
+    const uint16_t *quad_rect;   // [4][h][cell_pitch]: per direction quadrant q = (dy >= 0) * 2 + (dx >= 0) and cell, a free
+                                 // rectangle with that cell at its corner, extending towards the quadrant:
+                                 // width | height << 8 in cells (1..255 each), 0 = stop cell
+    int32_t quad_plane_bytes;    // bytes per quadrant plane
     const uint32_t *packed_blocks; // [blk_h][blk_w] for 4x4 blocks: bits 0-15 occupancy of the block's cells
                                  // (bit (iy&3)*4 + (ix&3), sentinel ring included), bits 16-23 the value above
     int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes, packed_w;   // packed_w: uint32 per packed row
@@ -61,7 +65,8 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
     size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8
     int32_t raycast_variant;     // 0 plain, 1 skipping, 2 skipping tuned, 3 tuned + packed table in LDS,
-                                 // 4 packed table read from global memory, 5 per-cell distance table from global memory (identical results)
+                                 // 4 packed table read from global memory, 5 per-cell distance table from global memory,
+                                 // 6 per-cell, per-quadrant free rectangles from global memory (identical results)
 };
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
