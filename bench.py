@@ -101,6 +101,10 @@ def main():
     gather_src = {"none": None, "full": env.slab, "summary": env.summary_slab}[gather_mode]
     gather = TrajectoryGather(gather_src) if gather_src is not None else None
 
+    # the rollout loop works on the env's own stream (no cross-stream event waits between the step's kernels and
+    # the staging copy of the gather); `barrier()` synchronises the whole device
+    torch.cuda.set_stream(env.stream)
+
     def one_step(k, repeat=None):
         env.fill_random_actions(seed=1, step=k)
         env.step(None, repeat=repeat)

@@ -152,11 +152,17 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_sync(self._h))
 
     def _enter(self) -> None:
-        # order the env's stream after whatever produced the actions on torch's current stream
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        # order the env's stream after whatever produced the actions on torch's current stream; nothing to do
+        # when the caller already works on the env's stream (`with torch.cuda.stream(env.stream): ...`), which
+        # saves two cross-stream event waits per call (a few microseconds each on the device queue)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
 
     def _exit(self) -> None:
-        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        cur = torch.cuda.current_stream(self.device)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
 
     # ------------------------------------------------------------------ env API
     def reset(self, mask: Optional[Union[np.ndarray, torch.Tensor]] = None, mode: str = "grid",
