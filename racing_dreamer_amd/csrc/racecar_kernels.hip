@@ -706,6 +706,27 @@ __device__ __forceinline__ float cast_ray_cells(const uint8_t *cd, const RcTrack
 // plane per quadrant, chosen once per ray): it reaches as far as the walls ahead allow, where variant 5's
 // symmetric square is limited by the nearest wall in any direction.  Half the trips of variant 5
 // (tools/skip_stats9.py: 4.1 instead of 8.9 for the slowest ray of a wave on austria); same exit arithmetic.
+__device__ __forceinline__ int floor_to_int(float a) {         // (int)floorf(a) in one instruction
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
+__device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) {   // a * b + c on 24-bit operands
+    unsigned r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+template <int BYTE>
+__device__ __forceinline__ int byte_xor(unsigned word, int m) {              // ((word >> 8 BYTE) & 255) ^ m
+    int r;
+    if (BYTE == 0)
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(word), "v"(m));
+    else
+        asm("v_xor_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(word), "v"(m));
+    return r;
+}
+
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
                                                 float dx, float dy) {
     int ix = (int)floorf(gx), iy = (int)floorf(gy);
@@ -715,7 +736,7 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     const unsigned qoff = (unsigned)__mul24(pyi * 2 + pxi, t.quad_plane_bytes);
     unsigned v = 0;
     if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
-        v = *reinterpret_cast<const uint16_t *>(qb + ((unsigned)__mul24(iy, pitch2) + ((unsigned)ix << 1) + qoff));
+        v = *reinterpret_cast<const uint16_t *>(qb + (__umul24(iy, pitch2) + (((unsigned)ix << 1) + qoff)));
     const bool started = v != 0;                                          // false: the sensor sits in a stop cell
     const float idx = select64(dx != 0.0f, 1.0f / dx, 3.0e38f);
     const float idy = select64(dy != 0.0f, 1.0f / dy, 3.0e38f);
@@ -726,19 +747,19 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     const int cx = pxi - (2 * pxi - 1) - nx, cy = pyi - (2 * pyi - 1) - ny;
     const float tmax = t.tmax;
     float tt = 0.0f;
-    int guard = 0;
-    while (v != 0) {
-        const int xe = ix + cx + ((int)(v & 255u) ^ nx);
-        const int ye = iy + cy + ((int)(v >> 8) ^ ny);
+    // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
+    // loop ends within w + h trips; the counter only bounds a logic error (the result is then meaningless)
+    for (int guard = 4096; v != 0 && guard != 0; --guard) {
+        const int xe = ix + cx + byte_xor<0>(v, nx);
+        const int ye = iy + cy + byte_xor<1>(v, ny);
         const float txe = ((float)xe - gx) * idx;
         const float tye = ((float)ye - gy) * idy;
         const int mx = sign_mask(txe - tye);                              // -1: leaves through the x side
         tt = fminf(txe, tye);
         const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
         const float pe = og + tt * od;
-        const float fl = floorf(pe);
-        int on = (int)fl;
-        if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
+        int on = floor_to_int(pe);
+        if (fabsf(__builtin_amdgcn_fractf(pe) - 0.5f) > 0.499f) {         // within 1e-3 of a boundary: exact count
             const float oid = bfi(mx, idy, idx);
             const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
             const float osf = (float)os;
@@ -752,12 +773,11 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
         }
         ix = bfi(mx, xe + nx, on);
         iy = bfi(mx, on, ye + ny);
-        if (++guard > 4096) break;                                        // bounds a logic error only
-        v = *reinterpret_cast<const uint16_t *>(qb + ((unsigned)__mul24(iy, pitch2) + ((unsigned)ix << 1) + qoff));
+        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(iy, pitch2, ((unsigned)ix << 1) + qoff));
     }
     if (!started) return 0.0f;
     const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
-    return select64(!(tt < tmax) || ring || v != 0, RCS_MAX_RANGE, tt * t.res);
+    return select64(!(tt < tmax) || ring, RCS_MAX_RANGE, tt * t.res);
 }
 
 template <int A, int VARIANT>
