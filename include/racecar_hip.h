@@ -190,6 +190,11 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant);
 /* Host-only: the beam (cos, sin) and footprint tables the kernels use (float32 [1080][2], [34][2]). */
 void rc_spec_tables(float *beams_1080x2, float *footprint_34x2);
 
+/* Device self-test of an arithmetic property the raycast kernel relies on: v_rcp_f32 + one FMA Newton step is
+ * the correctly rounded (IEEE) reciprocal.  Checks every fp32 of both signs with biased exponent in
+ * [27, 227] (2^-100 .. 2^100, 3.37e9 values) on `device`; *n_mismatch must come back 0. */
+int rc_selftest_reciprocal(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
+
 const char *rc_last_error(void);
 int rc_abi_version(void);
 

@@ -221,6 +221,22 @@ void make_tables(float *beams, float *foot) {
 
 extern "C" {
 
+int rc_selftest_reciprocal(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch) {
+    if (!n_checked || !n_mismatch) return fail(RC_ERR_INVALID, "NULL output pointer");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *dev = nullptr, host = 0;
+    HIP_TRY(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemset(dev, 0, sizeof(host));
+    const uint32_t exp_lo = 127 - 100, exp_hi = 127 + 100;
+    if (e == hipSuccess) e = rck_launch_selftest_rcp(exp_lo, exp_hi, dev, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(RC_ERR_HIP, "rc_selftest_reciprocal: %s", hipGetErrorString(e));
+    *n_checked = 2ull * ((uint64_t)(exp_hi - exp_lo + 1) << 23);
+    *n_mismatch = host;
+    return RC_OK;
+}
+
 void rc_spec_tables(float *beams_1080x2, float *footprint_34x2) {
     if (beams_1080x2 && footprint_34x2) make_tables(beams_1080x2, footprint_34x2);
 }
