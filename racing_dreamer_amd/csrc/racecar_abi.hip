@@ -399,7 +399,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     if (!(resolution > 0.f)) return fail(RC_ERR_INVALID, "resolution must be > 0");
     HIP_TRY(hipSetDevice(env->cfg.device));
     const size_t nwords = (size_t)h * pitch;
-    const size_t bm_bytes = align_up(nwords * 4, 64);
+    const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_kernel)
     if (bm_bytes > 160 * 1024)
         return fail(RC_ERR_INVALID, "track bitmap %zu B does not fit the 160 KiB LDS", bm_bytes);
     // occupancy with the sentinel ring set

@@ -884,10 +884,35 @@ __device__ __forceinline__ uint32_t select64u(bool cond, uint32_t a, uint32_t b)
     return r;
 }
 
+__device__ __forceinline__ unsigned long long cmp_le_u32(uint32_t a, uint32_t b) {      // lane mask of a <= b
+    unsigned long long m;
+    asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint32_t select_mask(unsigned long long m, uint32_t a, uint32_t b) {   // m ? a : b
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t offset, uint32_t width) {       // offset, width mod 32
+    uint32_t r;
+    asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(offset), "v"(width));
+    return r;
+}
+__device__ __forceinline__ uint32_t lshl_add(uint32_t a, int sh, uint32_t c) { return (a << sh) + c; }
+__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t c) { return (a << sh) | c; }
+__device__ __forceinline__ int mad_i24(int a, int b, int c) {
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+
 __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
-    stage_bitmap(lds_words, t.drv_words, t.h * t.pitch);
+    const int nwords = t.h * t.pitch;
+    stage_bitmap(lds_words, t.drv_words, nwords + 1);        // + the all-zero word behind the bitmap (rc_load_track)
+    const uint32_t zero_addr = (uint32_t)nwords * 4u;        // where rejected taps read
     uint4 *out128 = reinterpret_cast<uint4 *>(p.out.patch);
     const int wm1 = t.w - 1, hm1 = t.h - 1, pitch4 = t.pitch * 4;
     const char *lds_bytes = reinterpret_cast<const char *>(lds_words);
@@ -913,18 +938,19 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
             if (hix < lox) { lox = 0x40000000; hix = lox; }                // empty range: nothing passes
             if (hiy < loy) { loy = 0x40000000; hiy = loy; }
             const unsigned spanx = (unsigned)(hix - lox), spany = (unsigned)(hiy - loy);
+            const int rowbase = icy * pitch4;                              // only used by accepted taps
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const float ox = u * ct - vst;
                 const float oy = u * st + vct;
-                const int fx = (int)floorf(ox), fy = (int)floorf(oy);
-                const int ix = icx + fx, iy = icy + fy;
-                const bool ok = (unsigned)(fx - lox) <= spanx && (unsigned)(fy - loy) <= spany;
-                const uint32_t m = select64u(ok, 0xffffffffu, 0u);       // cell (0, 0) stands in for rejected taps
-                const int ixc = ix & (int)m, iyc = iy & (int)m;
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(lds_bytes + __mul24(iyc, pitch4) + ((ixc >> 3) & ~3));
-                const uint32_t bit = (w >> (ixc & 31)) & m & 1u;
-                words[k >> 2] |= bit << (8 * (k & 3));
+                const int fx = floor_to_int(ox), fy = floor_to_int(oy);
+                // both range tests into SGPR pairs, ANDed on the scalar unit, one e64 select (no i1 round trip
+                // through a VGPR, no VCC-reading e32 select)
+                const unsigned long long ok = cmp_le_u32((unsigned)(fx - lox), spanx) & cmp_le_u32((unsigned)(fy - loy), spany);
+                const int ix = icx + fx;
+                const uint32_t addr = lshl_add(bfe_u32((uint32_t)ix, 5, 16), 2, (uint32_t)mad_i24(fy, pitch4, rowbase));
+                const uint32_t w = *reinterpret_cast<const uint32_t *>(lds_bytes + select_mask(ok, addr, zero_addr));
+                words[k >> 2] = lshl_or(bfe_u32(w, (uint32_t)ix, 1), 8 * (k & 3), words[k >> 2]);   // bfe uses ix & 31
                 u += RCS_PATCH_CELLS;
             }
         }
