@@ -397,6 +397,9 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     if (h < 3 || w < 3 || pitch * 32 < w) return fail(RC_ERR_INVALID, "bad track shape h=%d w=%d pitch=%d", h, w, pitch);
     if (n_centerline < 1) return fail(RC_ERR_INVALID, "centerline table is empty");
     if (!(resolution > 0.f)) return fail(RC_ERR_INVALID, "resolution must be > 0");
+    // the skipping traversals place a ray inside a free rectangle with fp32 arithmetic on cell coordinates and
+    // fall back to exact comparisons within 1e-3 cell of a boundary; that margin is sized for coordinates < 4096
+    if (h > 4096 || w > 4096) return fail(RC_ERR_INVALID, "grids larger than 4096 cells per side are not supported (h=%d w=%d)", h, w);
     HIP_TRY(hipSetDevice(env->cfg.device));
     const size_t nwords = (size_t)h * pitch;
     const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_kernel)
@@ -480,25 +483,30 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     const size_t quad_plane_bytes = align_up((size_t)cell_pitch * h * 2, 64);
     std::vector<uint16_t> quads(quad_plane_bytes / 2 * 4, 0);
     {
+        // entry: byte 0 = +width (ray heading +x) or -width (-x) as int8, byte 1 the same for the height;
+        // wall = 0x0000, sentinel ring = 0x0100 (byte 0 == 0 stops the ray, entry != 0 then means "no return")
+        const int cap = 127;
         std::vector<uint8_t> run((size_t)h * w);
         const float a1 = 1.0f / 0.92387953f, b1 = 1.0f / 0.38268343f, a2 = b1, b2 = a1;
         for (int q = 0; q < 4; ++q) {
             const int sx = (q & 1) ? 1 : -1, sy = (q & 2) ? 1 : -1;
-            for (int iy = 0; iy < h; ++iy) {                      // free run length towards sx, capped at 255
+            for (int iy = 0; iy < h; ++iy) {                      // free run length towards sx, capped
                 int r = 0;
                 for (int k = 0; k < w; ++k) {
                     const int ix = sx > 0 ? w - 1 - k : k;
-                    r = dist[(size_t)iy * w + ix] ? std::min(r + 1, 255) : 0;
+                    r = dist[(size_t)iy * w + ix] ? std::min(r + 1, cap) : 0;
                     run[(size_t)iy * w + ix] = (uint8_t)r;
                 }
             }
             uint16_t *plane = quads.data() + (size_t)q * (quad_plane_bytes / 2);
             for (int iy = 0; iy < h; ++iy)
                 for (int ix = 0; ix < w; ++ix) {
+                    uint16_t &e = plane[(size_t)iy * cell_pitch + ix];
+                    if (ix == 0 || iy == 0 || ix == w - 1 || iy == h - 1) { e = 0x0100; continue; }
                     if (!dist[(size_t)iy * w + ix]) continue;
-                    int cur = 255, bw = 1, bh = 1;
+                    int cur = cap, bw = 1, bh = 1;
                     float best = -1.0f;
-                    for (int n = 1; n <= 255; ++n) {
+                    for (int n = 1; n <= cap; ++n) {
                         const int y = iy + (n - 1) * sy;
                         if (y < 0 || y >= h) break;
                         cur = std::min<int>(cur, run[(size_t)y * w + ix]);
@@ -506,7 +514,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
                         const float sc = std::min((float)cur * a1, (float)n * b1) + std::min((float)cur * a2, (float)n * b2);
                         if (sc > best) { best = sc; bw = cur; bh = n; }
                     }
-                    plane[(size_t)iy * cell_pitch + ix] = (uint16_t)(bw | (bh << 8));
+                    e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
                 }
         }
     }

@@ -763,9 +763,50 @@ __global__ __launch_bounds__(256) void rc_selftest_rcp_kernel(uint32_t exp_lo, u
     if (bad) atomicAdd(mismatches, bad);
 }
 
+__device__ __forceinline__ unsigned long long cmp_nlt_f32(float a, float b) {          // lane mask of !(a < b)
+    unsigned long long m;
+    asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ unsigned long long cmp_ne_u32(uint32_t a, uint32_t b) {      // lane mask of a != b
+    unsigned long long m;
+    asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float select_mask(unsigned long long m, float a, float b) {  // m ? a : b
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+template <int BYTE>
+__device__ __forceinline__ int add_sbyte(unsigned word, int a) {             // a + (int8)(word >> 8 BYTE)
+    int r;
+    if (BYTE == 0)
+        asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(word), "v"(a));
+    else
+        asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(word), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float max_with(float a, float lo) {               // IEEE maxNum: a NaN becomes `lo`
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(lo));
+    return r;
+}
+
+// Table entry (uint16 per quadrant plane and cell): byte 0 = signed x offset from the SHIFTED cell index to the
+// boundary that leaves the rectangle (+width for a ray heading +x, -width for -x), byte 1 the same for y; a wall
+// is 0x0000 and a cell of the sentinel ring 0x0100, so "stop" <=> byte 0 == 0 and "no return" <=> entry != 0
+// at the stop.  Shifted index: j = i for a positive direction, i + 1 for a negative one - then the boundary is
+// j + offset for both signs and the shifted index of the cell behind that boundary is the boundary itself, so a
+// trip needs no sign arithmetic at all.
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
                                                 float dx, float dy) {
-    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    // A NaN direction (non-finite car state) would make the cell arithmetic below meaningless and could walk
+    // the table index anywhere; v_max turns it into a finite number (any legal component is >= -1.0000002, so
+    // legal rays are untouched) and the ray then ends at the ring like every other.
+    dx = max_with(dx, -2.0f);
+    dy = max_with(dy, -2.0f);
+    const int ix = (int)floorf(gx), iy = (int)floorf(gy);
     const int pitch2 = t.cell_pitch * 2;
     const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;      // 1: the boundary ahead is the upper one
     const char *qb = reinterpret_cast<const char *>(qr);
@@ -773,47 +814,52 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     unsigned v = 0;
     if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
         v = *reinterpret_cast<const uint16_t *>(qb + (__umul24(iy, pitch2) + (((unsigned)ix << 1) + qoff)));
-    const bool started = v != 0;                                          // false: the sensor sits in a stop cell
+    const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     float idx, idy;
     ray_reciprocals(dx, dy, idx, idy);
     int nx = pxi - 1, ny = pyi - 1;                                       // -1 for a negative direction
     asm("" : "+v"(nx));                                                   // see cast_ray_packed
     asm("" : "+v"(ny));
-    // boundary leaving a rectangle of n cells: i + p + (n - 1) * s with s = 2p - 1 and n * s = (n ^ neg) - neg
-    const int cx = pxi - (2 * pxi - 1) - nx, cy = pyi - (2 * pyi - 1) - ny;
+    int jx = ix - nx, jy = iy - ny;                                       // shifted cell index
+    // other-axis position in shifted coordinates.  hx differs from gx + 1 by at most one rounding (< 1.3e-4
+    // cell on grids up to 2048 wide), far inside the 1e-3 band in which the exact count below takes over.
+    const float hx = gx - (float)nx, hy = gy - (float)ny;
+    // byte offset of shifted cell (jx, jy) in this ray's plane: true cell = (jx + nx, jy + ny)
+    unsigned qoffp = qoff - (unsigned)(ny & pitch2) + ((unsigned)nx << 1);
+    asm("" : "+v"(qoffp));                                                // one value: keep it out of the loop's address math
     const float tmax = t.tmax;
     float tt = 0.0f;
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
-    // loop ends within w + h trips; the counter only bounds a logic error (the result is then meaningless)
-    for (int guard = 4096; v != 0 && guard != 0; --guard) {
-        const int xe = ix + cx + byte_xor<0>(v, nx);
-        const int ye = iy + cy + byte_xor<1>(v, ny);
+    // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
+    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) {
+        const int xe = add_sbyte<0>(v, jx);                               // boundaries that leave the rectangle
+        const int ye = add_sbyte<1>(v, jy);
         const float txe = ((float)xe - gx) * idx;
         const float tye = ((float)ye - gy) * idy;
         const int mx = sign_mask(txe - tye);                              // -1: leaves through the x side
         tt = fminf(txe, tye);
-        const float og = bfi(mx, gy, gx), od = bfi(mx, dy, dx);
-        const float pe = og + tt * od;
-        int on = floor_to_int(pe);
+        const float pe = bfi(mx, hy, hx) + tt * bfi(mx, dy, dx);
+        int on = floor_to_int(pe);                                        // shifted cell on the other axis
         if (fabsf(__builtin_amdgcn_fractf(pe) - 0.5f) > 0.499f) {         // within 1e-3 of a boundary: exact count
-            const float oid = bfi(mx, idy, idx);
-            const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
+            const int na = bfi(mx, ny, nx), opi = na + 1, os = 2 * opi - 1;
+            const float og = bfi(mx, gy, gx), oid = bfi(mx, idy, idx);
+            const int oi = bfi(mx, jy, jx) + na;                          // true current cell on the other axis
             const float osf = (float)os;
             const float tc = tt + 0.0f;                                   // canonical +0
-            const int m0 = max(__mul24(on - oi, os) - 1, 0);
+            const int m0 = max(__mul24(on + na - oi, os) - 1, 0);
             const float b0 = (float)(oi + opi + __mul24(m0, os));
             const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
             const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
             const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-            on = oi + __mul24(m0 + c0 + c1, os);
+            on = oi + __mul24(m0 + c0 + c1, os) - na;
         }
-        ix = bfi(mx, xe + nx, on);
-        iy = bfi(mx, on, ye + ny);
-        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(iy, pitch2, ((unsigned)ix << 1) + qoff));
+        jx = bfi(mx, xe, on);
+        jy = bfi(mx, on, ye);
+        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, ((unsigned)jx << 1) + qoffp));
     }
     if (!started) return 0.0f;
-    const bool ring = ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1;
-    return select64(!(tt < tmax) || ring, RCS_MAX_RANGE, tt * t.res);
+    // stopped at a wall within range: the range; beyond 15 m, at the ring (entry 0x0100) or never stopped: no return
+    return select_mask(cmp_nlt_f32(tt, tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
 }
 
 template <int A, int VARIANT>
