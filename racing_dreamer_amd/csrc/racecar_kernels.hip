@@ -516,6 +516,23 @@ __device__ __forceinline__ float select64(bool cond, float a, float b) {
     return r;
 }
 
+// The exact other-axis cell after the exit crossing at time tt, for the rare iterations in which the fp32
+// position estimate lies within 1e-3 cell of a boundary.  `on_est` is that estimate (off by at most one cell),
+// oi the current cell, opi 1 / 0 for a positive / negative direction on that axis, og / oid the ray origin and
+// reciprocal direction on it.  The reference traversal crosses the other-axis boundary b before the exit iff
+// t_b < tt, or t_b == tt when the exit is an x crossing (mx = -1: "ties go to y"); boundary times can be -0.0
+// (sensor exactly on a boundary, negative direction), so these are IEEE comparisons, not sign-bit tests.
+__device__ __forceinline__ int exact_other_cell(int on_est, int oi, int opi, float og, float oid, float tt, int mx) {
+    const int os = 2 * opi - 1;
+    const float osf = (float)os;
+    const int m0 = max(__mul24(on_est - oi, os) - 1, 0);
+    const float b0 = (float)(oi + opi + __mul24(m0, os));
+    const float tb0 = (b0 - og) * oid, tb1 = ((b0 + osf) - og) * oid;
+    const int c0 = (tb0 < tt || (mx != 0 && tb0 == tt)) ? 1 : 0;
+    const int c1 = (tb1 < tt || (mx != 0 && tb1 == tt)) ? 1 : 0;
+    return oi + __mul24(m0 + c0 + c1, os);
+}
+
 __device__ __forceinline__ float cast_ray_fast(const uint32_t *bits, const uint8_t *blk, const RcTrackDev &t,
                                                float gx, float gy, float dx, float dy) {
     int ix = (int)floorf(gx), iy = (int)floorf(gy);
@@ -552,16 +569,7 @@ __device__ __forceinline__ float cast_ray_fast(const uint32_t *bits, const uint8
         const float fl = floorf(pe);
         int on = (int)fl;
         if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
-            const float oid = bfi(mx, idy, idx);
-            const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
-            const float osf = (float)os;
-            const float tc = tt + 0.0f;                                   // canonical +0
-            const int m0 = max(__mul24(on - oi, os) - 1, 0);
-            const float b0 = (float)(oi + opi + __mul24(m0, os));
-            const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
-            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
-            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-            on = oi + __mul24(m0 + c0 + c1, os);
+            on = exact_other_cell(on, bfi(mx, iy, ix), bfi(mx, pyi, pxi), og, bfi(mx, idy, idx), tt, mx);
         }
         ix = bfi(mx, xe + nx, on);
         iy = bfi(mx, on, ye + ny);
@@ -621,16 +629,7 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
         const float fl = floorf(pe);
         int on = (int)fl;
         if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
-            const float oid = bfi(mx, idy, idx);
-            const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
-            const float osf = (float)os;
-            const float tc = tt + 0.0f;                                   // canonical +0
-            const int m0 = max(__mul24(on - oi, os) - 1, 0);
-            const float b0 = (float)(oi + opi + __mul24(m0, os));
-            const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
-            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
-            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-            on = oi + __mul24(m0 + c0 + c1, os);
+            on = exact_other_cell(on, bfi(mx, iy, ix), bfi(mx, pyi, pxi), og, bfi(mx, idy, idx), tt, mx);
         }
         ix = bfi(mx, xe + nx, on);
         iy = bfi(mx, on, ye + ny);
@@ -680,16 +679,7 @@ __device__ __forceinline__ float cast_ray_cells(const uint8_t *cd, const RcTrack
         const float fl = floorf(pe);
         int on = (int)fl;
         if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
-            const float oid = bfi(mx, idy, idx);
-            const int oi = bfi(mx, iy, ix), opi = bfi(mx, pyi, pxi), os = 2 * opi - 1;
-            const float osf = (float)os;
-            const float tc = tt + 0.0f;                                   // canonical +0
-            const int m0 = max(__mul24(on - oi, os) - 1, 0);
-            const float b0 = (float)(oi + opi + __mul24(m0, os));
-            const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
-            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
-            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-            on = oi + __mul24(m0 + c0 + c1, os);
+            on = exact_other_cell(on, bfi(mx, iy, ix), bfi(mx, pyi, pxi), og, bfi(mx, idy, idx), tt, mx);
         }
         ix = bfi(mx, xe + nx, on);
         iy = bfi(mx, on, ye + ny);
@@ -841,17 +831,8 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
         const float pe = bfi(mx, hy, hx) + tt * bfi(mx, dy, dx);
         int on = floor_to_int(pe);                                        // shifted cell on the other axis
         if (fabsf(__builtin_amdgcn_fractf(pe) - 0.5f) > 0.499f) {         // within 1e-3 of a boundary: exact count
-            const int na = bfi(mx, ny, nx), opi = na + 1, os = 2 * opi - 1;
-            const float og = bfi(mx, gy, gx), oid = bfi(mx, idy, idx);
-            const int oi = bfi(mx, jy, jx) + na;                          // true current cell on the other axis
-            const float osf = (float)os;
-            const float tc = tt + 0.0f;                                   // canonical +0
-            const int m0 = max(__mul24(on + na - oi, os) - 1, 0);
-            const float b0 = (float)(oi + opi + __mul24(m0, os));
-            const float t2 = __int_as_float(__float_as_int(tc) - mx);     // x exit: y wins ties -> count t <= tt
-            const int c0 = (unsigned)__float_as_int((b0 - og) * oid - t2) >> 31;
-            const int c1 = (unsigned)__float_as_int(((b0 + osf) - og) * oid - t2) >> 31;
-            on = oi + __mul24(m0 + c0 + c1, os) - na;
+            const int na = bfi(mx, ny, nx);                               // true cell = shifted cell + na
+            on = exact_other_cell(on + na, bfi(mx, jy, jx) + na, na + 1, bfi(mx, gy, gx), bfi(mx, idy, idx), tt, mx) - na;
         }
         jx = bfi(mx, xe, on);
         jy = bfi(mx, on, ye);

@@ -151,6 +151,80 @@ def test_raycast_variants_from_arbitrary_poses(track_name):
     env.close()
 
 
+@pytest.mark.parametrize("track_name", ["austria", "barcelona", "columbia"])
+def test_default_raycast_dense_poses(track_name):
+    """Every raycast variant against the oracle from 24 576 poses per track: uniform over the grid, hugging the walls
+    (sensor within a few centimetres of an occupied cell, headings along the wall: the grazing rays that take the
+    exact-count path most often) and on exact cell boundaries."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track(track_name)
+    rng = np.random.default_rng(11)
+    n = 24576
+    x = t.origin[0] + rng.uniform(0.0, t.width * 0.05, n)
+    y = t.origin[1] + rng.uniform(0.0, t.height * 0.05, n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    # a third: free cells adjacent to an occupied cell, axis-parallel / slightly tilted headings
+    free = ~t.occ
+    near = free & (np.roll(t.occ, 1, 0) | np.roll(t.occ, -1, 0) | np.roll(t.occ, 1, 1) | np.roll(t.occ, -1, 1))
+    near[0, :] = near[-1, :] = near[:, 0] = near[:, -1] = False
+    cy, cx = np.nonzero(near)
+    k = n // 3
+    pick = rng.integers(0, len(cx), k)
+    head = rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2], k) + rng.choice([0.0, 1e-3, -1e-3, 0.02, -0.02], k)
+    s32, c32 = ro.sincos32(head.astype(np.float32))
+    fx = rng.choice([0.0, 0.5, 0.999, rng.uniform()], k)
+    fy = rng.choice([0.0, 0.5, 0.999, rng.uniform()], k)
+    x[:k] = t.origin[0] + (cx[pick] + fx) * 0.05 - 0.25 * c32
+    y[:k] = t.origin[1] + (cy[pick] + fy) * 0.05 - 0.25 * s32
+    th[:k] = head
+    poses = np.stack([x, y, th], 1).astype(np.float32)
+    want = _oracle_scan(t, poses)
+    env = BatchedRaceEnv(t, n, 1)
+    env.reset()
+    for variant in {"barcelona": [6, 0, 1, 2, 4, 5]}.get(track_name, [6, 0, 1, 2, 3, 4, 5]):
+        env.set_raycast_variant(variant)
+        got = env.set_pose(poses)["lidar"]
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().reshape(n, 1080)
+        bad = np.nonzero((got != want) | (np.signbit(got) != np.signbit(want)))     # -0.0 (zero-length first step) included
+        assert bad[0].size == 0, (track_name, variant, bad[0][:5], bad[1][:5], got[bad][:5], want[bad][:5])
+    env.close()
+
+
+def test_non_finite_poses_do_not_disturb_the_batch():
+    """NaN / inf car states (a diverged policy, a bad teleport) must neither hang the scan nor touch other cars:
+    the kernels terminate, finite cars keep their oracle ranges, and the next step still runs."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track("columbia")
+    n = 256
+    rng = np.random.default_rng(3)
+    cl = t.centerline[rng.integers(0, len(t.centerline), n)]
+    poses = np.stack([cl[:, 0], cl[:, 1], rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+    want = _oracle_scan(t, poses)
+    bad_rows = np.arange(0, n, 8)
+    evil = poses.copy()
+    evil[bad_rows[0::4], 2] = np.nan
+    evil[bad_rows[1::4], 0] = np.inf
+    evil[bad_rows[2::4], 1] = -np.inf
+    evil[bad_rows[3::4], :] = np.nan
+    for obs_type in ("lidar", "lidar_occupancy"):
+        env = BatchedRaceEnv(t, n, 1, obs_type=obs_type, auto_reset=True)
+        env.reset()
+        got = env.set_pose(evil)["lidar"]
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().reshape(n, 1080)
+        keep = np.setdiff1d(np.arange(n), bad_rows)
+        assert np.array_equal(got[keep], want[keep])
+        out = env.step(torch.zeros(n, 1, 2, device="cuda"))
+        torch.cuda.synchronize()
+        assert np.isfinite(out["lidar"].cpu().numpy().reshape(n, 1080)[keep]).all()
+        env.close()
+
+
 def test_raycast_variants_two_cars():
     import torch
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
