@@ -193,6 +193,45 @@ def test_default_raycast_dense_poses(track_name):
     env.close()
 
 
+@pytest.mark.parametrize("track_name", ["austria", "columbia", "gbr"])
+def test_occupancy_patch_dense_poses(track_name):
+    """The 64x64 lidar_occupancy render against the oracle from 4 096 arbitrary poses: anywhere on the grid and
+    half a metre beyond it (crop window and grid clipping), exactly on cell corners, axis-aligned and diagonal
+    headings (pixel taps that fall exactly on cell boundaries)."""
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track(track_name)
+    rng = np.random.default_rng(17)
+    n = 4096
+    x = t.origin[0] + rng.uniform(-0.5, t.width * 0.05 + 0.5, n)
+    y = t.origin[1] + rng.uniform(-0.5, t.height * 0.05 + 0.5, n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    k = n // 2
+    x[:k] = t.origin[0] + rng.integers(0, t.width, k) * 0.05
+    y[:k] = t.origin[1] + rng.integers(0, t.height, k) * 0.05
+    th[:k] = rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2, np.pi / 4, -np.pi / 4, 3 * np.pi / 4], k)
+    poses = np.stack([x, y, th], 1).astype(np.float32)
+    cfg = ro.OracleConfig(num_envs=n, cars_per_env=1, render_occupancy=True)
+    ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=8)
+    ora.reset()
+    ora.arr["x"][:], ora.arr["y"][:], ora.arr["theta"][:] = poses[:, 0], poses[:, 1], poses[:, 2]
+    ora.arr["st"][:], ora.arr["ct"][:] = ro.sincos32(poses[:, 2])
+    ora.arr["fresh"][:] = 0
+    ora._observe()
+    want = ora.patch.reshape(n, 64, 64)
+    env = BatchedRaceEnv(t, n, 1, obs_type="lidar_occupancy")
+    env.reset()
+    got = env.set_pose(poses)["lidar_occupancy"]
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().reshape(n, 64, 64)
+    bad = np.nonzero((got != want).reshape(n, -1).any(1))[0]
+    assert bad.size == 0, (track_name, bad[:5], poses[bad[:5]])
+    assert want.any() and not want.all()
+    env.close()
+
+
 def test_non_finite_poses_do_not_disturb_the_batch():
     """NaN / inf car states (a diverged policy, a bad teleport) must neither hang the scan nor touch other cars:
     the kernels terminate, finite cars keep their oracle ranges, and the next step still runs."""
