@@ -183,8 +183,8 @@ int rc_set_profiling(rc_env *env, int32_t enabled);
 int rc_kernel_time(rc_env *env, int32_t kernel, double *total_ms, uint64_t *launches);
 int rc_reset_kernel_times(rc_env *env);
 
-/* Raycast implementation selector, 0..6 (all variants return identical results; 6, the default, is the
- * fastest: per-cell, per-quadrant free rectangles; 0 is the cell-by-cell reference traversal). */
+/* Raycast implementation selector, 0..7 (all variants return identical results; 7, the default, is the
+ * fastest: per-cell, per-quadrant free rectangles, one wave per car; 0 is the cell-by-cell reference traversal). */
 int rc_set_raycast_variant(rc_env *env, int32_t variant);
 
 /* Host-only: the beam (cos, sin) and footprint tables the kernels use (float32 [1080][2], [34][2]). */

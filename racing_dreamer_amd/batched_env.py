@@ -208,7 +208,8 @@ class BatchedRaceEnv:
     def set_raycast_variant(self, variant: int) -> None:
         """0 = plain traversal, 1 = free-rectangle skipping, 2 = tuned skipping, 3 = tuned + packed block table
         in LDS, 4 = the same reading the table through L1/L2, 5 = per-cell distance table through L1/L2,
-        6 = per-cell, per-quadrant free rectangles through L1/L2 (default).  All variants return identical results."""
+        6 = per-cell, per-quadrant free rectangles through L1/L2,
+        7 = the same with one wave per car (default).  All variants return identical results."""
         L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
 
     def follow_the_gap(self, motor_straight: float = 0.6, motor_corner: float = 0.3) -> torch.Tensor:

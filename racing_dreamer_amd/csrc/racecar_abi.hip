@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -167,6 +168,23 @@ void set_launch_geometry(rc_env *env) {
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
     li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
+    // tuning knobs for experiments (not part of the interface): workgroup size / workgroups per CU of the LDS-free scan
+    if (li.raycast_variant == 7) {
+        const char *e = getenv("RC_RAY_THREADS");
+        const int threads = e ? atoi(e) : 0;
+        li.car_threads = (threads == 64 || threads == 128 || threads == 256) ? threads : 64;
+    } else if (li.raycast_variant >= 4) {
+        const char *e = getenv("RC_RAY_THREADS");
+        int threads = e ? atoi(e) : 0;
+        if (threads >= 64 && threads <= 1024 && threads % 64 == 0) li.ray_threads = threads;
+        e = getenv("RC_RAY_WG_PER_CU");
+        const int per_cu = e ? atoi(e) : 0;
+        if (threads || per_cu) {
+            const long long chunks = (rays + li.ray_threads - 1) / li.ray_threads;
+            const long long resident = (long long)li.n_cu * (per_cu > 0 ? per_cu : 2048 / li.ray_threads);
+            li.ray_blocks = (int)std::min<long long>(chunks, per_cu < 0 ? chunks : resident);
+        }
+    }
 }
 
 int observe(rc_env *env) {
@@ -551,10 +569,12 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.lds_bytes = bm_bytes;
     li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
     li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
-    // default: per-cell, per-quadrant free rectangles read through L1/L2 (variant 6).  Measured at 65 536 cars:
-    // austria 0.44 ms against 0.79 ms for the symmetric per-cell squares (variant 5), 0.97 ms for the packed 4x4
-    // table in LDS (variant 3); barcelona 0.46 against 0.92 (v5); gbr 0.51 against 0.86; columbia 0.52 against 0.78.
-    li.raycast_variant = 6;
+    // default: per-cell, per-quadrant free rectangles read through L1/L2, one wave per car (variant 7).  Measured
+    // at 65 536 cars on austria: 0.285 ms against 0.37 ms for the same traversal on persistent 1024-ray chunks
+    // (variant 6), 0.79 ms for symmetric per-cell squares (variant 5), 0.97 ms for the packed 4x4 table in LDS
+    // (variant 3); columbia 0.33 (v6 0.44), barcelona 0.34 (0.39), gbr 0.35 (0.43).
+    li.raycast_variant = 7;
+    li.car_threads = 64;
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
@@ -698,7 +718,7 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (variant < 0 || variant > 6) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
+    if (variant < 0 || variant > 7) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
     if (variant == 3 && env->launch.lds_bytes_packed == 0)
         return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");

@@ -60,13 +60,15 @@ struct RcParams {
 struct RcLaunchInfo {            // per-handle launch geometry decided at rc_load_track
     int32_t n_cu;
     int32_t ray_blocks, ray_threads;
+    int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one car per workgroup
     int32_t patch_blocks, patch_threads;
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
     size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8
     int32_t raycast_variant;     // 0 plain, 1 skipping, 2 skipping tuned, 3 tuned + packed table in LDS,
                                  // 4 packed table read from global memory, 5 per-cell distance table from global memory,
-                                 // 6 per-cell, per-quadrant free rectangles from global memory (identical results)
+                                 // 6 per-cell, per-quadrant free rectangles from global memory, 7 the same with one wave per car
+                                 // (identical results)
 };
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`

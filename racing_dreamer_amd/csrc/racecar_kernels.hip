@@ -898,6 +898,46 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
     }
 }
 
+// Variant 7: the traversal of variant 6 with ONE WAVE PER CAR.  The car index is wave-uniform, so the car state
+// comes through scalar loads, everything that depends only on the car (sensor position, start cell, its range
+// test) is computed once instead of once per 64 beams, and the wave walks its car's 1080 beams in 17 rounds of
+// 64 (the last with 56 active lanes) - consecutive rounds start from the same cell, so their table lines are
+// still in L1.  No persistent loop: 65 536 independent waves are balanced by the hardware dispatcher, where
+// equal shares of chunks per resident workgroup left the slowest workgroup's tail exposed.
+template <int A>
+__global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p) {
+    const RcTrackDev &t = p.trk;
+    const unsigned car = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (car >= (unsigned)p.n_cars) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const float ct = p.st.ct[car], st = p.st.st[car];
+    const float lx = p.st.x[car] + RCS_LIDAR_X * ct;
+    const float ly = p.st.y[car] + RCS_LIDAR_X * st;
+    const float gx = (lx - t.org_x) * t.inv_res;
+    const float gy = (ly - t.org_y) * t.inv_res;
+    float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
+    for (unsigned beam = lane; beam < RC_N_BEAMS; beam += 64u) {
+        const float cb = t.beams[2 * beam], sb = t.beams[2 * beam + 1];
+        const float dx = ct * cb - st * sb;
+        const float dy = st * cb + ct * sb;
+        float rng = cast_ray_rects(t.quad_rect, t, gx, gy, dx, dy);
+        if (A > 1) {
+            const unsigned env = car / A;
+#pragma unroll
+            for (unsigned o = 0; o < (unsigned)A; ++o) {
+                const unsigned oc = env * A + o;
+                if (oc != car) {
+                    const float tc = ray_vs_car(lx, ly, dx, dy, p.st.x[oc], p.st.y[oc], p.st.ct[oc], p.st.st[oc]);
+                    rng = tc < rng ? tc : rng;
+                }
+            }
+        }
+        if (p.lidar_transform == 1) rng = rng / RCS_MAX_RANGE - 0.5f;                 // dreamer/tools.py:274
+        else if (p.lidar_transform == 2) rng = rng * (1.0f / RCS_MAX_RANGE);          // single_agent.py:92-99
+        out[beam] = rng;
+    }
+}
+
 // lidar_occupancy (H11, dreamer/wrappers.py:390-408): ego-aligned 64x64 patch of the drivable area,
 // heading = +col, 3.125 cells per pixel, 1 = drivable.  Direct inverse map of the reference's
 // crop -> rotate -> centre-crop -> resize chain: centred on the north-west corner of the car's cell,
@@ -1181,7 +1221,10 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
-    if (li.raycast_variant == 6) {
+    if (li.raycast_variant == 7) {
+        const int threads = li.car_threads, per = threads / 64;                     // cars (waves) per workgroup
+        DISPATCH_A(p.cars_per_env, rc_raycast_car_kernel<kA><<<dim3((p.n_cars + per - 1) / per), dim3(threads), 0, s>>>(p));
+    } else if (li.raycast_variant == 6) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 6><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
     } else if (li.raycast_variant == 5) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 5><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));

@@ -139,7 +139,7 @@ def test_raycast_variants_from_arbitrary_poses(track_name):
     env = BatchedRaceEnv(t, n, 1)
     env.reset()
     # gbr / barcelona: the packed 4x4 table (247 / 177 KB) exceeds the LDS; gbr's u8 table uses 8x8 blocks
-    variants = {"gbr": [0, 1, 2, 4, 5, 6], "barcelona": [0, 1, 2, 4, 5, 6]}.get(track_name, [0, 1, 2, 3, 4, 5, 6])
+    variants = {"gbr": [0, 1, 2, 4, 5, 6, 7], "barcelona": [0, 1, 2, 4, 5, 6, 7]}.get(track_name, [0, 1, 2, 3, 4, 5, 6, 7])
     for variant in variants:
         env.set_raycast_variant(variant)
         got = env.set_pose(poses)["lidar"]
@@ -183,7 +183,7 @@ def test_default_raycast_dense_poses(track_name):
     want = _oracle_scan(t, poses)
     env = BatchedRaceEnv(t, n, 1)
     env.reset()
-    for variant in {"barcelona": [6, 0, 1, 2, 4, 5]}.get(track_name, [6, 0, 1, 2, 3, 4, 5]):
+    for variant in {"barcelona": [7, 6, 0, 1, 2, 4, 5]}.get(track_name, [7, 6, 0, 1, 2, 3, 4, 5]):
         env.set_raycast_variant(variant)
         got = env.set_pose(poses)["lidar"]
         torch.cuda.synchronize()
@@ -280,7 +280,7 @@ def test_raycast_variants_two_cars():
     want = _oracle_scan(t, poses, cars=2)
     env = BatchedRaceEnv(t, n // 2, 2)
     env.reset()
-    for variant in (0, 1, 2, 3, 4, 5, 6):
+    for variant in (0, 1, 2, 3, 4, 5, 6, 7):
         env.set_raycast_variant(variant)
         got = env.set_pose(poses)["lidar"]
         torch.cuda.synchronize()
