@@ -789,21 +789,27 @@ __device__ __forceinline__ float max_with(float a, float lo) {               // 
 // at the stop.  Shifted index: j = i for a positive direction, i + 1 for a negative one - then the boundary is
 // j + offset for both signs and the shifted index of the cell behind that boundary is the boundary itself, so a
 // trip needs no sign arithmetic at all.
+// START4 = false: the entry of the start cell is loaded here (v4 unused).  START4 = true: the caller read the
+// start cell's four plane entries once for all rays of the car (v4[q], 0 if the sensor is off the grid).
+template <bool START4>
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
-                                                float dx, float dy) {
+                                                float dx, float dy, int ix, int iy, const unsigned *v4) {
     // A NaN direction (non-finite car state) would make the cell arithmetic below meaningless and could walk
     // the table index anywhere; v_max turns it into a finite number (any legal component is >= -1.0000002, so
     // legal rays are untouched) and the ray then ends at the ring like every other.
     dx = max_with(dx, -2.0f);
     dy = max_with(dy, -2.0f);
-    const int ix = (int)floorf(gx), iy = (int)floorf(gy);
     const int pitch2 = t.cell_pitch * 2;
     const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;      // 1: the boundary ahead is the upper one
     const char *qb = reinterpret_cast<const char *>(qr);
     const unsigned qoff = (unsigned)__mul24(pyi * 2 + pxi, t.quad_plane_bytes);
     unsigned v = 0;
-    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
+    if (START4) {
+        const unsigned lo = pxi ? v4[1] : v4[0], hi = pxi ? v4[3] : v4[2];
+        v = pyi ? hi : lo;
+    } else if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
         v = *reinterpret_cast<const uint16_t *>(qb + (__umul24(iy, pitch2) + (((unsigned)ix << 1) + qoff)));
+    }
     const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     float idx, idy;
     ray_reciprocals(dx, dy, idx, idy);
@@ -874,7 +880,7 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 6   ? cast_ray_rects(t.quad_rect, t, gx, gy, dx, dy)
+        float rng = VARIANT == 6   ? cast_ray_rects<false>(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy), nullptr)
                     : VARIANT == 5 ? cast_ray_cells(t.cell_dist, t, gx, gy, dx, dy)
                     : VARIANT == 4 ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
                     : VARIANT == 3 ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
@@ -916,11 +922,21 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p) {
     const float gx = (lx - t.org_x) * t.inv_res;
     const float gy = (ly - t.org_y) * t.inv_res;
     float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
+    // the start cell and its entry in each of the four quadrant planes: the same for all 1080 rays
+    const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
+    unsigned v4[4] = {0u, 0u, 0u, 0u};
+    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
+        const char *cell = reinterpret_cast<const char *>(t.quad_rect) + ((size_t)iy * t.cell_pitch + ix) * 2;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const uint16_t *>(cell + (size_t)q * t.quad_plane_bytes);
+    }
+    float2 bm = *reinterpret_cast<const float2 *>(t.beams + 2 * lane);
     for (unsigned beam = lane; beam < RC_N_BEAMS; beam += 64u) {
-        const float cb = t.beams[2 * beam], sb = t.beams[2 * beam + 1];
+        const float cb = bm.x, sb = bm.y;
+        if (beam + 64u < RC_N_BEAMS) bm = *reinterpret_cast<const float2 *>(t.beams + 2 * (beam + 64u));   // next round's beam
         const float dx = ct * cb - st * sb;
         const float dy = st * cb + ct * sb;
-        float rng = cast_ray_rects(t.quad_rect, t, gx, gy, dx, dy);
+        float rng = cast_ray_rects<true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, v4);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll
