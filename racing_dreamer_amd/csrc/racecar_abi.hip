@@ -430,7 +430,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     auto setbit = [&](int ix, int iy) { ray[(size_t)iy * pitch + (ix >> 5)] |= 1u << (ix & 31); };
     for (int ix = 0; ix < w; ++ix) { setbit(ix, 0); setbit(ix, h - 1); }
     for (int iy = 0; iy < h; ++iy) { setbit(0, iy); setbit(w - 1, iy); }
-    std::vector<float> beams(RC_N_BEAMS * 2), foot(RCS_N_FOOTPRINT * 2);
+    std::vector<float> beams(((RC_N_BEAMS + 63) / 64) * 64 * 2, 0.0f), foot(RCS_N_FOOTPRINT * 2);   // beams padded to whole waves
     make_tables(beams.data(), foot.data());
     // Free-block table for the skipping traversal: exact chessboard distance transform of the stop cells
     // (two raster passes), then the minimum over each block.  A block value v >= 1 certifies that every

@@ -725,8 +725,8 @@ __device__ __forceinline__ int byte_xor(unsigned word, int m) {              // 
 // and only exactly zero or >= 1e-32 in practice, so that path runs when a beam is exactly axis-parallel.
 // 6 + 4 instructions instead of 2 x 11 for the division expansion.
 __device__ __forceinline__ void ray_reciprocals(float dx, float dy, float &idx, float &idy) {
-    const float ax = fabsf(dx), ay = fabsf(dy);
-    if (ax >= 0x1p-100f && ax <= 0x1p100f && ay >= 0x1p-100f && ay <= 0x1p100f) {
+    // callers pass components already forced into [-2, 2], so only the lower bound needs a test
+    if (fabsf(dx) >= 0x1p-100f && fabsf(dy) >= 0x1p-100f) {
         const float rx = __builtin_amdgcn_rcpf(dx), ry = __builtin_amdgcn_rcpf(dy);
         idx = __builtin_fmaf(__builtin_fmaf(-dx, rx, 1.0f), rx, rx);
         idy = __builtin_fmaf(__builtin_fmaf(-dy, ry, 1.0f), ry, ry);
@@ -745,8 +745,8 @@ __global__ __launch_bounds__(256) void rc_selftest_rcp_kernel(uint32_t exp_lo, u
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t bits = ((exp_lo + (uint32_t)(i >> 23)) << 23) | (uint32_t)(i & 0x7fffffu);
         const float d = __uint_as_float(bits), one = 1.0f;
-        float fx, fy;
-        ray_reciprocals(d, -d, fx, fy);
+        const float rp = __builtin_amdgcn_rcpf(d), rn = __builtin_amdgcn_rcpf(-d);          // the fast path of ray_reciprocals
+        const float fx = __builtin_fmaf(__builtin_fmaf(-d, rp, 1.0f), rp, rp), fy = __builtin_fmaf(__builtin_fmaf(d, rn, 1.0f), rn, rn);
         bad += __float_as_uint(fx) != __float_as_uint(one / d);
         bad += __float_as_uint(fy) != __float_as_uint(one / -d);
     }
@@ -782,6 +782,11 @@ __device__ __forceinline__ float max_with(float a, float lo) {               // 
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(lo));
     return r;
 }
+__device__ __forceinline__ float min_with(float a, float hi) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(hi));
+    return r;
+}
 
 // Table entry (uint16 per quadrant plane and cell): byte 0 = signed x offset from the SHIFTED cell index to the
 // boundary that leaves the rectangle (+width for a ray heading +x, -width for -x), byte 1 the same for y; a wall
@@ -794,35 +799,35 @@ __device__ __forceinline__ float max_with(float a, float lo) {               // 
 template <bool START4>
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
                                                 float dx, float dy, int ix, int iy, const unsigned *v4) {
-    // A NaN direction (non-finite car state) would make the cell arithmetic below meaningless and could walk
-    // the table index anywhere; v_max turns it into a finite number (any legal component is >= -1.0000002, so
-    // legal rays are untouched) and the ray then ends at the ring like every other.
-    dx = max_with(dx, -2.0f);
-    dy = max_with(dy, -2.0f);
+    // A non-finite direction (diverged car state) would make the cell arithmetic below meaningless and could walk
+    // the table index anywhere; v_max / v_min (IEEE maxNum / minNum: a NaN operand yields the other one) force it
+    // into [-2, 2].  Any legal component has magnitude <= 1.0000002, so legal rays are untouched; an illegal one
+    // becomes some finite ray that ends at the ring like every other.
+    dx = min_with(max_with(dx, -2.0f), 2.0f);
+    dy = min_with(max_with(dy, -2.0f), 2.0f);
+    // -1 for a negative direction, 0 otherwise.  The spec steps towards + iff d >= 0, which includes -0.0, hence
+    // the + 0.0f (-0.0 + 0.0 = +0.0) in front of the sign extraction.
+    const int nx = sign_mask(dx + 0.0f), ny = sign_mask(dy + 0.0f);
     const int pitch2 = t.cell_pitch * 2;
-    const int pxi = dx >= 0.0f ? 1 : 0, pyi = dy >= 0.0f ? 1 : 0;      // 1: the boundary ahead is the upper one
     const char *qb = reinterpret_cast<const char *>(qr);
-    const unsigned qoff = (unsigned)__mul24(pyi * 2 + pxi, t.quad_plane_bytes);
+    int jx = ix - nx, jy = iy - ny;                                       // shifted cell index
+    // other-axis position in shifted coordinates.  gx + 1 is off by at most one rounding (< 1.3e-4 cell on grids
+    // up to 2048 wide), far inside the 1e-3 band in which the exact count below takes over.
+    const float hx = bfi(nx, gx + 1.0f, gx), hy = bfi(ny, gy + 1.0f, gy);
+    // byte offset of shifted cell (0, 0) in this ray's plane q = 2 (dy >= 0) + (dx >= 0); true cell = shifted + n:
+    // q * P + ny * pitch2 + nx * 2 with q = 3 + 2 ny + nx
+    const int P = t.quad_plane_bytes;
+    unsigned qoffp = (unsigned)(3 * P) - (unsigned)(ny & (2 * P + pitch2)) - (unsigned)(nx & (P + 2));
+    asm("" : "+v"(qoffp));                                                // one value: keep it out of the loop's address math
     unsigned v = 0;
     if (START4) {
-        const unsigned lo = pxi ? v4[1] : v4[0], hi = pxi ? v4[3] : v4[2];
-        v = pyi ? hi : lo;
+        v = (unsigned)bfi(ny, bfi(nx, (int)v4[0], (int)v4[1]), bfi(nx, (int)v4[2], (int)v4[3]));
     } else if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
-        v = *reinterpret_cast<const uint16_t *>(qb + (__umul24(iy, pitch2) + (((unsigned)ix << 1) + qoff)));
+        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, ((unsigned)jx << 1) + qoffp));
     }
     const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     float idx, idy;
     ray_reciprocals(dx, dy, idx, idy);
-    int nx = pxi - 1, ny = pyi - 1;                                       // -1 for a negative direction
-    asm("" : "+v"(nx));                                                   // see cast_ray_packed
-    asm("" : "+v"(ny));
-    int jx = ix - nx, jy = iy - ny;                                       // shifted cell index
-    // other-axis position in shifted coordinates.  hx differs from gx + 1 by at most one rounding (< 1.3e-4
-    // cell on grids up to 2048 wide), far inside the 1e-3 band in which the exact count below takes over.
-    const float hx = gx - (float)nx, hy = gy - (float)ny;
-    // byte offset of shifted cell (jx, jy) in this ray's plane: true cell = (jx + nx, jy + ny)
-    unsigned qoffp = qoff - (unsigned)(ny & pitch2) + ((unsigned)nx << 1);
-    asm("" : "+v"(qoffp));                                                // one value: keep it out of the loop's address math
     const float tmax = t.tmax;
     float tt = 0.0f;
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
@@ -930,10 +935,16 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const uint16_t *>(cell + (size_t)q * t.quad_plane_bytes);
     }
-    float2 bm = *reinterpret_cast<const float2 *>(t.beams + 2 * lane);
-    for (unsigned beam = lane; beam < RC_N_BEAMS; beam += 64u) {
+    const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
+    unsigned boff = lane * 8u;
+    float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
+    constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
+    for (int round = 0; round < kRounds; ++round) {
+        const unsigned beam = lane + 64u * (unsigned)round;
+        if (beam >= RC_N_BEAMS) break;                                    // last round: 56 of 64 lanes
         const float cb = bm.x, sb = bm.y;
-        if (beam + 64u < RC_N_BEAMS) bm = *reinterpret_cast<const float2 *>(t.beams + 2 * (beam + 64u));   // next round's beam
+        boff += 512u;
+        if (round + 1 < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);                      // next round's beams
         const float dx = ct * cb - st * sb;
         const float dy = st * cb + ct * sb;
         float rng = cast_ray_rects<true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, v4);
