@@ -174,6 +174,13 @@ int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes);
  * plus OCCUPANCY when enabled): the source buffer of the multi-GPU all-gather. */
 int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes);
 
+/* Re-point the output fields (everything rc_get returns except RC_F_ACTION_IN, which stays where it is) at
+ * another device buffer of at least rc_arena_bytes(), 64-byte aligned; NULL = back to the handle's own arena.
+ * Stream-ordered: the next rc_reset / rc_step / rc_set_pose writes there.  This is how a device-resident
+ * trajectory ring is filled without copies - the step after Collect.step in the reference
+ * (dreamer/wrappers.py:213-219, dreamer/tools.py:235-264): one arena per time slot, rotate before each step. */
+int rc_set_arena(rc_env *env, void *arena, size_t bytes);
+
 int rc_sync(rc_env *env);
 void *rc_stream(rc_env *env);      /* the hipStream_t the handle launches on */
 

@@ -63,6 +63,7 @@ SYMBOLS = {
     "rc_reset_kernel_times": (C.c_int, [C.c_void_p]),
     "rc_set_raycast_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "rc_spec_tables": (None, [C.c_void_p, C.c_void_p]),
+    "rc_set_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rc_last_error": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),

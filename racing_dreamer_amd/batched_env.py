@@ -124,6 +124,7 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_get(self._h, L.F_POSE, C.byref(p0), C.byref(n0)))
         L.check(self._lib.rc_get(self._h, L.F_TIME, C.byref(p1), C.byref(n1)))
         self.summary_slab = self._arena_view[p0.value - base:p1.value - base + n1.value]
+        self._own_views = self.views
         if profiling:
             self.set_profiling(True)
 
@@ -245,6 +246,32 @@ class BatchedRaceEnv:
             out[name] = {"total_ms": ms.value, "launches": int(n.value),
                          "avg_ms": ms.value / n.value if n.value else 0.0}
         return out
+
+    @property
+    def arena_nbytes(self) -> int:
+        return int(self._arena_view.numel())
+
+    def views_of(self, arena: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """Typed views [num_envs, cars_per_env, ...] of every output field inside another arena-sized uint8 buffer."""
+        out = {}
+        for name, (off, nb, dtype, tail) in self._host_layout.items():
+            out[name] = arena[off:off + nb].view(getattr(torch, dtype)).view(self.num_envs, self.cars_per_env, *tail)
+        return out
+
+    def set_arena(self, arena: Optional[torch.Tensor], views: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """Re-point the outputs of the following reset()/step() calls at `arena` (uint8, >= arena_nbytes, 64-byte
+        aligned, on the env's device); None = back to the env's own arena.  `action_in` stays where it is.  This is
+        how `replay.TrajectoryRing` records trajectories on the device without copies."""
+        if arena is None:
+            L.check(self._lib.rc_set_arena(self._h, None, 0))
+            self.views = self._own_views
+            return
+        if arena.dtype != torch.uint8 or arena.device != self.device or not arena.is_contiguous():
+            raise ValueError("arena must be a contiguous uint8 tensor on the env's device")
+        L.check(self._lib.rc_set_arena(self._h, arena.data_ptr(), arena.numel()))
+        new = dict(views) if views is not None else self.views_of(arena)
+        new["action_in"] = self._own_views["action_in"]
+        self.views = new
 
     def host_snapshot(self) -> Dict[str, np.ndarray]:
         """Every output field on the host from ONE device-to-host copy of the arena (for small batches, e.g. the

@@ -86,7 +86,8 @@ struct rc_env {
     void *state_mem = nullptr;
     void *track_mem = nullptr;
     uint8_t *mask_dev = nullptr;
-    float *actions_in = nullptr;   // inside the arena (RC_F_ACTION_IN)
+    float *actions_in = nullptr;   // inside the arena the handle was created with (RC_F_ACTION_IN)
+    void *out_arena = nullptr;     // where the output fields currently point (rc_set_arena)
     RcParams params{};
     RcLaunchInfo launch{};
     bool has_track = false;
@@ -185,6 +186,37 @@ void set_launch_geometry(rc_env *env) {
             li.ray_blocks = (int)std::min<long long>(chunks, per_cu < 0 ? chunks : resident);
         }
     }
+}
+
+// Point every output field at `arena` (layout of make_layout).  The action input buffer is NOT part of this: it
+// stays in the arena the handle was created with, so re-pointing the outputs (rc_set_arena) between producing
+// the actions and stepping is safe.
+void bind_outputs(rc_env *env, void *arena) {
+    char *a = (char *)arena;
+    const Layout &l = env->layout;
+    RcOutDev &o = env->params.out;
+    o.lidar = (float *)(a + l.offset[RC_F_LIDAR]);
+    o.pose = (float *)(a + l.offset[RC_F_POSE]);
+    o.velocity = (float *)(a + l.offset[RC_F_VELOCITY]);
+    o.speed = (float *)(a + l.offset[RC_F_SPEED]);
+    o.action = (float *)(a + l.offset[RC_F_ACTION]);
+    o.reward = (float *)(a + l.offset[RC_F_REWARD]);
+    o.discount = (float *)(a + l.offset[RC_F_DISCOUNT]);
+    o.progress_total = (float *)(a + l.offset[RC_F_PROGRESS_TOTAL]);
+    o.time = (float *)(a + l.offset[RC_F_TIME]);
+    o.patch = (uint8_t *)(a + l.offset[RC_F_OCCUPANCY]);
+    o.progress = (float *)(a + l.offset[RC_F_PROGRESS]);
+    o.lap = (int32_t *)(a + l.offset[RC_F_LAP]);
+    o.cp = (int32_t *)(a + l.offset[RC_F_CHECKPOINT]);
+    o.done = (uint8_t *)(a + l.offset[RC_F_DONE]);
+    o.trunc = (uint8_t *)(a + l.offset[RC_F_TRUNCATED]);
+    o.wall = (uint8_t *)(a + l.offset[RC_F_WALL_COLLISION]);
+    o.opp = (uint8_t *)(a + l.offset[RC_F_OPPONENT_COLLISION]);
+    o.wrong = (uint8_t *)(a + l.offset[RC_F_WRONG_WAY]);
+    o.fresh = (uint8_t *)(a + l.offset[RC_F_FRESH]);
+    o.accel = (float *)(a + l.offset[RC_F_ACCELERATION]);
+    o.steer = (float *)(a + l.offset[RC_F_STEERING_ANGLE]);
+    env->out_arena = arena;
 }
 
 int observe(rc_env *env) {
@@ -341,33 +373,8 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         uint8_t **bp[] = {&s.wall, &s.opp, &s.wrong, &s.done, &s.trunc, &s.fresh};
         for (uint8_t **b : bp) { *b = (uint8_t *)m; m += nc; }
     }
-    {
-        char *a = (char *)env->arena;
-        const Layout &l = env->layout;
-        RcOutDev &o = env->params.out;
-        o.lidar = (float *)(a + l.offset[RC_F_LIDAR]);
-        o.pose = (float *)(a + l.offset[RC_F_POSE]);
-        o.velocity = (float *)(a + l.offset[RC_F_VELOCITY]);
-        o.speed = (float *)(a + l.offset[RC_F_SPEED]);
-        o.action = (float *)(a + l.offset[RC_F_ACTION]);
-        o.reward = (float *)(a + l.offset[RC_F_REWARD]);
-        o.discount = (float *)(a + l.offset[RC_F_DISCOUNT]);
-        o.progress_total = (float *)(a + l.offset[RC_F_PROGRESS_TOTAL]);
-        o.time = (float *)(a + l.offset[RC_F_TIME]);
-        o.patch = (uint8_t *)(a + l.offset[RC_F_OCCUPANCY]);
-        o.progress = (float *)(a + l.offset[RC_F_PROGRESS]);
-        o.lap = (int32_t *)(a + l.offset[RC_F_LAP]);
-        o.cp = (int32_t *)(a + l.offset[RC_F_CHECKPOINT]);
-        o.done = (uint8_t *)(a + l.offset[RC_F_DONE]);
-        o.trunc = (uint8_t *)(a + l.offset[RC_F_TRUNCATED]);
-        o.wall = (uint8_t *)(a + l.offset[RC_F_WALL_COLLISION]);
-        o.opp = (uint8_t *)(a + l.offset[RC_F_OPPONENT_COLLISION]);
-        o.wrong = (uint8_t *)(a + l.offset[RC_F_WRONG_WAY]);
-        o.fresh = (uint8_t *)(a + l.offset[RC_F_FRESH]);
-        o.accel = (float *)(a + l.offset[RC_F_ACCELERATION]);
-        o.steer = (float *)(a + l.offset[RC_F_STEERING_ANGLE]);
-        env->actions_in = (float *)(a + l.offset[RC_F_ACTION_IN]);
-    }
+    bind_outputs(env, env->arena);
+    env->actions_in = (float *)((char *)env->arena + env->layout.offset[RC_F_ACTION_IN]);
     RcParams &p = env->params;
     p.num_envs = cfg->num_envs;
     p.cars_per_env = cfg->cars_per_env;
@@ -656,7 +663,8 @@ int rc_get(rc_env *env, int32_t field, void **dev_ptr, size_t *bytes) {
     if (!env || !dev_ptr || !bytes) return fail(RC_ERR_INVALID, "NULL argument");
     if (field < 0 || field >= RC_F_COUNT) return fail(RC_ERR_INVALID, "unknown field %d", field);
     if (env->layout.bytes[field] == 0) return fail(RC_ERR_INVALID, "field %d is not enabled in this configuration", field);
-    *dev_ptr = (char *)env->arena + env->layout.offset[field];
+    // outputs follow rc_set_arena; the action input buffer stays in the handle's own arena
+    *dev_ptr = (char *)(field == RC_F_ACTION_IN ? env->arena : env->out_arena) + env->layout.offset[field];
     *bytes = env->layout.bytes[field];
     return RC_OK;
 }
@@ -675,7 +683,7 @@ int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes) {
 
 int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes) {
     if (!env || !dev_ptr || !bytes) return fail(RC_ERR_INVALID, "NULL argument");
-    *dev_ptr = env->arena;
+    *dev_ptr = env->out_arena;
     *bytes = env->layout.slab_bytes;
     return RC_OK;
 }
@@ -713,6 +721,17 @@ int rc_reset_kernel_times(rc_env *env) {
     int rc = drain_events(env);
     if (rc) return rc;
     for (int k = 0; k < RC_K_COUNT; ++k) { env->k_ms[k] = 0; env->k_n[k] = 0; }
+    return RC_OK;
+}
+
+int rc_set_arena(rc_env *env, void *arena, size_t bytes) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!arena) arena = env->arena;                                   // NULL: back to the handle's own arena
+    else {
+        if (bytes < env->layout.total) return fail(RC_ERR_INVALID, "arena too small: %zu < %zu", bytes, env->layout.total);
+        if ((uintptr_t)arena % 64) return fail(RC_ERR_INVALID, "arena must be 64-byte aligned");
+    }
+    bind_outputs(env, arena);
     return RC_OK;
 }
 

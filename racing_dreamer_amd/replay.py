@@ -1,0 +1,132 @@
+"""Device-resident trajectory ring: the replay store of the batched env.
+
+The reference keeps experience as episode files: `Collect` appends one transition per agent step
+(dreamer/wrappers.py:213-219), `save_episodes` writes `.npz` files (dreamer/callbacks.py:41-53) and
+`load_episodes` samples fixed-length windows out of them for the learner (dreamer/tools.py:235-264).  With tens of
+thousands of envs on one MI355X the same role is played by a ring of the last `capacity` step records of EVERY
+car, resident in HBM (288 GB hold ~900 steps of 65 536 cars with full 1080-beam scans): before each step the env's
+output arena is re-pointed at the next slot (`rc_set_arena`), so the kernels write the record straight into the
+ring - no copy, no host - and `sample()` gathers `[batch, length, ...]` windows with one indexed read per field.
+
+Window semantics follow the reference's dataset: a window never crosses an episode boundary (an auto-reset inside
+a window would splice two episodes); a window that starts on the first record of an episode gets the reference's
+reset row there (action 0, reward 0, discount 1, progress -1, time 0 - wrappers.py:232-236).  `EpisodeRecorder` (trajectory.py) remains
+the way to write reference-format episode files for a subset of cars.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Sequence
+
+import torch
+
+DEFAULT_SAMPLE_FIELDS = ("lidar", "lidar_occupancy", "action", "reward", "discount", "progress_total", "time",
+                         "speed", "done", "fresh")
+
+
+class TrajectoryRing:
+    def __init__(self, env, capacity: int):
+        """`env`: a BatchedRaceEnv (anything with `_host_layout`, `arena_nbytes`, `device`, `num_envs`,
+        `cars_per_env`, `set_arena()`, `reset()`, `step()`).  Allocates capacity x arena bytes on the env's device."""
+        if capacity < 2:
+            raise ValueError("capacity must be >= 2")
+        self.env = env
+        self.capacity = int(capacity)
+        self.slot_bytes = (env.arena_nbytes + 63) // 64 * 64
+        raw = torch.zeros(self.capacity * self.slot_bytes + 64, dtype=torch.uint8, device=env.device)
+        pad = (-raw.data_ptr()) % 64
+        self._raw = raw
+        self.buffer = raw[pad:pad + self.capacity * self.slot_bytes]
+        self.head = -1            # slot of the latest record
+        self.count = 0            # records held (<= capacity)
+        self.steps_written = 0
+        self._slot_views: Dict[int, Dict[str, torch.Tensor]] = {}
+        # one strided tensor per field over all slots: [capacity, num_envs, cars_per_env, ...]
+        self.fields: Dict[str, torch.Tensor] = {}
+        for name, (off, nb, dtype, tail) in env._host_layout.items():
+            if name == "action_in":
+                continue
+            flat = torch.as_strided(self.buffer, (self.capacity, nb), (self.slot_bytes, 1), off)
+            self.fields[name] = flat.view(getattr(torch, dtype)).view(self.capacity, env.num_envs, env.cars_per_env, *tail)
+
+    # ------------------------------------------------------------------ writing
+    def slot(self, k: int) -> torch.Tensor:
+        return self.buffer[k * self.slot_bytes:(k + 1) * self.slot_bytes]
+
+    def _advance(self) -> None:
+        self.head = (self.head + 1) % self.capacity
+        views = self._slot_views.get(self.head)
+        if views is None:
+            views = self.env.views_of(self.slot(self.head))
+            self._slot_views[self.head] = views
+        self.env.set_arena(self.slot(self.head), views)
+        self.count = min(self.count + 1, self.capacity)
+        self.steps_written += 1
+
+    def reset(self, *args, **kwargs) -> Dict[str, torch.Tensor]:
+        """env.reset() recorded as the next ring record."""
+        self._advance()
+        return self.env.reset(*args, **kwargs)
+
+    def step(self, actions=None, repeat=None) -> Dict[str, torch.Tensor]:
+        """env.step() recorded as the next ring record.  Device-side agents that read the current observation
+        (`env.follow_the_gap()`) must run BEFORE this call: it re-points the outputs first."""
+        self._advance()
+        return self.env.step(actions, repeat=repeat)
+
+    def latest(self) -> Dict[str, torch.Tensor]:
+        return self.env.views
+
+    def detach(self) -> None:
+        """Give the env its own arena back (the ring keeps its contents)."""
+        self.env.set_arena(None)
+
+    # ------------------------------------------------------------------ reading
+    def window_starts(self, length: int) -> int:
+        """Number of distinct start times of a `length`-step window inside the filled part of the ring."""
+        return max(self.count - length + 1, 0)
+
+    def sample(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
+               generator: Optional[torch.Generator] = None, reset_rows: bool = True,
+               max_tries: int = 16) -> Dict[str, torch.Tensor]:
+        """`batch` windows of `length` consecutive records of one car each, uniformly over (time, env, car) among
+        the windows that contain no episode start after their first record.  Returns field -> [batch, length, ...]
+        (copies, on the ring's device) plus `env`, `car`, `t0` (ring age of the first record, 0 = oldest)."""
+        nstart = self.window_starts(length)
+        if nstart <= 0:
+            raise ValueError(f"ring holds {self.count} records, a window needs {length}")
+        names = [f for f in (fields or DEFAULT_SAMPLE_FIELDS) if f in self.fields]
+        dev = self.buffer.device
+        oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
+        ar = torch.arange(length, device=dev)
+        fresh = self.fields["fresh"]
+        keep_t, keep_e, keep_c, have = [], [], [], 0
+        for _ in range(max_tries):
+            m = max(2 * (batch - have), 16)
+            t0 = torch.randint(0, nstart, (m,), device=dev, generator=generator)
+            e = torch.randint(0, self.env.num_envs, (m,), device=dev, generator=generator)
+            c = torch.randint(0, self.env.cars_per_env, (m,), device=dev, generator=generator)
+            slots = (oldest + t0[:, None] + ar[None, :]) % self.capacity                    # [m, length]
+            ok = ~(fresh[slots[:, 1:], e[:, None], c[:, None]] != 0).any(1) if length > 1 else torch.ones(m, dtype=torch.bool, device=dev)
+            keep_t.append(t0[ok]); keep_e.append(e[ok]); keep_c.append(c[ok])
+            have += int(ok.sum())
+            if have >= batch:
+                break
+        else:
+            raise RuntimeError(f"could not find {batch} windows of {length} records without an episode boundary")
+        t0 = torch.cat(keep_t)[:batch]; e = torch.cat(keep_e)[:batch]; c = torch.cat(keep_c)[:batch]
+        slots = (oldest + t0[:, None] + ar[None, :]) % self.capacity
+        out = {name: self.fields[name][slots, e[:, None], c[:, None]] for name in names}
+        if reset_rows:
+            first = self.fields["fresh"][slots[:, 0], e, c] != 0               # window starts an episode
+            if "action" in out:
+                out["action"][first, 0] = 0.0
+            if "reward" in out:
+                out["reward"][first, 0] = 0.0
+            if "discount" in out:
+                out["discount"][first, 0] = 1.0
+            if "time" in out:
+                out["time"][first, 0] = 0.0
+            if "progress_total" in out:
+                out["progress_total"][first, 0] = -1.0
+        out["env"], out["car"], out["t0"] = e, c, t0
+        return out
