@@ -193,7 +193,7 @@ def main():
                 "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
                 "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
                 "rays_per_s": n_cars * 1080 / ray_s if ray_s > 0 else 0.0,
-                "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by VALU/LDS work "
+                "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by VALU work "
                         "of the grid traversal, not by HBM (SURVEY.md §8d); see DESIGN.md §5",
             },
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},

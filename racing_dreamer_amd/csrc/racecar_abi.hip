@@ -174,6 +174,16 @@ void set_launch_geometry(rc_env *env) {
         const char *e = getenv("RC_RAY_THREADS");
         const int threads = e ? atoi(e) : 0;
         li.car_threads = (threads == 64 || threads == 128 || threads == 256) ? threads : 64;
+        // one wave per car needs >= ~4 waves per wave slot (8 per SIMD x 4 SIMDs x CUs) to keep the chip busy and let
+        // the dispatcher balance; smaller batches split each car's 17 rounds over several waves
+        e = getenv("RC_RAY_SPLIT");
+        int split = e ? atoi(e) : 0;
+        if (split < 1 || split > 17) {
+            // (17 rounds: 1, 2 and 4 waves get 17, 9/8 and 5/4/4/4 rounds; anything finer is best done as one round per wave)
+            const long long want = 4LL * 32 * li.n_cu, n = env->n_cars;
+            split = n >= want ? 1 : (2 * n >= want ? 2 : (4 * n >= want ? 4 : 17));
+        }
+        li.car_split = split;
     } else if (li.raycast_variant >= 4) {
         const char *e = getenv("RC_RAY_THREADS");
         int threads = e ? atoi(e) : 0;
@@ -582,6 +592,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     // (variant 3); columbia 0.33 (v6 0.44), barcelona 0.34 (0.39), gbr 0.35 (0.43).
     li.raycast_variant = 7;
     li.car_threads = 64;
+    li.car_split = 1;
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));

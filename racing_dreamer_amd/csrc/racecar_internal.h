@@ -60,7 +60,8 @@ struct RcParams {
 struct RcLaunchInfo {            // per-handle launch geometry decided at rc_load_track
     int32_t n_cu;
     int32_t ray_blocks, ray_threads;
-    int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one car per workgroup
+    int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one wave per workgroup
+    int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
     int32_t patch_blocks, patch_threads;
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit

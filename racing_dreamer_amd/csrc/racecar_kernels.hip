@@ -915,10 +915,12 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
 // 64 (the last with 56 active lanes) - consecutive rounds start from the same cell, so their table lines are
 // still in L1.  No persistent loop: 65 536 independent waves are balanced by the hardware dispatcher, where
 // equal shares of chunks per resident workgroup left the slowest workgroup's tail exposed.
+// `split` waves share a car (wave part k takes rounds k, k + split, ...): small batches still fill the chip.
 template <int A>
-__global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p) {
+__global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int split) {
     const RcTrackDev &t = p.trk;
-    const unsigned car = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
     if (car >= (unsigned)p.n_cars) return;
     const unsigned lane = threadIdx.x & 63u;
     const float ct = p.st.ct[car], st = p.st.st[car];
@@ -936,15 +938,16 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p) {
         for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const uint16_t *>(cell + (size_t)q * t.quad_plane_bytes);
     }
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
-    unsigned boff = lane * 8u;
-    float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
-    for (int round = 0; round < kRounds; ++round) {
+    const unsigned bstep = 512u * (unsigned)split;
+    unsigned boff = lane * 8u + 512u * part;
+    float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
+    for (int round = (int)part; round < kRounds; round += split) {
         const unsigned beam = lane + 64u * (unsigned)round;
         if (beam >= RC_N_BEAMS) break;                                    // last round: 56 of 64 lanes
         const float cb = bm.x, sb = bm.y;
-        boff += 512u;
-        if (round + 1 < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);                      // next round's beams
+        boff += bstep;
+        if (round + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);                  // next round's beams
         const float dx = ct * cb - st * sb;
         const float dy = st * cb + ct * sb;
         float rng = cast_ray_rects<true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, v4);
@@ -1249,8 +1252,9 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
     if (li.raycast_variant == 7) {
-        const int threads = li.car_threads, per = threads / 64;                     // cars (waves) per workgroup
-        DISPATCH_A(p.cars_per_env, rc_raycast_car_kernel<kA><<<dim3((p.n_cars + per - 1) / per), dim3(threads), 0, s>>>(p));
+        const int threads = li.car_threads, per = threads / 64;                     // waves per workgroup
+        const long long waves = (long long)p.n_cars * li.car_split;
+        DISPATCH_A(p.cars_per_env, rc_raycast_car_kernel<kA><<<dim3((unsigned)((waves + per - 1) / per)), dim3(threads), 0, s>>>(p, li.car_split));
     } else if (li.raycast_variant == 6) {
         DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 6><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
     } else if (li.raycast_variant == 5) {
