@@ -162,6 +162,9 @@ def main():
     if rank == 0:
         n_cars = shard.num_envs * args.cars
         ray = ktimes["rc_raycast_kernel"]
+        # the symbol rocprofv3 lists: the default scan (variant 7) is rc_raycast_car_kernel<A>, variants 0-6 rc_raycast_kernel<A, V>
+        variant = 7 if args.raycast_variant is None else args.raycast_variant
+        ray_symbol = f"rc_raycast_car_kernel<{args.cars}>" if variant == 7 else f"rc_raycast_kernel<{args.cars}, {variant}>"
         ray_s = ray["avg_ms"] * 1e-3
         achieved = RAYCAST_BYTES_PER_CAR * n_cars / ray_s / 1e9 if ray_s > 0 else 0.0
         traffic = None
@@ -188,7 +191,7 @@ def main():
                 "gather": gather_mode,
             },
             "roofline": {
-                "bound": "hbm", "kernel": "rc_raycast_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": ray_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
                 "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
