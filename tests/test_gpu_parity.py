@@ -43,6 +43,13 @@ def test_single_car_rollout_matches_oracle(track):
     assert n_done > 0          # the rollout exercised collisions + auto-reset
 
 
+@pytest.mark.parametrize("num_envs,cars", [(1, 1), (7, 3), (65, 1), (1000, 2), (3, 4)])
+def test_odd_batch_shapes(num_envs, cars):
+    """Batch sizes that are not multiples of a wave / workgroup, down to one car: every launch geometry of the
+    default scan (1, 2, 4 or 17 waves per car) and the tails of the other kernels."""
+    _run_pair("columbia", num_envs=num_envs, cars=cars, steps=6, repeat=2, obs_type="lidar_occupancy")
+
+
 def test_occupancy_patch_matches_oracle():
     _run_pair("austria", num_envs=64, cars=1, steps=12, repeat=4, obs_type="lidar_occupancy")
 
