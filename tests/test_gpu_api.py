@@ -114,3 +114,22 @@ def test_reciprocal_selftest_is_exact_on_this_device():
     L.check(lib.rc_selftest_reciprocal(0, C.byref(n), C.byref(bad)))
     assert n.value == 2 * 201 * (1 << 23)
     assert bad.value == 0
+
+
+def test_plain_c_client_builds_and_runs(tmp_path):
+    """The boundary is a C-ABI: examples/c_rollout.c (C99, only include/racecar_hip.h) builds with gcc against the
+    shared library and drives 512 cars with the device-side follow-the-gap agent on a circuit it built itself."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    exe = tmp_path / "c_rollout"
+    libdir = os.path.join(root, "racing_dreamer_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "examples", "c_rollout.c"), "-o", str(exe), "-L", libdir, "-lracecar_hip",
+                    f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    out = subprocess.run([str(exe), "512", "120"], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert 'step before reset: "Must reset environment."' in out
+    assert out.strip().endswith("OK"), out
