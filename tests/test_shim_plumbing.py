@@ -96,3 +96,87 @@ def test_reference_multi_agent_scenario_and_grid_reset(ref_wrappers):
     assert all(0.8 < g < 2.5 for g in gaps)                                 # ~1.2 m of arc apart, never overlapping
     obs, rew, done, info = env.step({a: np.array([0.5, 0.0]) for a in env.agent_ids})
     assert set(rew) == set(done) == {"A", "B", "C", "D"}
+
+
+# ---------------------------------------------------------------------------------------------- baselines side
+class _FilterObservation:                                   # gym.wrappers.FilterObservation (gym 0.17), not reference code
+    def __init__(self, env, filter_keys):
+        import gym
+        self.env, self._keys = env, list(filter_keys)
+        self.action_space = env.action_space
+        self.observation_space = gym.spaces.Dict({k: v for k, v in env.observation_space.spaces.items() if k in self._keys})
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def _f(self, obs):
+        return {k: v for k, v in obs.items() if k in self._keys}
+
+    def reset(self, **kw):
+        return self._f(self.env.reset(**kw))
+
+    def step(self, action):
+        obs, r, d, info = self.env.step(action)
+        return self._f(obs), r, d, info
+
+
+class _TimeLimit:                                           # gym.wrappers.TimeLimit (gym 0.17), not reference code
+    def __init__(self, env, max_episode_steps):
+        self.env, self._max, self._t = env, max_episode_steps, None
+        self.action_space, self.observation_space = env.action_space, env.observation_space
+
+    def __getattr__(self, name):
+        return getattr(self.env, name)
+
+    def reset(self, **kw):
+        self._t = 0
+        return self.env.reset(**kw)
+
+    def step(self, action):
+        assert self._t is not None, "Cannot call env.step() before calling reset()"
+        obs, r, d, info = self.env.step(action)
+        self._t += 1
+        if self._t >= self._max:
+            info["TimeLimit.truncated"] = not d
+            d = True
+        return obs, r, d, info
+
+
+def test_reference_baselines_wrapper_stack_runs_on_the_shim(ref_wrappers, monkeypatch):
+    """The env construction and wrapper order of baselines/racing/experiments/sb3/sb_experiment.py:42-63 with the
+    reference's own wrapper classes (single_agent.py, common.py) on the shim's single-agent env."""
+    import importlib.util
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    SA = load("ref_single_agent", os.path.join(REF, "baselines/racing/environment/single_agent.py"))
+    CM = load("ref_common", os.path.join(REF, "baselines/racing/environment/common.py"))
+    import racecar_gym.envs.single_agent_race as sar
+    from racecar_gym import SingleAgentScenario
+    from racecar_gym.envs import ChangingTrackSingleAgentRaceEnv
+    monkeypatch.chdir(os.path.join(REF, "baselines"))
+    scenarios = [SingleAgentScenario.from_spec(f"scenarios/max_progress/{t}.yml", rendering=False)
+                 for t in ("columbia", "austria")]                                              # sb_experiment.py:61-63
+    env = ChangingTrackSingleAgentRaceEnv(scenarios=scenarios, order="sequential")
+    env = _FilterObservation(env, filter_keys=["lidar"])                                        # :43-48
+    env = SA.Flatten(env, flatten_obs=True, flatten_actions=True)
+    env = SA.NormalizeObservations(env)
+    env = CM.FixedResetMode(env, mode="random")
+    env = _TimeLimit(env, max_episode_steps=40)
+    env = SA.ActionRepeat(env, n=4)
+    assert env.observation_space.shape == (1080,) and env.action_space.shape == (2,)
+    for episode, track in enumerate(("columbia", "austria")):                                   # sequential track order
+        obs = env.reset()
+        assert obs.shape == (1080,) and obs.min() >= 0.0 and obs.max() <= 1.0                   # ranges / 15
+        done, steps, total = False, 0, 0.0
+        while not done:
+            obs, r, done, info = env.step(np.array([0.4, 0.1 if steps % 2 else -0.1]))          # flat (motor, steering)
+            total += r
+            steps += 1
+            assert obs.shape == (1080,) and 0.0 <= obs.min() and obs.max() <= 1.0
+        assert 1 <= steps <= 10                                                                 # 40 sub-steps / repeat 4
+        assert {"wrong_way", "progress", "lap", "wall_collision", "time"} <= set(info)
+        assert np.isfinite(total)
