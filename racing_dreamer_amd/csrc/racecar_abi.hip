@@ -522,7 +522,19 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         // wall = 0x0000, sentinel ring = 0x0100 (byte 0 == 0 stops the ray, entry != 0 then means "no return")
         const int cap = 127;
         std::vector<uint8_t> run((size_t)h * w);
-        const float a1 = 1.0f / 0.92387953f, b1 = 1.0f / 0.38268343f, a2 = b1, b2 = a1;
+        float log_table[128];
+        log_table[0] = -1.0e30f;
+        for (int k = 1; k < 128; ++k) log_table[k] = std::log((float)k);
+        // score of a candidate rectangle: the geometric mean of the exit distances of rays at 11.25, 33.75, 56.25 and
+        // 78.75 degrees inside the quadrant (sum of logs; tools/skip_stats9.py: 4 % fewer trips than the arithmetic
+        // mean at 22.5 / 67.5 degrees, and far fewer than squares or maximal area)
+        float ka[4], kb[4], log_ka_sum = 0.0f;
+        for (int k = 0; k < 4; ++k) {
+            const double ang = (11.25 + 22.5 * k) * 3.14159265358979323846 / 180.0;
+            ka[k] = (float)(1.0 / std::cos(ang));
+            kb[k] = (float)(1.0 / std::sin(ang));
+            log_ka_sum += std::log(ka[k]);
+        }
         for (int q = 0; q < 4; ++q) {
             const int sx = (q & 1) ? 1 : -1, sy = (q & 2) ? 1 : -1;
             for (int iy = 0; iy < h; ++iy) {                      // free run length towards sx, capped
@@ -540,13 +552,15 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
                     if (ix == 0 || iy == 0 || ix == w - 1 || iy == h - 1) { e = 0x0100; continue; }
                     if (!dist[(size_t)iy * w + ix]) continue;
                     int cur = cap, bw = 1, bh = 1;
-                    float best = -1.0f;
+                    float best = -1.0e30f;
                     for (int n = 1; n <= cap; ++n) {
                         const int y = iy + (n - 1) * sy;
                         if (y < 0 || y >= h) break;
                         cur = std::min<int>(cur, run[(size_t)y * w + ix]);
-                        if (cur == 0 || (float)cur * (a1 + a2) <= best) break;
-                        const float sc = std::min((float)cur * a1, (float)n * b1) + std::min((float)cur * a2, (float)n * b2);
+                        // the width only shrinks from here on and the score is at most sum log(width * ka)
+                        if (cur == 0 || 4.0f * log_table[cur] + log_ka_sum <= best) break;
+                        float sc = 0.0f;
+                        for (int k = 0; k < 4; ++k) sc += std::log(std::min((float)cur * ka[k], (float)n * kb[k]));
                         if (sc > best) { best = sc; bw = cur; bh = n; }
                     }
                     e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
