@@ -239,6 +239,51 @@ def test_occupancy_patch_dense_poses(track_name):
     env.close()
 
 
+def test_lap_counter_and_wrong_way_logic_around_the_finish_line():
+    """Cars teleported to just before the finish line drive over it (lap + 1, checkpoint 19 -> 0), cars placed just
+    after it facing backwards reverse over it (wrong_way, lap - 1): the checkpoint state machine (H4) of the kernel
+    against the oracle, step by step, with collisions not terminating so the cars keep going."""
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track("austria")
+    n = 256
+    cl = t.centerline
+    rng = np.random.default_rng(23)
+    fwd = np.nonzero((cl[:, 3] > 0.93) & (cl[:, 3] < 0.985))[0]
+    bwd = np.nonzero((cl[:, 3] > 0.015) & (cl[:, 3] < 0.07))[0]
+    pf = cl[rng.choice(fwd, n // 2)]
+    pb = cl[rng.choice(bwd, n // 2)]
+    poses = np.concatenate([np.stack([pf[:, 0], pf[:, 1], pf[:, 2]], 1),
+                            np.stack([pb[:, 0], pb[:, 1], pb[:, 2] + np.pi], 1)]).astype(np.float32)
+    poses[:, 2] = (poses[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    kw = dict(num_envs=n, cars_per_env=1, terminate_on_collision=False, auto_reset=False, laps=3)
+    env = BatchedRaceEnv(t, n, 1, terminate_on_collision=False, auto_reset=False, laps=3)
+    ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution,
+                              ro.OracleConfig(**kw), threads=8)
+    env.reset(mode="grid"); ora.reset(mode=0)
+    env.set_pose(poses)
+    ora.arr["x"][:], ora.arr["y"][:], ora.arr["theta"][:] = poses[:, 0], poses[:, 1], poses[:, 2]
+    ora.arr["st"][:], ora.arr["ct"][:] = ro.sincos32(poses[:, 2])
+    ora.arr["fresh"][:] = 0
+    ups = downs = wrong_seen = 0
+    prev = np.ones(n, np.int32)            # lap after a grid reset
+    act = np.tile(np.array([[0.7, 0.0]], np.float32), (n, 1))
+    for k in range(45):
+        dv = env.step(torch.from_numpy(act).cuda(), repeat=4)
+        ov = ora.step(act, repeat=4)
+        compare_outputs(dv, ov, n, 1, f"finish line step {k}")
+        lap = np.asarray(ov["lap"]).reshape(n)
+        ups += int((lap > prev).sum()); downs += int((lap < prev).sum())
+        prev = lap.copy()
+        wrong_seen += int(ov["wrong_way"].sum())
+    # the teleport to checkpoint 19 itself reads as a backward jump (lap - 1, wrong_way), driving over the line
+    # forwards then counts the lap again; the reversed cars cross it backwards
+    assert ups >= 16 and downs >= n // 4 and wrong_seen > 0, (ups, downs, wrong_seen)
+    env.close()
+
+
 def test_non_finite_poses_do_not_disturb_the_batch():
     """NaN / inf car states (a diverged policy, a bad teleport) must neither hang the scan nor touch other cars:
     the kernels terminate, finite cars keep their oracle ranges, and the next step still runs."""
