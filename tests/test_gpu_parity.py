@@ -284,6 +284,59 @@ def test_lap_counter_and_wrong_way_logic_around_the_finish_line():
     env.close()
 
 
+@pytest.mark.parametrize("cars", [2, 3])
+def test_close_quarters_inter_car_rays_and_overlap(cars):
+    """Cars teleported next to / onto each other at random and at degenerate relative poses (parallel, touching
+    edge to edge, nose to tail, identical): the ray-vs-rectangle slab test of the scan (H18) and the separating-
+    axis overlap test of the collision check (H5), against the oracle."""
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track("austria")
+    B = 2048
+    n = B * cars
+    rng = np.random.default_rng(31)
+    base = t.centerline[rng.integers(0, len(t.centerline), B)]
+    poses = np.zeros((B, cars, 3), np.float32)
+    poses[:, 0] = np.stack([base[:, 0], base[:, 1], base[:, 2] + rng.uniform(-0.5, 0.5, B)], 1)
+    for a in range(1, cars):
+        off = rng.uniform(-0.9, 0.9, (B, 2))
+        th = rng.uniform(-np.pi, np.pi, B)
+        kind = rng.integers(0, 6, B)
+        c0, s0 = np.cos(poses[:, 0, 2]), np.sin(poses[:, 0, 2])
+        par = kind == 1; off[par] *= 0.5; th[par] = poses[par, 0, 2]                        # parallel, random offset
+        tail = kind == 2; off[tail] = np.stack([-0.55 * c0[tail], -0.55 * s0[tail]], 1); th[tail] = poses[tail, 0, 2]   # nose to tail
+        side = kind == 3; off[side] = np.stack([-0.30 * s0[side], 0.30 * c0[side]], 1); th[side] = poses[side, 0, 2]    # edge to edge
+        same = kind == 4; off[same] = 0.0; th[same] = poses[same, 0, 2]                     # identical pose
+        perp = kind == 5; th[perp] = poses[perp, 0, 2] + np.pi / 2                          # perpendicular
+        poses[:, a, 0] = poses[:, 0, 0] + off[:, 0]
+        poses[:, a, 1] = poses[:, 0, 1] + off[:, 1]
+        poses[:, a, 2] = (th + np.pi) % (2 * np.pi) - np.pi
+    flat = poses.reshape(n, 3)
+    kw = dict(num_envs=B, cars_per_env=cars, terminate_on_collision=False, auto_reset=False)
+    env = BatchedRaceEnv(t, B, cars, terminate_on_collision=False, auto_reset=False)
+    ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution,
+                              ro.OracleConfig(**kw), threads=8)
+    env.reset(mode="grid"); ora.reset(mode=0)
+    dv = env.set_pose(flat)
+    ora.arr["x"][:], ora.arr["y"][:], ora.arr["theta"][:] = flat[:, 0], flat[:, 1], flat[:, 2]
+    ora.arr["st"][:], ora.arr["ct"][:] = ro.sincos32(flat[:, 2])
+    ora.arr["fresh"][:] = 0
+    ora._observe()
+    torch.cuda.synchronize()
+    got = dv["lidar"].cpu().numpy().reshape(n, 1080)
+    assert np.array_equal(got, ora.lidar), np.nonzero((got != ora.lidar).any(1))[0][:8]
+    assert (ora.lidar < 0.6).any()                                             # some rays do end on the neighbour
+    zero = np.zeros((n, 2), np.float32)
+    dv = env.step(torch.from_numpy(zero).cuda(), repeat=1)                     # v = 0: nobody moves, flags are computed
+    ov = ora.step(zero, repeat=1)
+    compare_outputs(dv, ov, B, cars, f"close quarters, {cars} cars")
+    hit = np.asarray(ov["opponent_collision"]).reshape(B, cars)
+    assert 0.2 < hit.any(1).mean() < 0.98                                      # both outcomes well represented
+    env.close()
+
+
 def test_non_finite_poses_do_not_disturb_the_batch():
     """NaN / inf car states (a diverged policy, a bad teleport) must neither hang the scan nor touch other cars:
     the kernels terminate, finite cars keep their oracle ranges, and the next step still runs."""
