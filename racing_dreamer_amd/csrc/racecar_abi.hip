@@ -449,6 +449,9 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     for (int iy = 0; iy < h; ++iy) { setbit(0, iy); setbit(w - 1, iy); }
     std::vector<float> beams(((RC_N_BEAMS + 63) / 64) * 64 * 2, 0.0f), foot(RCS_N_FOOTPRINT * 2);   // beams padded to whole waves
     make_tables(beams.data(), foot.data());
+    // the one-wave-per-car scan relies on no beam being exactly axis-parallel in the sensor frame (racecar_kernels.hip)
+    for (int i = 0; i < 2 * RC_N_BEAMS; ++i)
+        if (!(std::fabs(beams[i]) >= 1e-4f)) return fail(RC_ERR_INVALID, "beam table holds a zero component");
     // Free-block table for the skipping traversal: exact chessboard distance transform of the stop cells
     // (two raster passes), then the minimum over each block.  A block value v >= 1 certifies that every
     // cell within Chebyshev distance v - 1 of any cell of the block is free.
@@ -595,6 +598,13 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
     t.tmax = RCS_MAX_RANGE * t.inv_res;
+    t.band = (float)(std::max(w, h) + 2) * 0x1p-21f;
+    if (const char *e = getenv("RC_RAY_BAND_LOG2")) {   // validation knob (tests/test_gpu_parity.py): a band below the
+        const int l2 = atoi(e);                         // rounding bound must make the parity tests fail
+        if (l2 <= -10 && l2 >= -40) t.band = std::ldexp((float)(std::max(w, h) + 2), l2);
+    }
+    t.band_p1 = 1.0f + t.band;
+    t.band2 = 2.0f * t.band;
     // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
     RcLaunchInfo &li = env->launch;
     li.lds_bytes = bm_bytes;

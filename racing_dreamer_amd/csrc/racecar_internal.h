@@ -24,6 +24,8 @@ struct RcTrackDev {
     int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes, packed_w;   // packed_w: uint32 per packed row
     int32_t h, w, pitch, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
+    float band, band_p1, band2;  // scan variants 6/7: half-width of the zone around a cell boundary in which the other-axis cell
+                                 // is counted exactly = (max(w, h) + 2) * 2^-21 cells; 1 + band; 2 * band
 };
 
 struct RcStateDev {              // persistent per-car / per-env simulator state (SoA)

@@ -758,6 +758,14 @@ __device__ __forceinline__ unsigned long long cmp_nlt_f32(float a, float b) {   
     asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
     return m;
 }
+__device__ __forceinline__ unsigned long long cmp_nlt_f32_s(float a, float b) {        // the same with a wave-uniform b
+    unsigned long long m;
+    asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
+    return m;
+}
+__device__ __forceinline__ bool cmp_lt_f32_s(float a, float b) {                        // a < b, b wave-uniform
+    return a < b;
+}
 __device__ __forceinline__ unsigned long long cmp_ne_u32(uint32_t a, uint32_t b) {      // lane mask of a != b
     unsigned long long m;
     asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
@@ -796,24 +804,36 @@ __device__ __forceinline__ float min_with(float a, float hi) {
 // trip needs no sign arithmetic at all.
 // START4 = false: the entry of the start cell is loaded here (v4 unused).  START4 = true: the caller read the
 // start cell's four plane entries once for all rays of the car (v4[q], 0 if the sensor is off the grid).
-template <bool START4>
+// CLEAN = true: the caller guarantees finite direction components in [-2, 2] that are never -0.0 (the one-wave-per-
+// car kernel checks the car's heading once instead of clamping 1080 directions).
+//
+// Other-axis cell after an exit: z = (origin + band) + tt * d, cell = floor(z), trusted unless fract(z) < 2 band,
+// i.e. unless the position lies within `band` of a cell boundary; then the spec's own comparisons decide
+// (exact_other_cell).  How wide the band must be: with M = the largest coordinate on the grid (cells), the spec
+// crosses boundary b iff fl(fl(b - g) * fl(1/d)) < tt, which differs from the real-number test "b before the
+// position at time tt" by at most 3 roundings = 1.8e-7 M cells, and z carries 3 roundings of its own (origin + band,
+// the product, the sum), another 1.8e-7 M.  band = M * 2^-21 = 4.8e-7 M covers their sum with 30 % to spare: 2.6e-4
+// cell on austria (548 cells wide), 1e-3 on a 2048-cell map.  (The band used to be a fixed 1e-3: a wave took the
+// exact path whenever one of its lanes was inside, 8.6 % of all trips on austria; now 2.3 %.)
+template <bool START4, bool CLEAN>
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
                                                 float dx, float dy, int ix, int iy, const unsigned *v4) {
-    // A non-finite direction (diverged car state) would make the cell arithmetic below meaningless and could walk
-    // the table index anywhere; v_max / v_min (IEEE maxNum / minNum: a NaN operand yields the other one) force it
-    // into [-2, 2].  Any legal component has magnitude <= 1.0000002, so legal rays are untouched; an illegal one
-    // becomes some finite ray that ends at the ring like every other.
-    dx = min_with(max_with(dx, -2.0f), 2.0f);
-    dy = min_with(max_with(dy, -2.0f), 2.0f);
+    if (!CLEAN) {
+        // A non-finite direction (diverged car state) would make the cell arithmetic below meaningless and could
+        // walk the table index anywhere; v_max / v_min (IEEE maxNum / minNum: a NaN operand yields the other one)
+        // force it into [-2, 2].  Any legal component has magnitude <= 1.0000002, so legal rays are untouched; an
+        // illegal one becomes some finite ray that ends at the ring like every other.
+        dx = min_with(max_with(dx, -2.0f), 2.0f) + 0.0f;
+        dy = min_with(max_with(dy, -2.0f), 2.0f) + 0.0f;
+    }
     // -1 for a negative direction, 0 otherwise.  The spec steps towards + iff d >= 0, which includes -0.0, hence
-    // the + 0.0f (-0.0 + 0.0 = +0.0) in front of the sign extraction.
-    const int nx = sign_mask(dx + 0.0f), ny = sign_mask(dy + 0.0f);
+    // the + 0.0f above (-0.0 + 0.0 = +0.0) in front of the sign extraction.
+    const int nx = sign_mask(dx), ny = sign_mask(dy);
     const int pitch2 = t.cell_pitch * 2;
     const char *qb = reinterpret_cast<const char *>(qr);
     int jx = ix - nx, jy = iy - ny;                                       // shifted cell index
-    // other-axis position in shifted coordinates.  gx + 1 is off by at most one rounding (< 1.3e-4 cell on grids
-    // up to 2048 wide), far inside the 1e-3 band in which the exact count below takes over.
-    const float hx = bfi(nx, gx + 1.0f, gx), hy = bfi(ny, gy + 1.0f, gy);
+    // other-axis origin in shifted coordinates, moved up by the band (one rounding each)
+    const float hx = bfi(nx, gx + t.band_p1, gx + t.band), hy = bfi(ny, gy + t.band_p1, gy + t.band);
     // byte offset of shifted cell (0, 0) in this ray's plane q = 2 (dy >= 0) + (dx >= 0); true cell = shifted + n:
     // q * P + ny * pitch2 + nx * 2 with q = 3 + 2 ny + nx
     const int P = t.quad_plane_bytes;
@@ -828,7 +848,7 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     float idx, idy;
     ray_reciprocals(dx, dy, idx, idy);
-    const float tmax = t.tmax;
+    const float band2 = t.band2;
     float tt = 0.0f;
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
     // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
@@ -839,9 +859,9 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
         const float tye = ((float)ye - gy) * idy;
         const int mx = sign_mask(txe - tye);                              // -1: leaves through the x side
         tt = fminf(txe, tye);
-        const float pe = bfi(mx, hy, hx) + tt * bfi(mx, dy, dx);
-        int on = floor_to_int(pe);                                        // shifted cell on the other axis
-        if (fabsf(__builtin_amdgcn_fractf(pe) - 0.5f) > 0.499f) {         // within 1e-3 of a boundary: exact count
+        const float z = bfi(mx, hy, hx) + tt * bfi(mx, dy, dx);
+        int on = floor_to_int(z);                                         // shifted cell on the other axis
+        if (cmp_lt_f32_s(__builtin_amdgcn_fractf(z), band2)) {            // within `band` of a boundary: exact count
             const int na = bfi(mx, ny, nx);                               // true cell = shifted cell + na
             on = exact_other_cell(on + na, bfi(mx, jy, jx) + na, na + 1, bfi(mx, gy, gx), bfi(mx, idy, idx), tt, mx) - na;
         }
@@ -851,7 +871,7 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     }
     if (!started) return 0.0f;
     // stopped at a wall within range: the range; beyond 15 m, at the ring (entry 0x0100) or never stopped: no return
-    return select_mask(cmp_nlt_f32(tt, tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
+    return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
 }
 
 template <int A, int VARIANT>
@@ -885,7 +905,7 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 6   ? cast_ray_rects<false>(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy), nullptr)
+        float rng = VARIANT == 6   ? cast_ray_rects<false, false>(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy), nullptr)
                     : VARIANT == 5 ? cast_ray_cells(t.cell_dist, t, gx, gy, dx, dy)
                     : VARIANT == 4 ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
                     : VARIANT == 3 ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
@@ -916,6 +936,8 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
 // still in L1.  No persistent loop: 65 536 independent waves are balanced by the hardware dispatcher, where
 // equal shares of chunks per resident workgroup left the slowest workgroup's tail exposed.
 // `split` waves share a car (wave part k takes rounds k, k + split, ...): small batches still fill the chip.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 template <int A>
 __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int split) {
     const RcTrackDev &t = p.trk;
@@ -923,7 +945,14 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
     if (car >= (unsigned)p.n_cars) return;
     const unsigned lane = threadIdx.x & 63u;
-    const float ct = p.st.ct[car], st = p.st.st[car];
+    float ct = p.st.ct[car], st = p.st.st[car];
+    // One check per car instead of a clamp per ray (cast_ray_rects<.., CLEAN>): a heading whose (cos, sin) pair is
+    // not finite, not of magnitude <= 2 or not at least 0.5 in one component (a diverged car state; sincos32 never
+    // produces one from a finite angle) is replaced by heading 0 - the scan of such a car is unspecified, it only
+    // has to terminate.  With a legal pair and the beam table's entries all non-zero (checked at rc_load_track) at
+    // least one of the two products in dx = ct cb - st sb and in dy = st cb + ct sb is non-zero, so neither
+    // component can be -0.0, which the spec would step as +.
+    if (!(fabsf(ct) <= 2.0f && fabsf(st) <= 2.0f && (fabsf(ct) >= 0.5f || fabsf(st) >= 0.5f))) { ct = 1.0f; st = 0.0f; }
     const float lx = p.st.x[car] + RCS_LIDAR_X * ct;
     const float ly = p.st.y[car] + RCS_LIDAR_X * st;
     const float gx = (lx - t.org_x) * t.inv_res;
@@ -945,12 +974,15 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     for (int round = (int)part; round < kRounds; round += split) {
         const unsigned beam = lane + 64u * (unsigned)round;
         if (beam >= RC_N_BEAMS) break;                                    // last round: 56 of 64 lanes
-        const float cb = bm.x, sb = bm.y;
+        // (dx, dy) = (ct cb - st sb, ct sb + st cb): two packed products and ONE packed add that negates only its low
+        // lane's second operand (the compiler emits two packed adds for the scalar form); one rounding per operator
+        const v2f pa = v2f{bm.x, bm.y} * ct, pb = v2f{bm.y, bm.x} * st;
         boff += bstep;
         if (round + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);                  // next round's beams
-        const float dx = ct * cb - st * sb;
-        const float dy = st * cb + ct * sb;
-        float rng = cast_ray_rects<true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, v4);
+        v2f d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
+        const float dx = d.x, dy = d.y;
+        float rng = cast_ray_rects<true, true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, v4);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll

@@ -201,6 +201,53 @@ def test_default_raycast_dense_poses(track_name):
 
 
 @pytest.mark.parametrize("track_name", ["austria", "columbia", "gbr"])
+def test_rays_aimed_at_wall_corners(track_name):
+    """Rays aimed through the corners of wall cells: 16 384 poses per track whose heading is turned so that one beam
+    passes within ~1e-5 cell of the lattice corner nearest to where it first hit - the only situation in which the
+    cell chosen on the OTHER axis after a rectangle exit decides the result, i.e. the case the scan's exact-count
+    band exists for (cast_ray_rects).  tools/band_validation.sh shows that this test fails when the band is
+    shrunk below the rounding bound."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track(track_name)
+    rng = np.random.default_rng(23)
+    n = 16384
+    res = 0.05
+    cl = t.centerline[rng.integers(0, len(t.centerline), n)]
+    lx = cl[:, 0] + rng.uniform(-0.3, 0.3, n)
+    ly = cl[:, 1] + rng.uniform(-0.3, 0.3, n)
+    th0 = rng.uniform(-np.pi, np.pi, n)
+
+    def poses_for(th):
+        return np.stack([lx - 0.25 * np.cos(th), ly - 0.25 * np.sin(th), th], 1).astype(np.float32)
+
+    scan0 = _oracle_scan(t, poses_for(th0))
+    cb, sb = ro.beam_table()
+    k = rng.integers(0, 1080, n)
+    r = scan0[np.arange(n), k].astype(np.float64)
+    r = np.where((r > 0) & (r < 15), r, 3.0)
+    ang = th0 + np.arctan2(sb[k].astype(np.float64), cb[k].astype(np.float64))
+    hx, hy = lx + r * np.cos(ang), ly + r * np.sin(ang)
+    cx = t.origin[0] + np.round((hx - t.origin[0]) / res) * res          # nearest lattice corner to the hit point
+    cy = t.origin[1] + np.round((hy - t.origin[1]) / res) * res
+    th1 = th0 + (np.arctan2(cy - ly, cx - lx) - ang) + rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6], n)
+    th1 = (th1 + np.pi) % (2 * np.pi) - np.pi
+    poses = poses_for(th1)
+    want = _oracle_scan(t, poses)
+    env = BatchedRaceEnv(t, n, 1)
+    env.reset()
+    for variant in (7, 6, 2):
+        env.set_raycast_variant(variant)
+        got = env.set_pose(poses)["lidar"]
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().reshape(n, 1080)
+        bad = np.nonzero(got != want)
+        assert bad[0].size == 0, (track_name, variant, bad[0].size, bad[0][:5], bad[1][:5], got[bad][:5], want[bad][:5])
+    env.close()
+
+
+@pytest.mark.parametrize("track_name", ["austria", "columbia", "gbr"])
 def test_occupancy_patch_dense_poses(track_name):
     """The 64x64 lidar_occupancy render against the oracle from 4 096 arbitrary poses: anywhere on the grid and
     half a metre beyond it (crop window and grid clipping), exactly on cell corners, axis-aligned and diagonal

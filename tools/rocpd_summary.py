@@ -36,5 +36,24 @@ def pmc(dbs):
     return "\n".join(out)
 
 
+def gaps(db):
+    """Idle time on the device between consecutive kernels (end of one to start of the next), by successor."""
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, start, end from kernels order by start"))
+    acc = defaultdict(list)
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        acc[(n0.split("(")[0][-40:], n1.split("(")[0][-40:])].append(s1 - e0)
+    out = ["prev,next,count,mean_gap_ns,median_gap_ns"]
+    for k, v in sorted(acc.items(), key=lambda kv: -len(kv[1])):
+        v = sorted(v)
+        out.append(f'"{k[0]}","{k[1]}",{len(v)},{sum(v) / len(v):.0f},{v[len(v) // 2]}')
+    return "\n".join(out)
+
+
 if __name__ == "__main__":
-    print(stats(sys.argv[2]) if sys.argv[1] == "stats" else pmc(sys.argv[2:]))
+    if sys.argv[1] == "stats":
+        print(stats(sys.argv[2]))
+    elif sys.argv[1] == "gaps":
+        print(gaps(sys.argv[2]))
+    else:
+        print(pmc(sys.argv[2:]))
