@@ -620,6 +620,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
+    HIP_TRY(rck_set_footprint(foot.data()));
     env->has_track = true;
     set_launch_geometry(env);
     env->was_reset = false;

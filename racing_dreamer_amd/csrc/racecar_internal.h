@@ -76,6 +76,7 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
 hipError_t rck_set_lds_limits(size_t lds_bytes);
+hipError_t rck_set_footprint(const float *foot_host);   // 34 x 2 body-frame perimeter points -> constant memory
 hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s);
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);
 hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s);

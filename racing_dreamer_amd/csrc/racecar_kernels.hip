@@ -36,8 +36,10 @@ __device__ __forceinline__ void cell_of(const RcTrackDev &t, float wx, float wy,
 __device__ __forceinline__ float progress_at(const RcTrackDev &t, float wx, float wy) {
     int ix, iy;
     cell_of(t, wx, wy, ix, iy);
-    if ((unsigned)ix >= (unsigned)t.w || (unsigned)iy >= (unsigned)t.h) return -1.0f;
-    return t.progress[iy * t.w + ix];
+    // branch-free (an off-grid car reads cell (0, 0) and discards it), so the load is issued next to the footprint's
+    const bool inb = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+    const float pr = t.progress[inb ? iy * t.w + ix : 0];
+    return inb ? pr : -1.0f;
 }
 
 struct Car {
@@ -46,19 +48,29 @@ struct Car {
     int wall, opp, wrong, done, trunc, fresh;
 };
 
-// Footprint perimeter vs occupancy (H5).  Outside the grid counts as wall.
+// Body-frame perimeter points of the car (spec constants; set once per device by rck_set_footprint): in constant
+// memory, so the unrolled test below reads them through the scalar unit.
+__constant__ float c_footprint[2 * RCS_N_FOOTPRINT];
+
+// Footprint perimeter vs occupancy (H5).  Outside the grid counts as wall: such a point reads cell (0, 0), which
+// belongs to the sentinel ring and is always set.  Branch-free and fully unrolled, so the 34 bitmap words are
+// requested back to back and waited for once (the rolled, branchy form took 34 dependent round trips: 3/4 of the
+// kernel's 17 us at 65 536 envs).
 __device__ __forceinline__ int wall_hit(const RcTrackDev &t, const Car &c) {
-    int hit = 0;
+    uint32_t hit = 0;
+#pragma unroll
     for (int k = 0; k < RCS_N_FOOTPRINT; ++k) {
-        const float fx = t.footprint[2 * k], fy = t.footprint[2 * k + 1];
+        const float fx = c_footprint[2 * k], fy = c_footprint[2 * k + 1];
         const float wx = c.x + (fx * c.ct - fy * c.st);
         const float wy = c.y + (fx * c.st + fy * c.ct);
         int ix, iy;
         cell_of(t, wx, wy, ix, iy);
         const bool inb = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
-        hit |= inb ? bit_at(t.ray_words, t.pitch, ix, iy) : 1;
+        const int word = inb ? iy * t.pitch + (ix >> 5) : 0;
+        const int shift = inb ? (ix & 31) : 0;
+        hit |= t.ray_words[word] >> shift;
     }
-    return hit;
+    return (int)(hit & 1u);
 }
 
 // Oriented-rectangle overlap by separating axes (car-car collision, H5/H18).
@@ -1224,6 +1236,10 @@ __global__ __launch_bounds__(256) void rc_random_actions_kernel(float *__restric
 
 // ------------------------------------------------------------------------------------------------
 // launchers
+hipError_t rck_set_footprint(const float *foot_host) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(c_footprint), foot_host, sizeof(float) * 2 * RCS_N_FOOTPRINT);
+}
+
 hipError_t rck_set_lds_limits(size_t lds_bytes) {
     hipError_t e;
     const int b = (int)lds_bytes;
