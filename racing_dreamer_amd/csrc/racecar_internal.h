@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define RC_FIRST_BINS 16                       // half-octave bins of |dy / dx| over 2^-4 .. 2^4
+#define RC_FIRST_PLANES (4 * RC_FIRST_BINS)     // x 2 bytes = one 128-byte line per cell
+
 struct RcTrackDev {
     const uint32_t *ray_words;   // occupancy | sentinel ring, [h][pitch]
     const uint32_t *drv_words;   // drivable area, [h][pitch]
@@ -19,6 +22,7 @@ struct RcTrackDev {
                                  // rectangle with that cell at its corner, extending towards the quadrant:
                                  // width | height << 8 in cells (1..255 each), 0 = stop cell
     int32_t quad_plane_bytes;    // bytes per quadrant plane
+    const uint16_t *first_rect;  // [h][cell_pitch][RC_FIRST_PLANES]: first-trip rectangles by quadrant and slope bin (variant 7)
     const uint32_t *packed_blocks; // [blk_h][blk_w] for 4x4 blocks: bits 0-15 occupancy of the block's cells
                                  // (bit (iy&3)*4 + (ix&3), sentinel ring included), bits 16-23 the value above
     int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes, packed_w;   // packed_w: uint32 per packed row

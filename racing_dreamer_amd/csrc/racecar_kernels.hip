@@ -719,6 +719,11 @@ __device__ __forceinline__ unsigned mad_u24(unsigned a, unsigned b, unsigned c) 
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ unsigned med3_u32(unsigned a, unsigned lo, unsigned hi) {  // clamp(a, lo, hi) in one instruction
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(lo), "v"(hi));
+    return r;
+}
 template <int BYTE>
 __device__ __forceinline__ int byte_xor(unsigned word, int m) {              // ((word >> 8 BYTE) & 255) ^ m
     int r;
@@ -814,8 +819,19 @@ __device__ __forceinline__ float min_with(float a, float hi) {
 // at the stop.  Shifted index: j = i for a positive direction, i + 1 for a negative one - then the boundary is
 // j + offset for both signs and the shifted index of the cell behind that boundary is the boundary itself, so a
 // trip needs no sign arithmetic at all.
-// START4 = false: the entry of the start cell is loaded here (v4 unused).  START4 = true: the caller read the
-// start cell's four plane entries once for all rays of the car (v4[q], 0 if the sensor is off the grid).
+// The start cell's entry in the first-trip table for a ray of direction (dx, dy): quadrant from the signs, slope bin
+// from the float bits of |dy| * |1/dx| (see cast_ray_rects).  first_line = null: sensor off the grid, entry 0.
+__device__ __forceinline__ unsigned first_trip_entry(const char *first_line, float dx, float dy, float idx) {
+    if (first_line == nullptr) return 0u;
+    const unsigned sbits = __float_as_uint(fabsf(dy) * fabsf(idx)) >> 22;
+    const unsigned bin = med3_u32(sbits, 246u, 246u + RC_FIRST_BINS - 1);
+    const unsigned off = ((unsigned)sign_mask(dy) & (4u * RC_FIRST_BINS)) | ((unsigned)sign_mask(dx) & (2u * RC_FIRST_BINS));
+    return *reinterpret_cast<const uint16_t *>(first_line + ((bin << 1) + off));
+}
+
+// START = 0: the entry of the start cell is loaded here from the ray's quadrant plane.  START = 1: the caller read the
+// start cell's four plane entries once for all rays of the car (v4[q], 0 if the sensor is off the grid).  START = 2:
+// the start cell's entry comes from the first-trip table (RcTrackDev::first_rect; see below).
 // CLEAN = true: the caller guarantees finite direction components in [-2, 2] that are never -0.0 (the one-wave-per-
 // car kernel checks the car's heading once instead of clamping 1080 directions).
 //
@@ -827,9 +843,11 @@ __device__ __forceinline__ float min_with(float a, float hi) {
 // the product, the sum), another 1.8e-7 M.  band = M * 2^-21 = 4.8e-7 M covers their sum with 30 % to spare: 2.6e-4
 // cell on austria (548 cells wide), 1e-3 on a 2048-cell map.  (The band used to be a fixed 1e-3: a wave took the
 // exact path whenever one of its lanes was inside, 8.6 % of all trips on austria; now 2.3 %.)
-template <bool START4, bool CLEAN>
+template <int START, bool CLEAN>
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
-                                                float dx, float dy, int ix, int iy, const unsigned *v4) {
+                                                float dx, float dy, int ix, int iy, const unsigned *v4,
+                                                const char *first_line = nullptr, float pre_idx = 0.0f,
+                                                float pre_idy = 0.0f, unsigned pre_v = 0u) {
     if (!CLEAN) {
         // A non-finite direction (diverged car state) would make the cell arithmetic below meaningless and could
         // walk the table index anywhere; v_max / v_min (IEEE maxNum / minNum: a NaN operand yields the other one)
@@ -851,15 +869,24 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     const int P = t.quad_plane_bytes;
     unsigned qoffp = (unsigned)(3 * P) - (unsigned)(ny & (2 * P + pitch2)) - (unsigned)(nx & (P + 2));
     asm("" : "+v"(qoffp));                                                // one value: keep it out of the loop's address math
-    unsigned v = 0;
-    if (START4) {
+    float idx = pre_idx, idy = pre_idy;
+    if (START != 3) ray_reciprocals(dx, dy, idx, idy);
+    unsigned v = pre_v;
+    if (START == 3) {
+        // reciprocals and start entry prepared by the caller one round ahead (first_trip_entry)
+    } else if (START == 2) {
+        // first-trip table: the start cell's rectangle for this ray's quadrant and slope bin.  The bin comes from
+        // the float bits of |dy| * |1/dx| = (exponent << 1 | top mantissa bit) >> 22, clamped to the table's 16
+        // half-octaves from 2^-4 (biased exponent 123 -> 246); ANY bin of the right quadrant is a valid certificate,
+        // the slope only picks the one that reaches furthest.  first_line points 2 * 246 bytes before the cell's
+        // line (or is null when the sensor is off the grid: v = 0, the ray reads 0).
+        v = first_trip_entry(first_line, dx, dy, idx);
+    } else if (START == 1) {
         v = (unsigned)bfi(ny, bfi(nx, (int)v4[0], (int)v4[1]), bfi(nx, (int)v4[2], (int)v4[3]));
     } else if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
         v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, ((unsigned)jx << 1) + qoffp));
     }
     const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
-    float idx, idy;
-    ray_reciprocals(dx, dy, idx, idy);
     const float band2 = t.band2;
     float tt = 0.0f;
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
@@ -917,7 +944,7 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 6   ? cast_ray_rects<false, false>(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy), nullptr)
+        float rng = VARIANT == 6   ? cast_ray_rects<0, false>(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy), nullptr)
                     : VARIANT == 5 ? cast_ray_cells(t.cell_dist, t, gx, gy, dx, dy)
                     : VARIANT == 4 ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
                     : VARIANT == 3 ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
@@ -970,31 +997,45 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const float gx = (lx - t.org_x) * t.inv_res;
     const float gy = (ly - t.org_y) * t.inv_res;
     float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
-    // the start cell and its entry in each of the four quadrant planes: the same for all 1080 rays
+    // the start cell and its 128-byte line of the first-trip table: the same for all 1080 rays
     const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
-    unsigned v4[4] = {0u, 0u, 0u, 0u};
-    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
-        const char *cell = reinterpret_cast<const char *>(t.quad_rect) + ((size_t)iy * t.cell_pitch + ix) * 2;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v4[q] = *reinterpret_cast<const uint16_t *>(cell + (size_t)q * t.quad_plane_bytes);
-    }
+    const char *first_line = nullptr;
+    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
+        first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * 246;
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
     const unsigned bstep = 512u * (unsigned)split;
     unsigned boff = lane * 8u + 512u * part;
+    // Software pipeline over the rounds: while round r is traversed, round r + 1's direction, reciprocals and
+    // first-trip entry are already computed / in flight (and round r + 2's beam pair is being fetched), so no round
+    // starts by waiting for its start entry.
+    // (dx, dy) = (ct cb - st sb, ct sb + st cb): two packed products and ONE packed add that negates only its low
+    // lane's second operand (the compiler emits two packed adds for the scalar form); one rounding per operator
+    auto prepare = [&](float2 b, float &dx, float &dy, float &idx, float &idy, unsigned &v) {
+        const v2f pa = v2f{b.x, b.y} * ct, pb = v2f{b.y, b.x} * st;
+        v2f d;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
+        dx = d.x; dy = d.y;
+        ray_reciprocals(dx, dy, idx, idy);
+        v = first_trip_entry(first_line, dx, dy, idx);
+    };
     float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
+    float ndx, ndy, nidx, nidy;
+    unsigned nv;
+    prepare(bm, ndx, ndy, nidx, nidy, nv);
+    boff += bstep;
+    if ((int)part + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
     for (int round = (int)part; round < kRounds; round += split) {
         const unsigned beam = lane + 64u * (unsigned)round;
         if (beam >= RC_N_BEAMS) break;                                    // last round: 56 of 64 lanes
-        // (dx, dy) = (ct cb - st sb, ct sb + st cb): two packed products and ONE packed add that negates only its low
-        // lane's second operand (the compiler emits two packed adds for the scalar form); one rounding per operator
-        const v2f pa = v2f{bm.x, bm.y} * ct, pb = v2f{bm.y, bm.x} * st;
-        boff += bstep;
-        if (round + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);                  // next round's beams
-        v2f d;
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
-        const float dx = d.x, dy = d.y;
-        float rng = cast_ray_rects<true, true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, v4);
+        const float dx = ndx, dy = ndy, idx = nidx, idy = nidy;
+        const unsigned v0 = nv;
+        if (round + split < kRounds) {
+            prepare(bm, ndx, ndy, nidx, nidy, nv);                        // next round (the padded beams of the last round included)
+            boff += bstep;
+            if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
+        }
+        float rng = cast_ray_rects<3, true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, nullptr, nullptr, idx, idy, v0);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll
