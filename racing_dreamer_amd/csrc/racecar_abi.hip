@@ -10,7 +10,6 @@
 #include <cstring>
 #include <new>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../../include/racecar_hip.h"
@@ -571,74 +570,11 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
                 }
         }
     }
-    // First-trip table of the one-wave-per-car scan (variant 7): per cell 64 free rectangles = 4 quadrants x 16 bins of
-    // the ray's slope |dy / dx| (half-octave bins over 2^-4 .. 2^4, the outer bins open-ended), each the rectangle
-    // with the largest summed exit distance for two directions inside its bin.  All 1080 rays of a car start in
-    // the same cell, so a car reads ONE 128-byte line of this table (plane = (dy < 0) * 32 + (dx < 0) * 16 + bin,
-    // the bin taken from the float bits of |dy| * |1/dx|), and its rays leave the start cell through rectangles
-    // shaped for their own direction: 3.44 instead of 4.14 trips for the slowest ray of a wave on austria
-    // (tools/skip_stats12.py); rectangles specialised for the later trips too would gain nothing more
-    // (tools/skip_stats11.py).  128 B per cell (austria 33 MB, gbr 127 MB) - sized for HBM, not for the L2: every
-    // line is fetched once per car and step.  Same entry format as the quadrant planes.
+    // First-trip table of the one-wave-per-car scan (variant 7): RC_FIRST_PLANES rectangles per cell, one per
+    // quadrant and bin of the ray's slope |dy / dx| - built on the device by rc_build_first_kernel right after the
+    // upload (racecar_kernels.hip has the description); 256 B per cell: austria 65 MB, gbr 253 MB - sized for the
+    // 288 GB of HBM, not for the L2 (a car reads one line of it per step).
     const size_t first_bytes = align_up((size_t)cell_pitch * h * RC_FIRST_PLANES * 2, 64);
-    std::vector<uint16_t> firsts(first_bytes / 2, 0);
-    {
-        const int cap = 127;
-        float ka[RC_FIRST_BINS][2], kb[RC_FIRST_BINS][2];
-        for (int b = 0; b < RC_FIRST_BINS; ++b)
-            for (int k = 0; k < 2; ++k) {
-                const double l2 = -4.0 + 0.5 * (b + (k ? 0.75 : 0.25));       // log2 of the sample slope
-                const double ang = std::atan(std::exp2(l2));
-                ka[b][k] = (float)(1.0 / std::cos(ang));
-                kb[b][k] = (float)(1.0 / std::sin(ang));
-            }
-        std::vector<uint8_t> run((size_t)h * w);
-        for (int q = 0; q < 4; ++q) {
-            const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;     // plane group q = (dy < 0) * 2 + (dx < 0)
-            for (int iy = 0; iy < h; ++iy) {                            // free run length towards sx, capped
-                int r = 0;
-                for (int k = 0; k < w; ++k) {
-                    const int ix = sx > 0 ? w - 1 - k : k;
-                    r = dist[(size_t)iy * w + ix] ? std::min(r + 1, cap) : 0;
-                    run[(size_t)iy * w + ix] = (uint8_t)r;
-                }
-            }
-            auto rows = [&](int y0, int y1) {
-                for (int iy = y0; iy < y1; ++iy)
-                    for (int ix = 0; ix < w; ++ix) {
-                        uint16_t *e = firsts.data() + ((size_t)iy * cell_pitch + ix) * RC_FIRST_PLANES + q * RC_FIRST_BINS;
-                        if (ix == 0 || iy == 0 || ix == w - 1 || iy == h - 1) {
-                            for (int b = 0; b < RC_FIRST_BINS; ++b) e[b] = 0x0100;
-                            continue;
-                        }
-                        if (!dist[(size_t)iy * w + ix]) continue;
-                        int cur = cap, bw[RC_FIRST_BINS], bh[RC_FIRST_BINS];
-                        float best[RC_FIRST_BINS];
-                        for (int b = 0; b < RC_FIRST_BINS; ++b) { best[b] = -1.0f; bw[b] = bh[b] = 1; }
-                        for (int n = 1; n <= cap; ++n) {
-                            const int y = iy + (n - 1) * sy;
-                            if (y < 0 || y >= h) break;
-                            cur = std::min<int>(cur, run[(size_t)y * w + ix]);
-                            if (cur == 0) break;
-                            const float fw = (float)cur, fh = (float)n;
-                            bool open = false;             // can any bin still improve with a lower, narrower rectangle?
-                            for (int b = 0; b < RC_FIRST_BINS; ++b) {
-                                const float sc = std::min(fw * ka[b][0], fh * kb[b][0]) + std::min(fw * ka[b][1], fh * kb[b][1]);
-                                if (sc > best[b]) { best[b] = sc; bw[b] = cur; bh[b] = n; }
-                                open |= fw * (ka[b][0] + ka[b][1]) > best[b];
-                            }
-                            if (!open) break;
-                        }
-                        for (int b = 0; b < RC_FIRST_BINS; ++b)
-                            e[b] = (uint16_t)(((sx * bw[b]) & 0xff) | (((sy * bh[b]) & 0xff) << 8));
-                    }
-            };
-            const int n_thr = std::max(1, std::min<int>(16, (int)std::thread::hardware_concurrency()));
-            std::vector<std::thread> pool;
-            for (int k = 0; k < n_thr; ++k) pool.emplace_back(rows, (int)((long long)h * k / n_thr), (int)((long long)h * (k + 1) / n_thr));
-            for (std::thread &th : pool) th.join();
-        }
-    }
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
     const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
@@ -663,7 +599,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.cell_pitch = cell_pitch;
     HIP_TRY(hipMemcpy(m, quads.data(), 4 * quad_plane_bytes, hipMemcpyHostToDevice)); t.quad_rect = (const uint16_t *)m; m += 4 * quad_plane_bytes;
     t.quad_plane_bytes = (int32_t)quad_plane_bytes;
-    HIP_TRY(hipMemcpy(m, firsts.data(), first_bytes, hipMemcpyHostToDevice)); t.first_rect = (const uint16_t *)m; m += first_bytes;
+    t.first_rect = (const uint16_t *)m; m += first_bytes;      // filled below, on the device
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
@@ -691,6 +627,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
     HIP_TRY(rck_set_footprint(foot.data()));
+    HIP_TRY(rck_build_first_table(t, (uint16_t *)t.first_rect, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
     env->has_track = true;
     set_launch_geometry(env);
     env->was_reset = false;

@@ -4,8 +4,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define RC_FIRST_BINS 16                       // half-octave bins of |dy / dx| over 2^-4 .. 2^4
-#define RC_FIRST_PLANES (4 * RC_FIRST_BINS)     // x 2 bytes = one 128-byte line per cell
+#define RC_FIRST_BINS 32                       // bins of |dy / dx|: four per octave over 2^-4 .. 2^4 (outer bins open-ended)
+#define RC_FIRST_SHIFT 21                      // slope bits >> 21 = (exponent << 2) | two mantissa bits
+#define RC_FIRST_BIAS (123u << 2)              // ... of 2^-4
+#define RC_FIRST_PLANES (4 * RC_FIRST_BINS)     // x 2 bytes = 256 bytes per cell
 
 struct RcTrackDev {
     const uint32_t *ray_words;   // occupancy | sentinel ring, [h][pitch]
@@ -80,6 +82,7 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
 hipError_t rck_set_lds_limits(size_t lds_bytes);
+hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch
 hipError_t rck_set_footprint(const float *foot_host);   // 34 x 2 body-frame perimeter points -> constant memory
 hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s);
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);

@@ -819,12 +819,70 @@ __device__ __forceinline__ float min_with(float a, float hi) {
 // at the stop.  Shifted index: j = i for a positive direction, i + 1 for a negative one - then the boundary is
 // j + offset for both signs and the shifted index of the cell behind that boundary is the boundary itself, so a
 // trip needs no sign arithmetic at all.
-// The start cell's entry in the first-trip table for a ray of direction (dx, dy): quadrant from the signs, slope bin
-// from the float bits of |dy| * |1/dx| (see cast_ray_rects).  first_line = null: sensor off the grid, entry 0.
+// ---- First-trip table (RcTrackDev::first_rect) --------------------------------------------------------------
+// All 1080 rays of a car start in the same cell, so the FIRST rectangle of every ray can come from a much richer
+// table than the four quadrant planes without any cache cost: a car reads one 256-byte line per step.  Per cell
+// the line holds RC_FIRST_PLANES = 4 quadrants x RC_FIRST_BINS entries, the bin being the ray's slope |dy / dx|
+// in four steps per octave over 2^-4 .. 2^4 (the outer bins open-ended): exactly what the scan gets from the float
+// bits of |dy| * |1 / dx| (exponent and two mantissa bits) in two instructions.  An entry is a rectangle anchored at the cell like the plane entries, but
+// it only has to be free INSIDE THE SECTOR that rays of its bin can touch (start point anywhere in the cell, slope
+// anywhere in the bin, both widened by a margin far above the traversal's rounding) - its far corners may lie
+// inside walls.  The exit arithmetic is unchanged: a ray of that bin visits only sector cells before it leaves
+// the rectangle, and those are free.  A ray heading down a diagonal straight thus crosses it in one trip where
+// fully free rectangles need one per stair of the wall.  tools/skip_stats12.py / 13.py: 3.1 trips for the slowest
+// ray of a wave on austria against 4.1 with the quadrant planes alone; specialising the later trips as well
+// would need the big table in L2 and gain little more (tools/skip_stats11.py).
+//
+// Bin parameters (set by rck_build_first_table): slope range in the bin's own frame (bins >= RC_FIRST_BINS / 2 are
+// y-dominant and handled with the axes swapped, slope = |dx / dy|) and 1/cos, 1/sin of two sample directions.
+struct RcFirstBin { float s1, s2, ka0, kb0, ka1, kb1; };
+__constant__ RcFirstBin c_first_bins[RC_FIRST_BINS];
+
+// One thread per (cell, quadrant, bin).  Column c of the rectangle (offset along the bin's dominant axis) is touched
+// by rays of the bin in rows floor(s1 (c - 1) - 0.01) .. floor(1 + s2 (c + 1) + 0.01): the ray is inside column c
+// for travelled distances in (c - 1, c + 1) along the dominant axis and starts anywhere in [0, 1]^2.  The first
+// stop cell in that range caps the height of every rectangle that includes the column; among the rectangles
+// (c + 1) x cap(c) the one with the largest summed exit distance for the two sample directions is kept.
+__global__ __launch_bounds__(256) void rc_build_first_kernel(RcTrackDev t, uint16_t *__restrict__ out) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned total = (unsigned)t.h * (unsigned)t.w * RC_FIRST_PLANES;
+    if (gid >= total) return;
+    const int bin = (int)(gid % RC_FIRST_BINS), q = (int)((gid / RC_FIRST_BINS) & 3u);
+    const unsigned cell = gid / RC_FIRST_PLANES;
+    const int ix = (int)(cell % (unsigned)t.w), iy = (int)(cell / (unsigned)t.w);
+    uint16_t &e = out[((size_t)iy * t.cell_pitch + ix) * RC_FIRST_PLANES + q * RC_FIRST_BINS + bin];
+    if (ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1) { e = 0x0100; return; }     // sentinel ring: "no return"
+    if (bit_at(t.ray_words, t.pitch, ix, iy)) { e = 0; return; }                            // wall
+    const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane group q = (dy < 0) * 2 + (dx < 0)
+    const bool swap = bin >= RC_FIRST_BINS / 2;
+    const RcFirstBin b = c_first_bins[bin];
+    const int cap = 127;
+    int hmax = cap, bw = 1, bh = 1;
+    float best = -1.0f;
+    for (int c = 0; c < cap; ++c) {
+        const int lo = max(0, (int)floorf(b.s1 * (float)max(0, c - 1) - 0.01f));
+        const int hi = min(hmax - 1, (int)floorf(1.0f + b.s2 * (float)(c + 1) + 0.01f));
+        for (int r = lo; r <= hi; ++r) {
+            const int x = swap ? ix + sx * r : ix + sx * c, y = swap ? iy + sy * c : iy + sy * r;
+            const bool stop = (unsigned)x >= (unsigned)t.w || (unsigned)y >= (unsigned)t.h || bit_at(t.ray_words, t.pitch, x, y);
+            if (stop) { hmax = r; break; }
+        }
+        if (hmax <= 0) break;
+        const int pw = swap ? hmax : c + 1, ph = swap ? c + 1 : hmax;          // extents along x and y
+        const float sc = fminf((float)pw * b.ka0, (float)ph * b.kb0) + fminf((float)pw * b.ka1, (float)ph * b.kb1);
+        if (sc > best) { best = sc; bw = pw; bh = ph; }
+    }
+    e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
+}
+
+// The start cell's entry for a ray of direction (dx, dy): quadrant from the signs, slope bin from the float bits of
+// |dy| * |1/dx| (relative error 1.2e-7 against the bin edges the builder widened by 1e-6; 1/0 is stood in for by
+// 3e38, which lands in the steepest bin like every slope above 2^4).  first_line points RC_FIRST_BIAS entries
+// before the cell's line, or is null when the sensor is off the grid (entry 0: the ray reads 0).
 __device__ __forceinline__ unsigned first_trip_entry(const char *first_line, float dx, float dy, float idx) {
     if (first_line == nullptr) return 0u;
-    const unsigned sbits = __float_as_uint(fabsf(dy) * fabsf(idx)) >> 22;
-    const unsigned bin = med3_u32(sbits, 246u, 246u + RC_FIRST_BINS - 1);
+    const unsigned sbits = __float_as_uint(fabsf(dy) * fabsf(idx)) >> RC_FIRST_SHIFT;
+    const unsigned bin = med3_u32(sbits, RC_FIRST_BIAS, RC_FIRST_BIAS + RC_FIRST_BINS - 1);
     const unsigned off = ((unsigned)sign_mask(dy) & (4u * RC_FIRST_BINS)) | ((unsigned)sign_mask(dx) & (2u * RC_FIRST_BINS));
     return *reinterpret_cast<const uint16_t *>(first_line + ((bin << 1) + off));
 }
@@ -875,11 +933,6 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     if (START == 3) {
         // reciprocals and start entry prepared by the caller one round ahead (first_trip_entry)
     } else if (START == 2) {
-        // first-trip table: the start cell's rectangle for this ray's quadrant and slope bin.  The bin comes from
-        // the float bits of |dy| * |1/dx| = (exponent << 1 | top mantissa bit) >> 22, clamped to the table's 16
-        // half-octaves from 2^-4 (biased exponent 123 -> 246); ANY bin of the right quadrant is a valid certificate,
-        // the slope only picks the one that reaches furthest.  first_line points 2 * 246 bytes before the cell's
-        // line (or is null when the sensor is off the grid: v = 0, the ray reads 0).
         v = first_trip_entry(first_line, dx, dy, idx);
     } else if (START == 1) {
         v = (unsigned)bfi(ny, bfi(nx, (int)v4[0], (int)v4[1]), bfi(nx, (int)v4[2], (int)v4[3]));
@@ -1001,7 +1054,7 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
     const char *first_line = nullptr;
     if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
-        first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * 246;
+        first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * RC_FIRST_BIAS;
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
     const unsigned bstep = 512u * (unsigned)split;
@@ -1277,6 +1330,33 @@ __global__ __launch_bounds__(256) void rc_random_actions_kernel(float *__restric
 
 // ------------------------------------------------------------------------------------------------
 // launchers
+hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s) {
+    RcFirstBin bins[RC_FIRST_BINS];
+    // bin b = the float bits of the slope >> RC_FIRST_SHIFT, less RC_FIRST_BIAS: exponent -4 + b / 4 and the top two
+    // mantissa bits b % 4, i.e. the slopes [2^e (1 + m / 4), 2^e (1 + (m + 1) / 4)) - four LINEAR steps per octave
+    static_assert(RC_FIRST_BINS == 32 && RC_FIRST_SHIFT == 21, "bin edges below assume two mantissa bits over 2^-4 .. 2^4");
+    auto edge = [](int b) { return std::exp2(-4.0 + (double)(b / 4)) * (1.0 + 0.25 * (b % 4)); };
+    for (int b = 0; b < RC_FIRST_BINS; ++b) {
+        const double lo = edge(b), hi = edge(b + 1);                 // slope |dy / dx| of the bin
+        const bool swap = b >= RC_FIRST_BINS / 2;
+        // slope range in the bin's own frame, widened by 1e-6; the outermost bins are open-ended
+        const double e1 = swap ? 1.0 / hi : lo, e2 = swap ? 1.0 / lo : hi;
+        bins[b].s1 = (b == 0 || b == RC_FIRST_BINS - 1) ? 0.0f : (float)(e1 * (1.0 - 1e-6));
+        bins[b].s2 = (float)(e2 * (1.0 + 1e-6));
+        for (int k = 0; k < 2; ++k) {
+            const double ang = std::atan(lo + (hi - lo) * (k ? 0.75 : 0.25));
+            (k ? bins[b].ka1 : bins[b].ka0) = (float)(1.0 / std::cos(ang));
+            (k ? bins[b].kb1 : bins[b].kb0) = (float)(1.0 / std::sin(ang));
+        }
+    }
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_first_bins), bins, sizeof(bins));
+    if (e != hipSuccess) return e;
+    const long long total = (long long)t.h * t.w * RC_FIRST_PLANES;
+    if (total >= (1LL << 32)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rc_build_first_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t, first_rect_dev);
+    return hipGetLastError();
+}
+
 hipError_t rck_set_footprint(const float *foot_host) {
     return hipMemcpyToSymbol(HIP_SYMBOL(c_footprint), foot_host, sizeof(float) * 2 * RCS_N_FOOTPRINT);
 }

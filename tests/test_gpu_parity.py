@@ -247,6 +247,41 @@ def test_rays_aimed_at_wall_corners(track_name):
     env.close()
 
 
+@pytest.mark.parametrize("track_name", ["austria", "treitlstrasse_v2"])
+def test_rays_on_the_slope_bin_edges_of_the_first_trip_table(track_name):
+    """The default scan picks each ray's first rectangle by the bin of its slope |dy / dx| (four bins per octave from
+    the float bits), and that rectangle is only certified for slopes inside the bin: 12 288 poses per track turned
+    so that one beam's slope sits on a bin edge (2^e (1 + m / 4), both axes, all quadrants) give or take a few ulps
+    of the heading, from sensor positions all over the track."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track(track_name)
+    rng = np.random.default_rng(29)
+    n = 12288
+    cl = t.centerline[rng.integers(0, len(t.centerline), n)]
+    lx = cl[:, 0] + rng.uniform(-0.4, 0.4, n)
+    ly = cl[:, 1] + rng.uniform(-0.4, 0.4, n)
+    cb, sb = ro.beam_table()
+    k = rng.integers(0, 1080, n)
+    edges = np.array([2.0 ** e * (1 + m / 4) for e in range(-5, 5) for m in range(4)])
+    slope = rng.choice(edges, n)
+    ang = np.arctan2(slope * rng.choice([-1.0, 1.0], n), rng.choice([-1.0, 1.0], n))       # world angle of the aimed beam
+    th = ang - np.arctan2(sb[k].astype(np.float64), cb[k].astype(np.float64))
+    th = th + rng.choice([0.0, 6e-8, -6e-8, 1.2e-7, -1.2e-7, 2.4e-7, -2.4e-7, 1e-6, -1e-6], n)
+    th = (th + np.pi) % (2 * np.pi) - np.pi
+    poses = np.stack([lx - 0.25 * np.cos(th), ly - 0.25 * np.sin(th), th], 1).astype(np.float32)
+    want = _oracle_scan(t, poses)
+    env = BatchedRaceEnv(t, n, 1)
+    env.reset()
+    got = env.set_pose(poses)["lidar"]
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().reshape(n, 1080)
+    bad = np.nonzero(got != want)
+    assert bad[0].size == 0, (track_name, bad[0].size, bad[0][:5], bad[1][:5], got[bad][:5], want[bad][:5])
+    env.close()
+
+
 @pytest.mark.parametrize("track_name", ["austria", "columbia", "gbr"])
 def test_occupancy_patch_dense_poses(track_name):
     """The 64x64 lidar_occupancy render against the oracle from 4 096 arbitrary poses: anywhere on the grid and
