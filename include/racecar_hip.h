@@ -160,6 +160,11 @@ int rc_set_pose(rc_env *env, const float *xyyaw_host);
 
 /* Fill RC_F_ACTION_IN with U(-1,1)^2 from Philox4x32-10 keyed by (seed, step, global car id). */
 int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step);
+/* rc_fill_random_actions(seed, step) followed by rc_step(NULL, repeat) as ONE pass: the dynamics kernel draws the
+ * same actions itself (and leaves them in RC_F_ACTION_IN).  The step of a synthetic random-action rollout - the
+ * reference's default prefill policy is random actions too (dreamer/dream.py:207-210) - without a
+ * launch of its own for the action generator.  Results are identical to the two-call form. */
+int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat);
 
 /* Batched follow-the-gap agent on the device (the prefill / baseline agent of dreamer/dream.py:211-216, whose
  * host form is agents.gap_follower.GapFollower): from the current LiDAR scan of every car, clip to 3 m,

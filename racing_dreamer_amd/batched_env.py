@@ -198,6 +198,16 @@ class BatchedRaceEnv:
         self._exit()
         return self.views
 
+    def step_random(self, seed: int, step: int, repeat: Optional[int] = None) -> Dict[str, torch.Tensor]:
+        """``fill_random_actions(seed, step)`` + ``step(None, repeat)`` in one pass of the dynamics kernel (identical
+        results): the step of a synthetic random-action rollout (the reference's default prefill policy,
+        dreamer/dream.py:207-210)."""
+        repeat = self.action_repeat if repeat is None else int(repeat)
+        self._enter()
+        L.check(self._lib.rc_step_random(self._h, C.c_uint64(seed), C.c_uint32(step), repeat))
+        self._exit()
+        return self.views
+
     def set_pose(self, xyyaw) -> Dict[str, torch.Tensor]:
         """Teleport every car: float32 [num_envs, cars_per_env, 3] = x, y, yaw; recomputes the observation."""
         a = np.ascontiguousarray(np.asarray(xyyaw, np.float32).reshape(self.n_cars, 3))

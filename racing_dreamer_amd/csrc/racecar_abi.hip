@@ -135,13 +135,12 @@ struct KernelTimer {
             HIP_TRY(hipEventCreate(&ep.b));
         }
         ep.kernel = kernel;
-        HIP_TRY(hipEventRecord(ep.a, e->stream));
+        rck_set_launch_events(ep.a, ep.b);      // the launch that follows carries the two timestamps itself
         on = true;
         return RC_OK;
     }
     int end() {
         if (!on) return RC_OK;
-        HIP_TRY(hipEventRecord(ep.b, env->stream));
         env->pending.push_back(ep);
         return RC_OK;
     }
@@ -661,8 +660,20 @@ int rc_step(rc_env *env, const float *actions_dev, int32_t repeat) {
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_step");
     if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
     if (repeat < 1) return fail(RC_ERR_INVALID, "repeat must be >= 1 (got %d)", repeat);
-    const float *act = actions_dev ? actions_dev : env->actions_in;
-    TIMED(env, RC_K_DYNAMICS, rck_launch_dynamics(env->params, act, repeat, env->stream));
+    // the kernel only reads the caller's buffer (its actions pointer is written in random-action mode alone)
+    float *act = actions_dev ? const_cast<float *>(actions_dev) : env->actions_in;
+    const RcRandomActions none{0, 0u, 0u, 0u};
+    TIMED(env, RC_K_DYNAMICS, rck_launch_dynamics(env->params, act, repeat, none, env->stream));
+    return observe(env);
+}
+
+int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_step_random");
+    if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+    if (repeat < 1) return fail(RC_ERR_INVALID, "repeat must be >= 1 (got %d)", repeat);
+    const RcRandomActions ra{1, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step};
+    TIMED(env, RC_K_DYNAMICS, rck_launch_dynamics(env->params, env->actions_in, repeat, ra, env->stream));
     return observe(env);
 }
 

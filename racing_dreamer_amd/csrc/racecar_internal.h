@@ -81,10 +81,12 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
 };
 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
+void rck_set_launch_events(hipEvent_t start, hipEvent_t stop);   // attach start / stop timestamps to the NEXT launch of this thread
 hipError_t rck_set_lds_limits(size_t lds_bytes);
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch
 hipError_t rck_set_footprint(const float *foot_host);   // 34 x 2 body-frame perimeter points -> constant memory
-hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s);
+struct RcRandomActions { int32_t on; uint32_t seed_lo, seed_hi, step; };   // on != 0: draw the actions in the dynamics kernel
+hipError_t rck_launch_dynamics(const RcParams &p, float *actions, int repeat, const RcRandomActions &ra, hipStream_t s);
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);
 hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s);
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);

@@ -11,6 +11,7 @@
 // Numerics: fp32, one IEEE operation per written operator (-ffp-contract=off), same order as
 // oracle/racecar_oracle.py, so results are bit-identical to the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <math.h>
 
 #include "racecar_device.h"
@@ -186,7 +187,11 @@ __device__ __forceinline__ void store_step_results(const RcParams &p, int e, con
 
 // ------------------------------------------------------------------------------------------------
 template <int A>
-__global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, const float *__restrict__ actions, int repeat) {
+// rand_on != 0: the actions are not read but drawn here, U(-1, 1)^2 from Philox keyed by (seed, step, global car id) -
+// the same numbers rc_random_actions_kernel writes (synthetic random-action rollouts without a launch of their own);
+// they are stored to `actions` as well, so the buffer shows what was applied.
+__global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__restrict__ actions, int repeat,
+                                                          int rand_on, uint32_t rand_lo, uint32_t rand_hi, uint32_t rand_step) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.num_envs) return;
     const RcTrackDev &t = p.trk;
@@ -198,7 +203,17 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, const floa
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         const int i = e * A + a;
-        const float a0 = actions[2 * i], a1 = actions[2 * i + 1];
+        float a0, a1;
+        if (rand_on) {
+            const rcd::u32x4 r = rcd::philox4x32(p.first_env * (uint32_t)A + (uint32_t)i, rand_step, 1u, 0u, rand_lo, rand_hi);
+            a0 = (float)(r.x >> 8) * 5.9604644775390625e-8f * 2.0f - 1.0f;      // as rc_random_actions_kernel
+            a1 = (float)(r.y >> 8) * 5.9604644775390625e-8f * 2.0f - 1.0f;
+            actions[2 * i] = a0;
+            actions[2 * i + 1] = a1;
+        } else {
+            a0 = actions[2 * i];
+            a1 = actions[2 * i + 1];
+        }
         p.out.action[2 * i] = a0;
         p.out.action[2 * i + 1] = a1;
         float m = a0, s = a1;
@@ -1330,6 +1345,22 @@ __global__ __launch_bounds__(256) void rc_random_actions_kernel(float *__restric
 
 // ------------------------------------------------------------------------------------------------
 // launchers
+// Kernel timing without extra packets on the queue: the events handed to rck_set_launch_events are attached to the
+// NEXT launch itself (hipExtLaunchKernelGGL: start / stop timestamps of the dispatch, what rocprofv3 reports), where a
+// hipEventRecord before and after costs two barrier packets, ~3 us of device time per timed kernel.
+namespace {
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
+template <typename K, typename... Args>
+inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
+    const hipEvent_t a = g_ev_start, b = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, a, b, 0u, args...);
+}
+}  // namespace
+
+void rck_set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s) {
     RcFirstBin bins[RC_FIRST_BINS];
     // bin b = the float bits of the slope >> RC_FIRST_SHIFT, less RC_FIRST_BIAS: exponent -4 + b / 4 and the top two
@@ -1406,15 +1437,15 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
         default: { constexpr int kA = 4; __VA_ARGS__; } break; \
     }
 
-hipError_t rck_launch_dynamics(const RcParams &p, const float *actions, int repeat, hipStream_t s) {
+hipError_t rck_launch_dynamics(const RcParams &p, float *actions, int repeat, const RcRandomActions &ra, hipStream_t s) {
     const int threads = 256, blocks = (p.num_envs + threads - 1) / threads;
-    DISPATCH_A(p.cars_per_env, rc_dynamics_kernel<kA><<<dim3(blocks), dim3(threads), 0, s>>>(p, actions, repeat));
+    DISPATCH_A(p.cars_per_env, launch((rc_dynamics_kernel<kA>), dim3(blocks), dim3(threads), 0, s, p, actions, repeat, ra.on, ra.seed_lo, ra.seed_hi, ra.step));
     return hipGetLastError();
 }
 
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s) {
     const int threads = 256, blocks = (p.num_envs + threads - 1) / threads;
-    DISPATCH_A(p.cars_per_env, rc_reset_kernel<kA><<<dim3(blocks), dim3(threads), 0, s>>>(p, mask_dev));
+    DISPATCH_A(p.cars_per_env, launch((rc_reset_kernel<kA>), dim3(blocks), dim3(threads), 0, s, p, mask_dev));
     return hipGetLastError();
 }
 
@@ -1423,40 +1454,40 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
     if (li.raycast_variant == 7) {
         const int threads = li.car_threads, per = threads / 64;                     // waves per workgroup
         const long long waves = (long long)p.n_cars * li.car_split;
-        DISPATCH_A(p.cars_per_env, rc_raycast_car_kernel<kA><<<dim3((unsigned)((waves + per - 1) / per)), dim3(threads), 0, s>>>(p, li.car_split));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), 0, s, p, li.car_split));
     } else if (li.raycast_variant == 6) {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 6><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 6>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
     } else if (li.raycast_variant == 5) {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 5><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 5>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
     } else if (li.raycast_variant == 4) {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 4><<<dim3(li.ray_blocks), dim3(li.ray_threads), 0, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 4>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
     } else if (li.raycast_variant == 3) {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 3><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_packed, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 3>), dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_packed, s, p, total));
     } else if (li.raycast_variant == 2) {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 2><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 2>), dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s, p, total));
     } else if (li.raycast_variant == 1) {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 1><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 1>), dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes_skip, s, p, total));
     } else {
-        DISPATCH_A(p.cars_per_env, rc_raycast_kernel<kA, 0><<<dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes, s>>>(p, total));
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 0>), dim3(li.ray_blocks), dim3(li.ray_threads), li.lds_bytes, s, p, total));
     }
     return hipGetLastError();
 }
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_PATCH * (RC_PATCH / 16);
-    hipLaunchKernelGGL(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
+    launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
     return hipGetLastError();
 }
 
 hipError_t rck_launch_ftg(const RcParams &p, float *actions, float motor_straight, float motor_corner, hipStream_t s) {
     const int threads = 256, blocks = (p.n_cars + 3) / 4;
-    rc_ftg_kernel<<<dim3(blocks), dim3(threads), 0, s>>>(p, actions, motor_straight, motor_corner);
+    launch(rc_ftg_kernel, dim3(blocks), dim3(threads), 0, s, p, actions, motor_straight, motor_corner);
     return hipGetLastError();
 }
 
 hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s) {
     const int threads = 256, blocks = (p.n_cars + threads - 1) / threads;
-    rc_set_pose_kernel<<<dim3(blocks), dim3(threads), 0, s>>>(p, xyyaw_dev);
+    launch(rc_set_pose_kernel, dim3(blocks), dim3(threads), 0, s, p, xyyaw_dev);
     return hipGetLastError();
 }
 
@@ -1468,6 +1499,6 @@ hipError_t rck_launch_selftest_rcp(uint32_t exp_lo, uint32_t exp_hi, unsigned lo
 hipError_t rck_launch_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t seed_lo,
                                      uint32_t seed_hi, uint32_t step, hipStream_t s) {
     const int threads = 256, blocks = (n_cars + threads - 1) / threads;
-    hipLaunchKernelGGL(rc_random_actions_kernel, dim3(blocks), dim3(threads), 0, s, actions, n_cars, first_car, seed_lo, seed_hi, step);
+    launch(rc_random_actions_kernel, dim3(blocks), dim3(threads), 0, s, actions, n_cars, first_car, seed_lo, seed_hi, step);
     return hipGetLastError();
 }

@@ -133,3 +133,25 @@ def test_plain_c_client_builds_and_runs(tmp_path):
     out = subprocess.run([str(exe), "512", "120"], check=True, capture_output=True, text=True, timeout=120).stdout
     assert 'step before reset: "Must reset environment."' in out
     assert out.strip().endswith("OK"), out
+
+
+def test_step_random_equals_fill_then_step():
+    """rc_step_random draws the actions inside the dynamics kernel: same actions, same results as the two-call form
+    (sharded handle: the Philox key is the GLOBAL car id)."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    for cars in (1, 2):
+        a = BatchedRaceEnv("columbia", 200, cars, obs_type="lidar_occupancy", auto_reset=True, first_env=1000)
+        b = BatchedRaceEnv("columbia", 200, cars, obs_type="lidar_occupancy", auto_reset=True, first_env=1000)
+        a.reset(mode="random", seed=5)
+        b.reset(mode="random", seed=5)
+        for k in range(12):
+            a.fill_random_actions(seed=(3 << 32) | 9, step=k)
+            va = a.step(None, repeat=2)
+            vb = b.step_random(seed=(3 << 32) | 9, step=k, repeat=2)
+            torch.cuda.synchronize()
+            for name in ("lidar", "lidar_occupancy", "pose", "velocity", "action", "reward", "done", "progress", "lap", "time"):
+                assert torch.equal(va[name], vb[name]), (cars, k, name)
+            assert torch.equal(a.views["action_in"], b.views["action_in"])
+        a.close()
+        b.close()
