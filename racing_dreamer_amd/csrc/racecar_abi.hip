@@ -538,7 +538,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
             log_ka_sum += std::log(ka[k]);
         }
         for (int q = 0; q < 4; ++q) {
-            const int sx = (q & 1) ? 1 : -1, sy = (q & 2) ? 1 : -1;
+            const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane q = (dy < 0) * 2 + (dx < 0)
             for (int iy = 0; iy < h; ++iy) {                      // free run length towards sx, capped
                 int r = 0;
                 for (int k = 0; k < w; ++k) {

@@ -20,7 +20,7 @@ struct RcTrackDev {
                                  // Chebyshev distance to the nearest occupied/ring cell (0 = block not free)
     const uint8_t *cell_dist;    // [h][cell_pitch]: per cell, chessboard distance to the nearest stop cell (0 = stop, capped 255)
     int32_t cell_pitch;
-    const uint16_t *quad_rect;   // [4][h][cell_pitch]: per direction quadrant q = (dy >= 0) * 2 + (dx >= 0) and cell, a free
+    const uint16_t *quad_rect;   // [4][h][cell_pitch]: per direction quadrant q = (dy < 0) * 2 + (dx < 0) and cell, a free
                                  // rectangle with that cell at its corner, extending towards the quadrant:
                                  // width | height << 8 in cells (1..255 each), 0 = stop cell
     int32_t quad_plane_bytes;    // bytes per quadrant plane

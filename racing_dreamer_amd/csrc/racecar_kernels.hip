@@ -894,20 +894,17 @@ __global__ __launch_bounds__(256) void rc_build_first_kernel(RcTrackDev t, uint1
 // |dy| * |1/dx| (relative error 1.2e-7 against the bin edges the builder widened by 1e-6; 1/0 is stood in for by
 // 3e38, which lands in the steepest bin like every slope above 2^4).  first_line points RC_FIRST_BIAS entries
 // before the cell's line, or is null when the sensor is off the grid (entry 0: the ray reads 0).
-__device__ __forceinline__ unsigned first_trip_entry(const char *first_line, float dx, float dy, float idx) {
+__device__ __forceinline__ unsigned first_trip_entry(const char *first_line, float dy, float idx, int nx, int ny) {
     if (first_line == nullptr) return 0u;
-    const unsigned sbits = __float_as_uint(fabsf(dy) * fabsf(idx)) >> RC_FIRST_SHIFT;
-    const unsigned bin = med3_u32(sbits, RC_FIRST_BIAS, RC_FIRST_BIAS + RC_FIRST_BINS - 1);
-    const unsigned off = ((unsigned)sign_mask(dy) & (4u * RC_FIRST_BINS)) | ((unsigned)sign_mask(dx) & (2u * RC_FIRST_BINS));
-    return *reinterpret_cast<const uint16_t *>(first_line + ((bin << 1) + off));
+    float slope;
+    asm("v_mul_f32_e64 %0, |%1|, |%2|" : "=v"(slope) : "v"(dy), "v"(idx));
+    const unsigned bin = med3_u32(__float_as_uint(slope) >> RC_FIRST_SHIFT, RC_FIRST_BIAS, RC_FIRST_BIAS + RC_FIRST_BINS - 1);
+    unsigned off, addr;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(ny), "v"(4u * RC_FIRST_BINS), "v"((unsigned)nx & (2u * RC_FIRST_BINS)));
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(bin), "v"(off));
+    return *reinterpret_cast<const uint16_t *>(first_line + addr);
 }
 
-// START = 0: the entry of the start cell is loaded here from the ray's quadrant plane.  START = 1: the caller read the
-// start cell's four plane entries once for all rays of the car (v4[q], 0 if the sensor is off the grid).  START = 2:
-// the start cell's entry comes from the first-trip table (RcTrackDev::first_rect; see below).
-// CLEAN = true: the caller guarantees finite direction components in [-2, 2] that are never -0.0 (the one-wave-per-
-// car kernel checks the car's heading once instead of clamping 1080 directions).
-//
 // Other-axis cell after an exit: z = (origin + band) + tt * d, cell = floor(z), trusted unless fract(z) < 2 band,
 // i.e. unless the position lies within `band` of a cell boundary; then the spec's own comparisons decide
 // (exact_other_cell).  How wide the band must be: with M = the largest coordinate on the grid (cells), the spec
@@ -916,44 +913,20 @@ __device__ __forceinline__ unsigned first_trip_entry(const char *first_line, flo
 // the product, the sum), another 1.8e-7 M.  band = M * 2^-21 = 4.8e-7 M covers their sum with 30 % to spare: 2.6e-4
 // cell on austria (548 cells wide), 1e-3 on a 2048-cell map.  (The band used to be a fixed 1e-3: a wave took the
 // exact path whenever one of its lanes was inside, 8.6 % of all trips on austria; now 2.3 %.)
-template <int START, bool CLEAN>
-__device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
-                                                float dx, float dy, int ix, int iy, const unsigned *v4,
-                                                const char *first_line = nullptr, float pre_idx = 0.0f,
-                                                float pre_idy = 0.0f, unsigned pre_v = 0u) {
-    if (!CLEAN) {
-        // A non-finite direction (diverged car state) would make the cell arithmetic below meaningless and could
-        // walk the table index anywhere; v_max / v_min (IEEE maxNum / minNum: a NaN operand yields the other one)
-        // force it into [-2, 2].  Any legal component has magnitude <= 1.0000002, so legal rays are untouched; an
-        // illegal one becomes some finite ray that ends at the ring like every other.
-        dx = min_with(max_with(dx, -2.0f), 2.0f) + 0.0f;
-        dy = min_with(max_with(dy, -2.0f), 2.0f) + 0.0f;
-    }
-    // -1 for a negative direction, 0 otherwise.  The spec steps towards + iff d >= 0, which includes -0.0, hence
-    // the + 0.0f above (-0.0 + 0.0 = +0.0) in front of the sign extraction.
-    const int nx = sign_mask(dx), ny = sign_mask(dy);
+// The traversal proper: from start cell (ix, iy) with start entry v, direction (dx, dy) (finite, never -0.0), its
+// reciprocals and sign masks nx, ny (-1 for a negative component, 0 otherwise).
+__device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, float gx, float gy, float dx,
+                                              float dy, float idx, float idy, int nx, int ny, int ix, int iy, unsigned v) {
     const int pitch2 = t.cell_pitch * 2;
     const char *qb = reinterpret_cast<const char *>(qr);
     int jx = ix - nx, jy = iy - ny;                                       // shifted cell index
     // other-axis origin in shifted coordinates, moved up by the band (one rounding each)
     const float hx = bfi(nx, gx + t.band_p1, gx + t.band), hy = bfi(ny, gy + t.band_p1, gy + t.band);
-    // byte offset of shifted cell (0, 0) in this ray's plane q = 2 (dy >= 0) + (dx >= 0); true cell = shifted + n:
-    // q * P + ny * pitch2 + nx * 2 with q = 3 + 2 ny + nx
+    // byte offset of shifted cell (0, 0) in this ray's plane q = 2 (dy < 0) + (dx < 0); true cell = shifted + n:
+    // q P + ny pitch2 + nx 2 = ny (pitch2 - 2 P) + nx (2 - P), and n K = n & -K for n in {0, -1}
     const int P = t.quad_plane_bytes;
-    unsigned qoffp = (unsigned)(3 * P) - (unsigned)(ny & (2 * P + pitch2)) - (unsigned)(nx & (P + 2));
+    unsigned qoffp = ((unsigned)ny & (unsigned)(2 * P - pitch2)) + ((unsigned)nx & (unsigned)(P - 2));
     asm("" : "+v"(qoffp));                                                // one value: keep it out of the loop's address math
-    float idx = pre_idx, idy = pre_idy;
-    if (START != 3) ray_reciprocals(dx, dy, idx, idy);
-    unsigned v = pre_v;
-    if (START == 3) {
-        // reciprocals and start entry prepared by the caller one round ahead (first_trip_entry)
-    } else if (START == 2) {
-        v = first_trip_entry(first_line, dx, dy, idx);
-    } else if (START == 1) {
-        v = (unsigned)bfi(ny, bfi(nx, (int)v4[0], (int)v4[1]), bfi(nx, (int)v4[2], (int)v4[3]));
-    } else if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
-        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, ((unsigned)jx << 1) + qoffp));
-    }
     const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     const float band2 = t.band2;
     float tt = 0.0f;
@@ -979,6 +952,28 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     if (!started) return 0.0f;
     // stopped at a wall within range: the range; beyond 15 m, at the ring (entry 0x0100) or never stopped: no return
     return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
+}
+
+// One ray of the per-ray kernel (variant 6): direction made safe, start entry read from its quadrant plane.
+__device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
+                                                float dx, float dy, int ix, int iy) {
+    // A non-finite direction (diverged car state) would make the cell arithmetic meaningless and could walk the table
+    // index anywhere; v_max / v_min (IEEE maxNum / minNum: a NaN operand yields the other one) force it into
+    // [-2, 2].  Any legal component has magnitude <= 1.0000002, so legal rays are untouched; an illegal one becomes
+    // some finite ray that ends at the ring like every other.  The spec steps towards + iff d >= 0, which includes
+    // -0.0, hence the + 0.0f (-0.0 + 0.0 = +0.0) in front of the sign extraction.
+    dx = min_with(max_with(dx, -2.0f), 2.0f) + 0.0f;
+    dy = min_with(max_with(dy, -2.0f), 2.0f) + 0.0f;
+    const int nx = sign_mask(dx), ny = sign_mask(dy);
+    float idx, idy;
+    ray_reciprocals(dx, dy, idx, idy);
+    unsigned v = 0;
+    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
+        const int pitch2 = t.cell_pitch * 2, P = t.quad_plane_bytes;
+        const unsigned q = ((unsigned)ny & (unsigned)(2 * P)) + ((unsigned)nx & (unsigned)P);
+        v = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(qr) + (size_t)iy * pitch2 + ix * 2 + q);
+    }
+    return ray_traverse(qr, t, gx, gy, dx, dy, idx, idy, nx, ny, ix, iy, v);
 }
 
 template <int A, int VARIANT>
@@ -1012,7 +1007,7 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
         const float dy = st * cb + ct * sb;
         const float gx = (lx - t.org_x) * t.inv_res;
         const float gy = (ly - t.org_y) * t.inv_res;
-        float rng = VARIANT == 6   ? cast_ray_rects<0, false>(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy), nullptr)
+        float rng = VARIANT == 6   ? cast_ray_rects(t.quad_rect, t, gx, gy, dx, dy, (int)floorf(gx), (int)floorf(gy))
                     : VARIANT == 5 ? cast_ray_cells(t.cell_dist, t, gx, gy, dx, dy)
                     : VARIANT == 4 ? cast_ray_packed(t.packed_blocks, t, gx, gy, dx, dy)
                     : VARIANT == 3 ? cast_ray_packed(lds_words, t, gx, gy, dx, dy)
@@ -1053,7 +1048,7 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     if (car >= (unsigned)p.n_cars) return;
     const unsigned lane = threadIdx.x & 63u;
     float ct = p.st.ct[car], st = p.st.st[car];
-    // One check per car instead of a clamp per ray (cast_ray_rects<.., CLEAN>): a heading whose (cos, sin) pair is
+    // One check per car instead of a clamp per ray: a heading whose (cos, sin) pair is
     // not finite, not of magnitude <= 2 or not at least 0.5 in one component (a diverged car state; sincos32 never
     // produces one from a finite angle) is replaced by heading 0 - the scan of such a car is unspecified, it only
     // has to terminate.  With a legal pair and the beam table's entries all non-zero (checked at rc_load_track) at
@@ -1073,51 +1068,63 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
     const unsigned bstep = 512u * (unsigned)split;
-    unsigned boff = lane * 8u + 512u * part;
-    // Software pipeline over the rounds: while round r is traversed, round r + 1's direction, reciprocals and
-    // first-trip entry are already computed / in flight (and round r + 2's beam pair is being fetched), so no round
-    // starts by waiting for its start entry.
+    unsigned boff = lane * 8u + 512u * part;                             // byte offset of this lane's beam pair
+    unsigned obyte = lane * 4u + 256u * part;                            // ... and of its range in the car's output row
+    // Software pipeline over the rounds: while round r is traversed, round r + 1's direction, reciprocals, sign masks
+    // and first-trip entry are already computed / in flight (and round r + 2's beam pair is being fetched), so no
+    // round starts by waiting for its start entry.  Two register sets take turns (the loop body holds two rounds), so
+    // nothing is copied between them.
+    struct Ray { float dx, dy, idx, idy; int nx, ny; unsigned v; };
     // (dx, dy) = (ct cb - st sb, ct sb + st cb): two packed products and ONE packed add that negates only its low
     // lane's second operand (the compiler emits two packed adds for the scalar form); one rounding per operator
-    auto prepare = [&](float2 b, float &dx, float &dy, float &idx, float &idy, unsigned &v) {
+    auto prepare = [&](float2 b, Ray &r) {
         const v2f pa = v2f{b.x, b.y} * ct, pb = v2f{b.y, b.x} * st;
         v2f d;
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
-        dx = d.x; dy = d.y;
-        ray_reciprocals(dx, dy, idx, idy);
-        v = first_trip_entry(first_line, dx, dy, idx);
+        r.dx = d.x; r.dy = d.y;
+        ray_reciprocals(r.dx, r.dy, r.idx, r.idy);
+        r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
+        r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
     };
     float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
-    float ndx, ndy, nidx, nidy;
-    unsigned nv;
-    prepare(bm, ndx, ndy, nidx, nidy, nv);
-    boff += bstep;
-    if ((int)part + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
-    for (int round = (int)part; round < kRounds; round += split) {
-        const unsigned beam = lane + 64u * (unsigned)round;
-        if (beam >= RC_N_BEAMS) break;                                    // last round: 56 of 64 lanes
-        const float dx = ndx, dy = ndy, idx = nidx, idy = nidy;
-        const unsigned v0 = nv;
+    // one round: prepare `nxt` for round + split, traverse `cur`, store.  false: this lane has no beam in the round
+    auto stage = [&](int round, const Ray &cur, Ray &nxt) -> bool {
+        if (obyte >= 4u * RC_N_BEAMS) return false;                       // last round: 56 of 64 lanes
+        // `cur` was requested a whole round ago and has arrived: say so BEFORE the next round's loads go out, or the
+        // compiler, unable to count the conditional loads in flight, waits for all of them at the first use of cur.v
+        // (vmcnt(0), other counters untouched)
+        __builtin_amdgcn_s_waitcnt(0x0F70);
         if (round + split < kRounds) {
-            prepare(bm, ndx, ndy, nidx, nidy, nv);                        // next round (the padded beams of the last round included)
+            prepare(bm, nxt);                                             // (the padded beams of the last round included)
             boff += bstep;
             if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
         }
-        float rng = cast_ray_rects<3, true>(t.quad_rect, t, gx, gy, dx, dy, ix, iy, nullptr, nullptr, idx, idy, v0);
+        float rng = ray_traverse(t.quad_rect, t, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ix, iy, cur.v);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll
             for (unsigned o = 0; o < (unsigned)A; ++o) {
                 const unsigned oc = env * A + o;
                 if (oc != car) {
-                    const float tc = ray_vs_car(lx, ly, dx, dy, p.st.x[oc], p.st.y[oc], p.st.ct[oc], p.st.st[oc]);
+                    const float tc = ray_vs_car(lx, ly, cur.dx, cur.dy, p.st.x[oc], p.st.y[oc], p.st.ct[oc], p.st.st[oc]);
                     rng = tc < rng ? tc : rng;
                 }
             }
         }
         if (p.lidar_transform == 1) rng = rng / RCS_MAX_RANGE - 0.5f;                 // dreamer/tools.py:274
         else if (p.lidar_transform == 2) rng = rng * (1.0f / RCS_MAX_RANGE);          // single_agent.py:92-99
-        out[beam] = rng;
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(out) + obyte) = rng;
+        obyte += 256u * (unsigned)split;
+        return true;
+    };
+    Ray ra, rb;
+    prepare(bm, ra);
+    boff += bstep;
+    if ((int)part + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
+    for (int round = (int)part; round < kRounds; round += 2 * split) {
+        if (!stage(round, ra, rb)) break;
+        if (round + split >= kRounds) break;
+        if (!stage(round + split, rb, ra)) break;
     }
 }
 
