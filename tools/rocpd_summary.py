@@ -36,13 +36,19 @@ def pmc(dbs):
     return "\n".join(out)
 
 
+def _short(name):
+    """`rc_raycast_car_kernel<1>` from `void (anonymous namespace)::rc_raycast_car_kernel<1>(RcParams, int)`."""
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    return name.split("(")[0][-48:]
+
+
 def gaps(db):
     """Idle time on the device between consecutive kernels (end of one to start of the next), by successor."""
     c = sqlite3.connect(db)
     rows = list(c.execute("select name, start, end from kernels order by start"))
     acc = defaultdict(list)
     for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
-        acc[(n0.split("(")[0][-40:], n1.split("(")[0][-40:])].append(s1 - e0)
+        acc[(_short(n0), _short(n1))].append(s1 - e0)
     out = ["prev,next,count,mean_gap_ns,median_gap_ns"]
     for k, v in sorted(acc.items(), key=lambda kv: -len(kv[1])):
         v = sorted(v)
