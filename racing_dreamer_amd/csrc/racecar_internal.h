@@ -7,7 +7,7 @@
 #define RC_FIRST_BINS 32                       // bins of |dy / dx|: four per octave over 2^-4 .. 2^4 (outer bins open-ended)
 #define RC_FIRST_SHIFT 21                      // slope bits >> 21 = (exponent << 2) | two mantissa bits
 #define RC_FIRST_BIAS (123u << 2)              // ... of 2^-4
-#define RC_FIRST_PLANES (4 * RC_FIRST_BINS)     // x 2 bytes = 256 bytes per cell
+#define RC_FIRST_PLANES (4 * RC_FIRST_BINS)     // x 2 bytes = 256 bytes per cell (64 bins: 512 B per cell measured 2 % slower)
 
 struct RcTrackDev {
     const uint32_t *ray_words;   // occupancy | sentinel ring, [h][pitch]

@@ -1372,8 +1372,9 @@ hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, 
     RcFirstBin bins[RC_FIRST_BINS];
     // bin b = the float bits of the slope >> RC_FIRST_SHIFT, less RC_FIRST_BIAS: exponent -4 + b / 4 and the top two
     // mantissa bits b % 4, i.e. the slopes [2^e (1 + m / 4), 2^e (1 + (m + 1) / 4)) - four LINEAR steps per octave
-    static_assert(RC_FIRST_BINS == 32 && RC_FIRST_SHIFT == 21, "bin edges below assume two mantissa bits over 2^-4 .. 2^4");
-    auto edge = [](int b) { return std::exp2(-4.0 + (double)(b / 4)) * (1.0 + 0.25 * (b % 4)); };
+    constexpr int kPerOctave = RC_FIRST_BINS / 8, kMantBits = 23 - RC_FIRST_SHIFT;
+    static_assert((1 << kMantBits) == kPerOctave && RC_FIRST_BIAS == (123u << kMantBits), "bins = exponent and top mantissa bits over 2^-4 .. 2^4");
+    auto edge = [](int b) { return std::exp2(-4.0 + (double)(b / kPerOctave)) * (1.0 + (double)(b % kPerOctave) / kPerOctave); };
     for (int b = 0; b < RC_FIRST_BINS; ++b) {
         const double lo = edge(b), hi = edge(b + 1);                 // slope |dy / dx| of the bin
         const bool swap = b >= RC_FIRST_BINS / 2;
