@@ -1044,12 +1044,9 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned kCarLdsBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges
 
 template <int A>
-__global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int split) {
+__device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
+                                         const unsigned lane, char *lds_row) {
     const RcTrackDev &t = p.trk;
-    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
-    if (car >= (unsigned)p.n_cars) return;
-    const unsigned lane = threadIdx.x & 63u;
     float ct = p.st.ct[car], st = p.st.st[car];
     // One check per car instead of a clamp per ray: a heading whose (cos, sin) pair is
     // not finite, not of magnitude <= 2 or not at least 0.5 in one component (a diverged car state; sincos32 never
@@ -1063,8 +1060,6 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const float gx = (lx - t.org_x) * t.inv_res;
     const float gy = (ly - t.org_y) * t.inv_res;
     float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
-    extern __shared__ uint32_t lds_words[];                              // 17 x 64 floats per wave of the workgroup
-    char *lds_row = reinterpret_cast<char *>(lds_words) + (threadIdx.x >> 6) * (kCarLdsBytes);
     // the start cell and its 128-byte line of the first-trip table: the same for all 1080 rays
     const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
     const char *first_line = nullptr;
@@ -1149,6 +1144,20 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
         for (unsigned o = lane * 4u + 256u * part; o < 4u * RC_N_BEAMS; o += 256u * (unsigned)split)
             *reinterpret_cast<float *>(out_bytes + o) = *reinterpret_cast<const float *>(lds_row + o);
     }
+}
+
+template <int A>
+__global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int split) {
+    // One car (or 1 / split of one) per wave and nothing more: several cars in sequence per wave were measured slower
+    // (2 per wave + 6 %, 8 per wave + 20 %) - the hardware dispatcher balances 65 536 short waves better than any
+    // static share, and a finished wave's flush is not waited for by anybody.
+    extern __shared__ uint32_t lds_words[];                              // 17 x 64 floats per wave of the workgroup
+    char *lds_row = reinterpret_cast<char *>(lds_words) + (threadIdx.x >> 6) * (kCarLdsBytes);
+    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
+    if (car >= (unsigned)p.n_cars) return;
+    scan_car<A>(p, car, part, split, lane, lds_row);
 }
 
 // lidar_occupancy (H11, dreamer/wrappers.py:390-408): ego-aligned 64x64 patch of the drivable area,
