@@ -173,14 +173,17 @@ void set_launch_geometry(rc_env *env) {
         const char *e = getenv("RC_RAY_THREADS");
         const int threads = e ? atoi(e) : 0;
         li.car_threads = (threads == 64 || threads == 128 || threads == 256) ? threads : 64;
-        // one wave per car needs >= ~4 waves per wave slot (8 per SIMD x 4 SIMDs x CUs) to keep the chip busy and let
-        // the dispatcher balance; smaller batches split each car's 17 rounds over several waves
+        // one wave per car keeps the chip busy only with several waves per wave slot (8 per SIMD x 4 SIMDs x CUs) for the
+        // dispatcher to balance; smaller batches split each car's 17 rounds over `split` waves (round k of a car goes to
+        // wave k mod split).  Measured on columbia: 4 096 cars 0.0343 / 0.0313 / 0.0284 / 0.0308 / 0.0293 / 0.0344 ms
+        // for split 1 / 2 / 3 / 4 / 9 / 17; 16 384 cars 0.0737 / 0.0799 / 0.0750 / 0.0869 ms for 1 / 2 / 3 / 4 - about
+        // 48 waves per CU in total is the sweet spot (a wave's fixed cost, the car's state and first-trip line, is
+        // paid once per wave).
         e = getenv("RC_RAY_SPLIT");
         int split = e ? atoi(e) : 0;
         if (split < 1 || split > 17) {
-            // (17 rounds: 1, 2 and 4 waves get 17, 9/8 and 5/4/4/4 rounds; anything finer is best done as one round per wave)
-            const long long want = 4LL * 32 * li.n_cu, n = env->n_cars;
-            split = n >= want ? 1 : (2 * n >= want ? 2 : (4 * n >= want ? 4 : 17));
+            const long long want = 48LL * li.n_cu, n = env->n_cars;
+            split = (int)std::min<long long>(17, std::max<long long>(1, (want + n - 1) / n));
         }
         li.car_split = split;
     } else if (li.raycast_variant >= 4) {

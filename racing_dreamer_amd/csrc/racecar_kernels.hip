@@ -1208,7 +1208,10 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
         const unsigned q = base + threadIdx.x;
         if (q >= (unsigned)total_items) break;
-        const unsigned car = q >> 8;             // 64 rows * 4 quarter rows
+        // 64 rows * 4 quarter rows per car: a wave's 64 items belong to ONE car, so its state comes through the scalar
+        // unit (its own counter) - as vector loads they shared the in-order counter with the previous item's store and
+        // every item waited for that store's acknowledgement
+        const unsigned car = __builtin_amdgcn_readfirstlane(q >> 8);
         const unsigned row = (q >> 2) & 63u;
         const unsigned c0 = (q & 3u) * 16u;
         uint32_t words[4] = {0u, 0u, 0u, 0u};

@@ -43,11 +43,14 @@ def test_single_car_rollout_matches_oracle(track):
     assert n_done > 0          # the rollout exercised collisions + auto-reset
 
 
-@pytest.mark.parametrize("num_envs,cars", [(1, 1), (7, 3), (65, 1), (1000, 2), (3, 4)])
+@pytest.mark.parametrize("num_envs,cars", [(1, 1), (7, 3), (65, 1), (1000, 2), (3, 4), (960, 1), (2500, 1), (4096, 1), (7000, 1)])
 def test_odd_batch_shapes(num_envs, cars):
-    """Batch sizes that are not multiples of a wave / workgroup, down to one car: every launch geometry of the
-    default scan (1, 2, 4 or 17 waves per car) and the tails of the other kernels."""
-    _run_pair("columbia", num_envs=num_envs, cars=cars, steps=6, repeat=2, obs_type="lidar_occupancy")
+    """Batch sizes that are not multiples of a wave / workgroup, down to one car: the launch geometries of the
+    default scan (17, 13, 7, 5, 3 or 2 waves per car: rounds k, k + split, ... of a car per wave) and the tails of
+    the other kernels."""
+    big = num_envs * cars > 2000        # the larger shapes are about the scan's geometry only: keep the oracle's share small
+    _run_pair("columbia", num_envs=num_envs, cars=cars, steps=3 if big else 6, repeat=2,
+              obs_type="lidar" if big else "lidar_occupancy")
 
 
 def test_occupancy_patch_matches_oracle():
