@@ -8,7 +8,7 @@
 A "step" is one pass of the hot path over one batch: random actions (Philox, on device) ->
 integrator + collision + progress/reward/done + auto-reset -> 1080-beam LiDAR scan, for 65 536 envs
 per GPU (weak scaling), action_repeat 1, so one step = one simulator sub-step (dt = 0.01 s) of every
-env.  For N > 1 every step also feeds the overlapped RCCL all-gather of the trajectory slab.
+env.  For N > 1 every step's record also goes into the overlapped RCCL all-gather of the trajectory slab.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
@@ -46,6 +46,8 @@ def parse_args():
                          "the LiDAR row (pose, velocity, speed, action, reward, discount, progress, time: 76 B/car; "
                          "the scans stay sharded in each rank's HBM); full = the whole 4 396 B/car record (xGMI-bound: "
                          "DESIGN.md §6); none = no collective")
+    ap.add_argument("--gather-every", type=int, default=4,
+                    help="N>1: steps per all-gather (each collective carries that many per-step records; same bytes, fewer launches)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
@@ -99,7 +101,7 @@ def main():
     env.reset(mode="random", seed=0)
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     gather_src = {"none": None, "full": env.slab, "summary": env.summary_slab}[gather_mode]
-    gather = TrajectoryGather(gather_src) if gather_src is not None else None
+    gather = TrajectoryGather(gather_src, every=max(1, args.gather_every)) if gather_src is not None else None
 
     # the rollout loop works on the env's own stream (no cross-stream event waits between the step's kernels and
     # the staging copy of the gather); `barrier()` synchronises the whole device
@@ -199,8 +201,8 @@ def main():
                 "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
                 "obs_type": args.obs_type, "action_repeat": args.repeat,
                 "parallelism": f"env-sharded x{world}" + ("" if gather is None else
-                                f" + overlapped RCCL all-gather of the {gather_mode} trajectory record every step "
-                                f"({gather_src.numel()} B per GPU per step)"),
+                                f" + overlapped RCCL all-gather of the {gather_mode} trajectory record of every step, "
+                                f"one collective per {max(1, args.gather_every)} steps ({gather_src.numel()} B per GPU per step)"),
                 "gather": gather_mode,
             },
             "roofline": {

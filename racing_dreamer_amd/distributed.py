@@ -6,8 +6,8 @@ with no data-path collective: rank r owns envs [r * per_rank, (r + 1) * per_rank
 (results do not depend on the number of ranks).  The only exchange is the all-gather that
 concatenates every rank's trajectory slab (the per-step record `Collect.step` builds in the
 reference, dreamer/wrappers.py:213-219) - issued through ``torch.distributed`` (backend "nccl" is
-RCCL over xGMI on ROCm; "gloo" on CPU for the tests) on a staging copy so that it overlaps with
-the next step's kernels, which are VALU/LDS-bound and leave HBM and the links idle.
+RCCL over xGMI on ROCm; "gloo" on CPU for the tests) on staging copies, several steps per collective, so that it
+overlaps with the following steps' kernels, which are VALU-bound and leave HBM and the links idle.
 """
 from __future__ import annotations
 
@@ -40,39 +40,66 @@ def shard_envs(total_envs: int, rank: int, world_size: int) -> Shard:
 
 
 class TrajectoryGather:
-    """All-gather of equally sized per-rank slabs with one step of overlap.
+    """All-gather of equally sized per-rank slabs, overlapped with the steps that follow.
 
-    ``launch(slab)`` snapshots the slab into a staging buffer (so the producer may overwrite it) and
-    starts the collective asynchronously; ``wait()`` returns the gathered buffer
-    ``[world_size, slab_bytes]`` of the *previous* launch.
+    ``launch(slab)`` snapshots the slab into a staging buffer (so the producer may overwrite it); every ``every``-th
+    call starts ONE asynchronous collective over the ``every`` snapshots taken since the last one (same bytes on the
+    links, 1 / every of the launches: at 0.2 ms per step a collective per step is mostly fixed cost).  Two staging
+    buffers take turns, so a collective has ``every`` steps to finish before its buffer is written again.
+    ``wait()`` flushes a partial batch, waits, and returns the gathered buffer of the last collective:
+    ``[world_size, slab_bytes]`` for ``every == 1``, else ``[world_size, n_snapshots, slab_bytes]``.
     """
 
-    def __init__(self, slab_like: torch.Tensor, group: Optional[dist.ProcessGroup] = None):
+    def __init__(self, slab_like: torch.Tensor, group: Optional[dist.ProcessGroup] = None, every: int = 1):
+        if every < 1:
+            raise ValueError("every must be >= 1")
         self.group = group
+        self.every = int(every)
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         flat = slab_like.reshape(-1)
-        self.staging = torch.empty_like(flat)
-        self.gathered = torch.empty(self.world * flat.numel(), dtype=flat.dtype, device=flat.device)
+        self.slab_numel = flat.numel()
+        self.staging = [torch.empty(self.every * flat.numel(), dtype=flat.dtype, device=flat.device) for _ in range(2)]
+        self.gathered = torch.empty(self.world * self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
         self._work = None
+        self._cur = 0            # staging buffer being filled
+        self._k = 0              # snapshots in it
+        self._last_n = self.every
 
     def launch(self, slab: torch.Tensor) -> None:
-        self.wait()
-        self.staging.copy_(slab.reshape(-1), non_blocking=True)
-        if dist.get_backend(self.group) == "gloo" and self.staging.is_cuda:
+        n = self.slab_numel
+        self.staging[self._cur][self._k * n:(self._k + 1) * n].copy_(slab.reshape(-1), non_blocking=True)
+        self._k += 1
+        if self._k == self.every:
+            self._issue()
+
+    def _issue(self) -> None:
+        if self._work is not None:       # the previous collective (it read the OTHER staging buffer, wrote `gathered`)
+            self._work.wait()
+            self._work = None
+        n, k = self.slab_numel, self._k
+        src = self.staging[self._cur][:k * n]
+        dst = self.gathered[:self.world * k * n]
+        self._last_n = k
+        self._cur ^= 1
+        self._k = 0
+        if dist.get_backend(self.group) == "gloo" and src.is_cuda:
             # gloo has no device all-gather: stage through the host (functional tests only)
-            host = self.staging.cpu()
+            host = src.cpu()
             out = torch.empty(self.world * host.numel(), dtype=host.dtype)
             dist.all_gather_into_tensor(out, host, group=self.group)
-            self.gathered.copy_(out)
+            dst.copy_(out)
             return
-        self._work = dist.all_gather_into_tensor(self.gathered, self.staging, group=self.group, async_op=True)
+        self._work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
 
     def wait(self) -> torch.Tensor:
+        if self._k:
+            self._issue()                # a partial batch (every rank holds the same number of snapshots)
         if self._work is not None:
             self._work.wait()
             self._work = None
-        return self.gathered.view(self.world, -1)
+        g = self.gathered[:self.world * self._last_n * self.slab_numel]
+        return g.view(self.world, -1) if self.every == 1 else g.view(self.world, self._last_n, -1)
 
 
 def slab_field_views(slab_rank: torch.Tensor, n_cars: int, occupancy: bool) -> dict:

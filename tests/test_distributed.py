@@ -65,6 +65,22 @@ def _worker(rank, world, port, total_envs, q):
         gather.launch(slab)            # overlaps with the next step
         last = out
     g = gather.wait()
+    # batched form: one collective per 2 snapshots; 3 launches = a full batch and a flushed partial one
+    batched = TrajectoryGather(slab, every=2)
+    marks = []
+    for k in range(3):
+        snap = slab.clone()
+        snap[:8] = torch.arange(8, dtype=torch.uint8) + 16 * k + rank
+        marks.append(snap)
+        batched.launch(snap)
+        if k == 1:
+            gb = batched.wait()
+            assert gb.shape[:2] == (world, 2)
+            for r in range(world):
+                for j in range(2):
+                    assert int(gb[r, j, 0]) == 16 * j + r and (r != rank or torch.equal(gb[r, j, 8:], slab[8:]))
+    gb = batched.wait()
+    assert gb.shape[:2] == (world, 1) and all(int(gb[r, 0, 0]) == 32 + r for r in range(world))
     views = [slab_field_views(g[r], sh.num_envs, False) for r in range(world)]
     lidar = torch.cat([v["lidar"] for v in views]).numpy()
     reward = torch.cat([v["reward"] for v in views]).numpy()
