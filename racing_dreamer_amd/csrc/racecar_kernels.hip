@@ -791,6 +791,19 @@ __device__ __forceinline__ unsigned long long cmp_nlt_f32(float a, float b) {   
     asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
     return m;
 }
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned long long cmp_lt_f32(float a, float b) {             // lane mask of a < b
+    unsigned long long m;
+    asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint32_t select_mask_u(unsigned long long m, uint32_t a, uint32_t b) {   // m ? a : b
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
 __device__ __forceinline__ unsigned long long cmp_nlt_f32_s(float a, float b) {        // the same with a wave-uniform b
     unsigned long long m;
     asm("v_cmp_nlt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
@@ -936,18 +949,23 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
     for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) {
         const int xe = add_sbyte<0>(v, jx);                               // boundaries that leave the rectangle
         const int ye = add_sbyte<1>(v, jy);
-        const float txe = ((float)xe - gx) * idx;
-        const float tye = ((float)ye - gy) * idy;
-        const int mx = sign_mask(txe - tye);                              // -1: leaves through the x side
-        tt = fminf(txe, tye);
-        const float z = bfi(mx, hy, hx) + tt * bfi(mx, dy, dx);
+        const v2f te = (v2f{(float)xe, (float)ye} - v2f{gx, gy}) * v2f{idx, idy};    // packed: one subtract, one multiply
+        const float txe = te.x, tye = te.y;
+        // leaves through the x side iff txe < tye (ties: y).  The lane mask goes to an SGPR pair and every choice
+        // below is an e64 select on it; both candidate positions come from one packed multiply and one packed add
+        // (19 instructions per trip against 21 with a sign mask, min and four bit-field inserts)
+        const unsigned long long xm = cmp_lt_f32(txe, tye);
+        tt = select_mask(xm, txe, tye);
+        const v2f zz = v2f{dx, dy} * tt + v2f{hx, hy};
+        const float z = select_mask(xm, zz.y, zz.x);
         int on = floor_to_int(z);                                         // shifted cell on the other axis
         if (cmp_lt_f32_s(__builtin_amdgcn_fractf(z), band2)) {            // within `band` of a boundary: exact count
+            const int mx = (int)select_mask_u(xm, 0xffffffffu, 0u);
             const int na = bfi(mx, ny, nx);                               // true cell = shifted cell + na
             on = exact_other_cell(on + na, bfi(mx, jy, jx) + na, na + 1, bfi(mx, gy, gx), bfi(mx, idy, idx), tt, mx) - na;
         }
-        jx = bfi(mx, xe, on);
-        jy = bfi(mx, on, ye);
+        jx = (int)select_mask_u(xm, (uint32_t)xe, (uint32_t)on);
+        jy = (int)select_mask_u(xm, (uint32_t)on, (uint32_t)ye);
         v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, ((unsigned)jx << 1) + qoffp));
     }
     if (!started) return 0.0f;
@@ -1039,8 +1057,6 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
 // still in L1.  No persistent loop: 65 536 independent waves are balanced by the hardware dispatcher, where
 // equal shares of chunks per resident workgroup left the slowest workgroup's tail exposed.
 // `split` waves share a car (wave part k takes rounds k, k + split, ...): small batches still fill the chip.
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned kCarLdsBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges
 
 template <int A>
