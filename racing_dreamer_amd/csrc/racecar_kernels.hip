@@ -3,8 +3,13 @@
 //   rc_dynamics_kernel  one lane per env: action remap, bicycle integrator (H2), wall / car-car
 //                       collision (H5), progress + lap state machine, reward, done (H4, H15),
 //                       in-kernel action repeat (H9), time limit (H10), auto-reset (H6)
-//   rc_raycast_kernel   one lane per (car, beam): exact grid traversal against the track's
-//                       bit-packed occupancy staged in LDS (H3), inter-car returns (H18)
+//   rc_raycast_car_kernel  the LiDAR scan (H3), inter-car returns (H18): one wave per car, 17 rounds of 64 beams;
+//                       exact grid traversal that crosses certified-free rectangles in one trip - the first from
+//                       the per-cell first-trip table (by quadrant and slope bin), the later ones from the four
+//                       quadrant planes; ranges staged in LDS and flushed at the end of the wave
+//   rc_raycast_kernel   the earlier forms of the scan (variants 0-6: one lane per ray, bitmap / block table in
+//                       LDS or tables through L1/L2), kept for the parity tests that cross-check them
+//   rc_build_first_kernel  builds the first-trip table on the device at rc_load_track
 //   rc_patch_kernel     lidar_occupancy 64x64 ego patch (H11), drivable bitmap staged in LDS
 //   rc_reset_kernel     masked reset from the centerline spawn table with Philox4x32-10 (H6)
 //
