@@ -1,0 +1,39 @@
+"""Soak run (GPU box): long random-action rollouts on every track, every output finite, ranges within [0, 15], and a
+spot check of the last scan against the CPU oracle.  Also prints the time rc_load_track takes per track."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import torch
+from racing_dreamer_amd.batched_env import BatchedRaceEnv
+from racing_dreamer_amd.track_assets import load_track
+from oracle import racecar_oracle as ro, c_oracle
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+for name in ("austria", "columbia", "barcelona", "gbr", "treitlstrasse_v2"):
+    t = load_track(name)
+    t0 = time.perf_counter()
+    env = BatchedRaceEnv(t, 16384, 1, auto_reset=True)
+    env.sync()
+    t_load = time.perf_counter() - t0
+    env.reset(mode="random", seed=1)
+    torch.cuda.set_stream(env.stream)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        out = env.step_random(7, k, repeat=1 + (k % 4 == 0) * 3)
+    env.sync()
+    dt = time.perf_counter() - t0
+    lid = out["lidar"].reshape(-1, 1080)
+    ok = bool(torch.isfinite(lid).all()) and float(lid.min()) >= 0.0 and float(lid.max()) <= 15.0
+    pose = out["pose"].reshape(-1, 6).cpu().numpy()
+    n = 512
+    cfg = ro.OracleConfig(num_envs=n)
+    o = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=8)
+    o.reset()
+    o.arr["x"][:], o.arr["y"][:], o.arr["theta"][:] = pose[:n, 0], pose[:n, 1], pose[:n, 5]
+    o.arr["st"][:], o.arr["ct"][:] = ro.sincos32(pose[:n, 5].astype(np.float32))
+    o._observe()
+    same = np.array_equal(o.lidar, lid[:n].cpu().numpy())
+    print(f"{name:18s} load {t_load:5.2f} s  {steps} steps in {dt:5.2f} s  finite/in-range {ok}  last scan == oracle {same}", flush=True)
+    assert ok and same
+    env.close()
+print("soak ok")
