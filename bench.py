@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for functional tests on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ftg", dest="no_cpu_baseline_ftg", action="store_true", help="skip the follow-the-gap secondary figure")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--raycast-variant", type=int, default=None)
     return ap.parse_args()
@@ -166,6 +167,37 @@ def main():
     barrier()
     dt4 = time.perf_counter() - t1
 
+    # secondary figure: the long-ray case of SURVEY.md 8d - cars driven along the track by the follow-the-gap agent
+    # (the reference's other prefill policy, dreamer/dream.py:211-216) instead of crashing into walls with random
+    # actions: rank 0 only, single-GPU runs only (it is a property of the scan, not of the scaling)
+    ftg = None
+    if world == 1 and not args.no_cpu_baseline_ftg:
+        mean_range_random = float(env.views["lidar"].float().mean().item())
+        env.reset(mode="random", seed=0)
+        for k in range(150):                      # let the cars settle on the racing line
+            env.follow_the_gap()
+            env.step(None)
+        env.sync()
+        env.reset_kernel_times()
+        env.set_profiling(True, kernels=[L.K_RAYCAST])
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        n_ftg = max(args.steps // 4, 5)
+        for k in range(n_ftg):
+            env.follow_the_gap()
+            env.step(None)
+        env.sync()
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t2
+        env.set_profiling(False)
+        kt = env.kernel_times()
+        ftg = {"env_steps_per_s": args.envs * n_ftg * args.repeat / dtf, "steps": n_ftg,
+               "raycast_ms": round(kt["rc_raycast_kernel"]["avg_ms"], 4),
+               "mean_range_m": float(env.views["lidar"].float().mean().item()),
+               "mean_range_m_random_actions": mean_range_random,
+               "note": "same envs driven by the device follow-the-gap agent after 150 settling steps (cars on the racing "
+                       "line, long rays) instead of random actions; includes the agent's kernel"}
+
     if distributed:
         tmax = torch.tensor([dt, dt4], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -219,6 +251,8 @@ def main():
                                 "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
                                 "note": "same workload with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55)"},
         }
+        if ftg is not None:
+            out["follow_the_gap"] = ftg
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
         print(json.dumps(out), flush=True)
