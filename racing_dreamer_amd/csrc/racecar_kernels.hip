@@ -1303,17 +1303,26 @@ __global__ __launch_bounds__(256) void rc_ftg_kernel(RcParams p, float *__restri
     if (car >= p.n_cars) return;
     const float *scan = p.out.lidar + (size_t)car * RC_N_BEAMS;
     const int e0 = lane * FTG_PER_LANE;                              // first element (relative to FTG_LO)
-    float r[FTG_PER_LANE + 4];
+    // The arc goes through LDS: read from memory with consecutive lanes on consecutive beams (256-byte requests; a lane
+    // reading its own 17 beams directly makes every load touch 52 lines), clipped, then each lane takes its 13 beams
+    // plus a halo of 2 on each side (stride 13 dwords: conflict-free).  Slots -2, -1 and >= FTG_N are zero padding.
+    __shared__ float arc[4][FTG_PER_LANE * 64 + 8];
+    float *row = arc[threadIdx.x >> 6] + 2;
 #pragma unroll
-    for (int k = 0; k < FTG_PER_LANE + 4; ++k) {                     // own beams plus a halo of 2 on each side
-        const int e = e0 + k - 2;
-        float v = 0.0f;                                              // zero padding outside the arc
-        if (e >= 0 && e < FTG_N) {
+    for (int k = 0; k < FTG_PER_LANE; ++k) {
+        const int e = lane + 64 * k;
+        float v = 0.0f;
+        if (e < FTG_N) {
             v = scan[FTG_LO + e];
             v = v > 3.0f ? 3.0f : v;
         }
-        r[k] = v;
+        row[e] = v;
     }
+    if (lane < 2) { row[lane - 2] = 0.0f; row[FTG_PER_LANE * 64 + lane] = 0.0f; }
+    __builtin_amdgcn_wave_barrier();                                 // one wave per car: its own LDS writes, in order
+    float r[FTG_PER_LANE + 4];
+#pragma unroll
+    for (int k = 0; k < FTG_PER_LANE + 4; ++k) r[k] = row[e0 + k - 2];
     float sm[FTG_PER_LANE];
     float best_v = INFINITY;
     int best_i = 0x7fffffff;
