@@ -250,6 +250,62 @@ def test_rays_aimed_at_wall_corners(track_name):
     env.close()
 
 
+def test_wall_corners_on_a_2040_cell_wide_map():
+    """The exact-count band is sized from the map (max(w, h) * 2^-21 cells); its widest legal case is a map about
+    2 000 cells across, where coordinates carry the largest rounding (the library takes no map whose bitmap exceeds the
+    160 KB of LDS, so such a map is at most 600 rows high).  A synthetic 2040 x 600 ring (102 x 30 m) with square
+    pillars scattered over it; rays aimed through pillar and wall corners from up to 15 m away, all from the far half
+    of the grid.  Fails with the band at max(w, h) * 2^-27 (tools/band_validation.sh)."""
+    import dataclasses
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import pack_words, synthetic_track
+    t = synthetic_track(height=600, width=2040, wall=40, name="synthetic_large")
+    rng = np.random.default_rng(31)
+    occ = t.occ.copy()
+    free = ~occ
+    for _ in range(6000):                                   # pillars of 1 .. 6 cells in the free area
+        cy, cx, k = rng.integers(60, 540), rng.integers(60, 1980), rng.integers(1, 7)
+        if free[cy - 8:cy + k + 8, cx - 8:cx + k + 8].all():
+            occ[cy:cy + k, cx:cx + k] = True
+    t = dataclasses.replace(t, occ_words=pack_words(occ, t.pitch))
+    n, res = 8192, 0.05
+    fy, fx = np.nonzero(~occ)
+    far = fx > 1000                                         # large coordinates
+    pick = rng.choice(np.nonzero(far)[0], n)
+    lx = t.origin[0] + (fx[pick] + rng.uniform(0, 1, n)) * res
+    ly = t.origin[1] + (fy[pick] + rng.uniform(0, 1, n)) * res
+    th0 = rng.uniform(-np.pi, np.pi, n)
+
+    def poses_for(th):
+        return np.stack([lx - 0.25 * np.cos(th), ly - 0.25 * np.sin(th), th], 1).astype(np.float32)
+
+    scan0 = _oracle_scan(t, poses_for(th0))
+    cb, sb = ro.beam_table()
+    k = rng.integers(0, 1080, n)
+    r = scan0[np.arange(n), k].astype(np.float64)
+    r = np.where((r > 0) & (r < 15), r, 3.0)
+    ang = th0 + np.arctan2(sb[k].astype(np.float64), cb[k].astype(np.float64))
+    hx, hy = lx + r * np.cos(ang), ly + r * np.sin(ang)
+    cx = t.origin[0] + np.round((hx - t.origin[0]) / res) * res
+    cy = t.origin[1] + np.round((hy - t.origin[1]) / res) * res
+    th1 = th0 + (np.arctan2(cy - ly, cx - lx) - ang) + rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6], n)
+    th1 = (th1 + np.pi) % (2 * np.pi) - np.pi
+    poses = poses_for(th1)
+    want = _oracle_scan(t, poses)
+    env = BatchedRaceEnv(t, n, 1)
+    env.reset()
+    for variant in (7, 6):
+        env.set_raycast_variant(variant)
+        got = env.set_pose(poses)["lidar"]
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().reshape(n, 1080)
+        bad = np.nonzero(got != want)
+        assert bad[0].size == 0, (variant, bad[0].size, bad[0][:5], bad[1][:5], got[bad][:5], want[bad][:5])
+    assert ((want > 0) & (want < 15)).mean() > 0.5
+    env.close()
+
+
 @pytest.mark.parametrize("track_name", ["austria", "treitlstrasse_v2"])
 def test_rays_on_the_slope_bin_edges_of_the_first_trip_table(track_name):
     """The default scan picks each ray's first rectangle by the bin of its slope |dy / dx| (four bins per octave from
