@@ -434,8 +434,9 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     if (h < 3 || w < 3 || pitch * 32 < w) return fail(RC_ERR_INVALID, "bad track shape h=%d w=%d pitch=%d", h, w, pitch);
     if (n_centerline < 1) return fail(RC_ERR_INVALID, "centerline table is empty");
     if (!(resolution > 0.f)) return fail(RC_ERR_INVALID, "resolution must be > 0");
-    // the skipping traversals place a ray inside a free rectangle with fp32 arithmetic on cell coordinates and
-    // fall back to exact comparisons within 1e-3 cell of a boundary; that margin is sized for coordinates < 4096
+    // the skipping traversals place a ray inside a free rectangle with fp32 arithmetic on cell coordinates and fall
+    // back to exact comparisons within max(w, h) * 2^-21 cell of a boundary (RcTrackDev::band, derived in
+    // racecar_kernels.hip); 4096 keeps that zone below 2e-3 cell and every index within the 24-bit multiplies
     if (h > 4096 || w > 4096) return fail(RC_ERR_INVALID, "grids larger than 4096 cells per side are not supported (h=%d w=%d)", h, w);
     HIP_TRY(hipSetDevice(env->cfg.device));
     const size_t nwords = (size_t)h * pitch;

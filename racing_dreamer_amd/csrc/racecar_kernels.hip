@@ -601,7 +601,7 @@ __device__ __forceinline__ float cast_ray_fast(const uint32_t *bits, const uint8
         const float pe = og + tt * od;
         const float fl = floorf(pe);
         int on = (int)fl;
-        if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
+        if (fabsf((pe - fl) - 0.5f) > 0.5f - t.band) {                           // within the band of a boundary: exact count
             on = exact_other_cell(on, bfi(mx, iy, ix), bfi(mx, pyi, pxi), og, bfi(mx, idy, idx), tt, mx);
         }
         ix = bfi(mx, xe + nx, on);
@@ -661,7 +661,7 @@ __device__ __forceinline__ float cast_ray_packed(const uint32_t *pk, const RcTra
         const float pe = og + tt * od;
         const float fl = floorf(pe);
         int on = (int)fl;
-        if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
+        if (fabsf((pe - fl) - 0.5f) > 0.5f - t.band) {                           // within the band of a boundary: exact count
             on = exact_other_cell(on, bfi(mx, iy, ix), bfi(mx, pyi, pxi), og, bfi(mx, idy, idx), tt, mx);
         }
         ix = bfi(mx, xe + nx, on);
@@ -711,7 +711,7 @@ __device__ __forceinline__ float cast_ray_cells(const uint8_t *cd, const RcTrack
         const float pe = og + tt * od;
         const float fl = floorf(pe);
         int on = (int)fl;
-        if (fabsf((pe - fl) - 0.5f) > 0.499f) {                           // within 1e-3 of a boundary: exact count
+        if (fabsf((pe - fl) - 0.5f) > 0.5f - t.band) {                           // within the band of a boundary: exact count
             on = exact_other_cell(on, bfi(mx, iy, ix), bfi(mx, pyi, pxi), og, bfi(mx, idy, idx), tt, mx);
         }
         ix = bfi(mx, xe + nx, on);
