@@ -160,7 +160,7 @@ struct KernelTimer {
 void set_launch_geometry(rc_env *env) {
     RcLaunchInfo &li = env->launch;
     auto blocks_for = [&](size_t lds, long long items, int threads) {
-        int wg_per_cu = (int)((160 * 1024) / lds);
+        int wg_per_cu = lds ? (int)((160 * 1024) / lds) : 2;
         wg_per_cu = wg_per_cu > 2 ? 2 : (wg_per_cu < 1 ? 1 : wg_per_cu);
         return (int)std::min<long long>((items + threads - 1) / threads, (long long)li.n_cu * wg_per_cu);
     };
@@ -441,8 +441,11 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(hipSetDevice(env->cfg.device));
     const size_t nwords = (size_t)h * pitch;
     const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_kernel)
-    if (bm_bytes > 160 * 1024)
-        return fail(RC_ERR_INVALID, "track bitmap %zu B does not fit the 160 KiB LDS", bm_bytes);
+    // The lidar_occupancy render and the scan's early forms (variants 0-3) keep the whole bitmap in the 160 KiB LDS;
+    // the default scan does not, so a larger map is fine as long as the patch is not asked for.
+    const bool fits_lds = bm_bytes <= 160 * 1024;
+    if (!fits_lds && env->params.render_patch)
+        return fail(RC_ERR_INVALID, "track bitmap %zu B does not fit the 160 KiB LDS (needed for obs_type lidar_occupancy)", bm_bytes);
     // occupancy with the sentinel ring set
     std::vector<uint32_t> ray(bm_bytes / 4, 0u), drv(bm_bytes / 4, 0u);
     std::memcpy(ray.data(), occ_words, nwords * 4);
@@ -616,7 +619,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.band2 = 2.0f * t.band;
     // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
     RcLaunchInfo &li = env->launch;
-    li.lds_bytes = bm_bytes;
+    li.lds_bytes = fits_lds ? bm_bytes : 0;
     li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
     li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
     // default: per-cell, per-quadrant free rectangles read through L1/L2, one wave per car (variant 7).  Measured
@@ -798,6 +801,8 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (variant < 0 || variant > 7) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
+    if (variant == 0 && env->launch.lds_bytes == 0)
+        return fail(RC_ERR_INVALID, "variant 0 needs the bitmap in the 160 KiB LDS; this track is too large");
     if (variant == 3 && env->launch.lds_bytes_packed == 0)
         return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");
     if ((variant == 1 || variant == 2) && env->launch.lds_bytes_skip == 0)

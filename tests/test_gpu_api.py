@@ -155,3 +155,33 @@ def test_step_random_equals_fill_then_step():
             assert torch.equal(a.views["action_in"], b.views["action_in"])
         a.close()
         b.close()
+
+
+def test_map_larger_than_the_lds_runs_the_default_scan_only():
+    """A 2040 x 1400 map (364 KB of bitmap) cannot keep its bitmap in the 160 KB LDS: the lidar_occupancy render and the
+    scan's variants 0-3 refuse it, the default path (dynamics, default scan, reset) runs and matches the oracle."""
+    import numpy as np
+    import torch
+    from helpers import compare_outputs, make_oracle
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd import _lib as L, spec
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import synthetic_track
+    t = synthetic_track(height=1400, width=2040, wall=40, name="synthetic_huge")
+    with pytest.raises(L.RacecarHipError, match="does not fit"):
+        BatchedRaceEnv(t, 4, 1, obs_type="lidar_occupancy")
+    n = 64
+    env = BatchedRaceEnv(t, n, 1, auto_reset=True)
+    ora = make_oracle(t, num_envs=n, cars_per_env=1, auto_reset=True)
+    dv = env.reset(mode="random", seed=2)
+    ov = ora.reset(mode=spec.RESET_MODES["random"], seed=2)
+    compare_outputs(dv, ov, n, 1, "huge reset")
+    for v in (0, 1, 2, 3):
+        with pytest.raises(L.RacecarHipError, match="too large"):
+            env.set_raycast_variant(v)
+    for k in range(8):
+        act = ro.random_actions(3, k, n)
+        dv = env.step(torch.from_numpy(act).cuda(), repeat=4)
+        ov = ora.step(act, repeat=4)
+        compare_outputs(dv, ov, n, 1, f"huge step {k}")
+    env.close()
