@@ -214,11 +214,13 @@ def main():
         ray_symbol = f"rc_raycast_car_kernel<{args.cars}>" if variant == 7 else f"rc_raycast_kernel<{args.cars}, {variant}>"
         ray_s = ray["avg_ms"] * 1e-3
         achieved = RAYCAST_BYTES_PER_CAR * n_cars / ray_s / 1e9 if ray_s > 0 else 0.0
-        traffic = None
+        traffic = valu = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tp):
             with open(tp) as f:
-                traffic = json.load(f).get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
+                prof = json.load(f)
+            traffic = prof.get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
+            valu = prof.get("_valu_wave_insts", {}).get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
         out = {
             "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -243,6 +245,10 @@ def main():
                 "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
                 "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
                 "rays_per_s": n_cars * 1080 / ray_s if ray_s > 0 else 0.0,
+                # what actually bounds the scan: wave-level VALU instructions per launch from the PMC
+                # profile, and the rate they retire at per SIMD (1 024 SIMDs) at the duration measured here
+                "valu_wave_insts_per_launch": valu,
+                "valu_insts_per_simd_per_us": (valu / 1024 / (ray_s * 1e6)) if (valu and ray_s > 0) else None,
                 "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by VALU work "
                         "of the grid traversal, not by HBM (SURVEY.md §8d); see DESIGN.md §5",
             },
