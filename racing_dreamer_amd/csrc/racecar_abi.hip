@@ -522,60 +522,12 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     // rectangle with the current cell at its corner: it reaches as far as the walls AHEAD allow, where the
     // symmetric square of variant 5 is limited by the nearest wall in any direction (a wall-grazing ray crawls).
     // Among the free rectangles (width = min over its rows of the free run towards sx) the one with the largest
-    // expected exit distance for rays at 22.5 and 67.5 degrees inside the quadrant is kept.  The choice only
-    // affects speed: any free rectangle gives the same result (see cast_ray_skip).
+    // geometric mean of exit distance for rays at 11.25, 33.75, 56.25 and 78.75 degrees inside the quadrant is kept
+    // (tools/skip_stats9.py: 4 % fewer trips than the arithmetic mean at 22.5 / 67.5 degrees, far fewer than squares
+    // or maximal area).  The choice only affects speed: any free rectangle gives the same result (see cast_ray_skip).
+    // (built on the device by rc_build_quad_kernel after the upload, like the first-trip table: 0.67 -> 0.1 s of
+    // rc_load_track for austria, 2.7 -> 0.4 s for gbr)
     const size_t quad_plane_bytes = align_up((size_t)cell_pitch * h * 2, 64);
-    std::vector<uint16_t> quads(quad_plane_bytes / 2 * 4, 0);
-    {
-        // entry: byte 0 = +width (ray heading +x) or -width (-x) as int8, byte 1 the same for the height;
-        // wall = 0x0000, sentinel ring = 0x0100 (byte 0 == 0 stops the ray, entry != 0 then means "no return")
-        const int cap = 127;
-        std::vector<uint8_t> run((size_t)h * w);
-        float log_table[128];
-        log_table[0] = -1.0e30f;
-        for (int k = 1; k < 128; ++k) log_table[k] = std::log((float)k);
-        // score of a candidate rectangle: the geometric mean of the exit distances of rays at 11.25, 33.75, 56.25 and
-        // 78.75 degrees inside the quadrant (sum of logs; tools/skip_stats9.py: 4 % fewer trips than the arithmetic
-        // mean at 22.5 / 67.5 degrees, and far fewer than squares or maximal area)
-        float ka[4], kb[4], log_ka_sum = 0.0f;
-        for (int k = 0; k < 4; ++k) {
-            const double ang = (11.25 + 22.5 * k) * 3.14159265358979323846 / 180.0;
-            ka[k] = (float)(1.0 / std::cos(ang));
-            kb[k] = (float)(1.0 / std::sin(ang));
-            log_ka_sum += std::log(ka[k]);
-        }
-        for (int q = 0; q < 4; ++q) {
-            const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane q = (dy < 0) * 2 + (dx < 0)
-            for (int iy = 0; iy < h; ++iy) {                      // free run length towards sx, capped
-                int r = 0;
-                for (int k = 0; k < w; ++k) {
-                    const int ix = sx > 0 ? w - 1 - k : k;
-                    r = dist[(size_t)iy * w + ix] ? std::min(r + 1, cap) : 0;
-                    run[(size_t)iy * w + ix] = (uint8_t)r;
-                }
-            }
-            uint16_t *plane = quads.data() + (size_t)q * (quad_plane_bytes / 2);
-            for (int iy = 0; iy < h; ++iy)
-                for (int ix = 0; ix < w; ++ix) {
-                    uint16_t &e = plane[(size_t)iy * cell_pitch + ix];
-                    if (ix == 0 || iy == 0 || ix == w - 1 || iy == h - 1) { e = 0x0100; continue; }
-                    if (!dist[(size_t)iy * w + ix]) continue;
-                    int cur = cap, bw = 1, bh = 1;
-                    float best = -1.0e30f;
-                    for (int n = 1; n <= cap; ++n) {
-                        const int y = iy + (n - 1) * sy;
-                        if (y < 0 || y >= h) break;
-                        cur = std::min<int>(cur, run[(size_t)y * w + ix]);
-                        // the width only shrinks from here on and the score is at most sum log(width * ka)
-                        if (cur == 0 || 4.0f * log_table[cur] + log_ka_sum <= best) break;
-                        float sc = 0.0f;
-                        for (int k = 0; k < 4; ++k) sc += std::log(std::min((float)cur * ka[k], (float)n * kb[k]));
-                        if (sc > best) { best = sc; bw = cur; bh = n; }
-                    }
-                    e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
-                }
-        }
-    }
     // First-trip table of the one-wave-per-car scan (variant 7): RC_FIRST_PLANES rectangles per cell, one per
     // quadrant and bin of the ray's slope |dy / dx| - built on the device by rc_build_first_kernel right after the
     // upload (racecar_kernels.hip has the description); 256 B per cell: austria 65 MB, gbr 253 MB - sized for the
@@ -603,7 +555,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.packed_w = pk_w;
     HIP_TRY(hipMemcpy(m, cells.data(), cell_bytes, hipMemcpyHostToDevice)); t.cell_dist = (const uint8_t *)m; m += cell_bytes;
     t.cell_pitch = cell_pitch;
-    HIP_TRY(hipMemcpy(m, quads.data(), 4 * quad_plane_bytes, hipMemcpyHostToDevice)); t.quad_rect = (const uint16_t *)m; m += 4 * quad_plane_bytes;
+    t.quad_rect = (const uint16_t *)m; m += 4 * quad_plane_bytes;      // filled below, on the device
     t.quad_plane_bytes = (int32_t)quad_plane_bytes;
     t.first_rect = (const uint16_t *)m; m += first_bytes;      // filled below, on the device
     t.h = h; t.w = w; t.pitch = pitch; t.n_centerline = n_centerline;
@@ -633,6 +585,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
     HIP_TRY(rck_set_footprint(foot.data()));
+    HIP_TRY(rck_build_quad_planes(t, (uint16_t *)t.quad_rect, env->stream));
     HIP_TRY(rck_build_first_table(t, (uint16_t *)t.first_rect, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
     env->has_track = true;

@@ -83,6 +83,7 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
 void rck_set_launch_events(hipEvent_t start, hipEvent_t stop);   // attach start / stop timestamps to the NEXT launch of this thread
 hipError_t rck_set_lds_limits(size_t lds_bytes);
+hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch, quad_plane_bytes
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch
 hipError_t rck_set_footprint(const float *foot_host);   // 34 x 2 body-frame perimeter points -> constant memory
 struct RcRandomActions { int32_t on; uint32_t seed_lo, seed_hi, step; };   // on != 0: draw the actions in the dynamics kernel

@@ -909,6 +909,58 @@ __global__ __launch_bounds__(256) void rc_build_first_kernel(RcTrackDev t, uint1
     e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
 }
 
+// ---- Quadrant planes (RcTrackDev::quad_rect), built on the device --------------------------------------------------
+// Free run length from every cell towards -x and towards +x (capped at 127; 0 on a stop cell): one thread per row.
+__global__ __launch_bounds__(256) void rc_build_runs_kernel(RcTrackDev t, uint8_t *__restrict__ run_neg, uint8_t *__restrict__ run_pos) {
+    const int iy = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iy >= t.h) return;
+    int r = 0;
+    for (int ix = 0; ix < t.w; ++ix) {                          // towards -x: cells ix, ix - 1, ... are free
+        r = bit_at(t.ray_words, t.pitch, ix, iy) ? 0 : min(r + 1, 127);
+        run_neg[(size_t)iy * t.w + ix] = (uint8_t)r;
+    }
+    r = 0;
+    for (int ix = t.w - 1; ix >= 0; --ix) {
+        r = bit_at(t.ray_words, t.pitch, ix, iy) ? 0 : min(r + 1, 127);
+        run_pos[(size_t)iy * t.w + ix] = (uint8_t)r;
+    }
+}
+
+// One thread per (cell, quadrant): among the free rectangles anchored at the cell (width = min over its rows of the free
+// run towards sx) the one with the largest geometric mean of the exit distances of rays at 11.25, 33.75, 56.25 and
+// 78.75 degrees inside the quadrant.
+__global__ __launch_bounds__(256) void rc_build_quad_kernel(RcTrackDev t, const uint8_t *__restrict__ run_neg,
+                                                            const uint8_t *__restrict__ run_pos, uint16_t *__restrict__ out) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (unsigned)t.h * (unsigned)t.w * 4u) return;
+    const int q = (int)(gid & 3u);
+    const unsigned cell = gid >> 2;
+    const int ix = (int)(cell % (unsigned)t.w), iy = (int)(cell / (unsigned)t.w);
+    uint16_t &e = out[(size_t)q * (t.quad_plane_bytes / 2) + (size_t)iy * t.cell_pitch + ix];
+    if (ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1) { e = 0x0100; return; }       // sentinel ring: "no return"
+    if (bit_at(t.ray_words, t.pitch, ix, iy)) { e = 0; return; }                              // wall
+    const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane q = (dy < 0) * 2 + (dx < 0)
+    const uint8_t *run = sx > 0 ? run_pos : run_neg;
+    // 1 / cos and 1 / sin of the four sample directions
+    const float ka[4] = {1.0195911f, 1.2026898f, 1.7999525f, 5.1258309f};
+    const float kb[4] = {5.1258309f, 1.7999525f, 1.2026898f, 1.0195911f};
+    const float log_ka_sum = __logf(ka[0]) + __logf(ka[1]) + __logf(ka[2]) + __logf(ka[3]);
+    int cur = 127, bw = 1, bh = 1;
+    float best = -1.0e30f;
+    for (int n = 1; n <= 127; ++n) {
+        const int y = iy + (n - 1) * sy;
+        if (y < 0 || y >= t.h) break;
+        cur = min(cur, (int)run[(size_t)y * t.w + ix]);
+        // the width only shrinks from here on and the score is at most sum log(width * ka)
+        if (cur == 0 || 4.0f * __logf((float)cur) + log_ka_sum <= best) break;
+        float sc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sc += __logf(fminf((float)cur * ka[k], (float)n * kb[k]));
+        if (sc > best) { best = sc; bw = cur; bh = n; }
+    }
+    e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
+}
+
 // The start cell's entry for a ray of direction (dx, dy): quadrant from the signs, slope bin from the float bits of
 // |dy| * |1/dx| (relative error 1.2e-7 against the bin edges the builder widened by 1e-6; 1/0 is stood in for by
 // 3e38, which lands in the steepest bin like every slope above 2^4).  first_line points RC_FIRST_BIAS entries
@@ -1432,6 +1484,20 @@ inline void launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, A
 }  // namespace
 
 void rck_set_launch_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+
+hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, hipStream_t s) {
+    uint8_t *runs = nullptr;
+    const size_t plane = (size_t)t.h * t.w;
+    hipError_t e = hipMalloc((void **)&runs, 2 * plane);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(rc_build_runs_kernel, dim3((unsigned)((t.h + 255) / 256)), dim3(256), 0, s, t, runs, runs + plane);
+    const long long total = (long long)plane * 4;
+    hipLaunchKernelGGL(rc_build_quad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, t, runs, runs + plane, quad_rect_dev);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(runs);
+    return e;
+}
 
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s) {
     RcFirstBin bins[RC_FIRST_BINS];
