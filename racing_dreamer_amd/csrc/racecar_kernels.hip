@@ -9,7 +9,8 @@
 //                       quadrant planes; ranges staged in LDS and flushed at the end of the wave
 //   rc_raycast_kernel   the earlier forms of the scan (variants 0-6: one lane per ray, bitmap / block table in
 //                       LDS or tables through L1/L2), kept for the parity tests that cross-check them
-//   rc_build_first_kernel  builds the first-trip table on the device at rc_load_track
+//   rc_build_quad_kernel, rc_build_first_kernel  build the quadrant planes and the first-trip table on the device
+//                       at rc_load_track
 //   rc_patch_kernel     lidar_occupancy 64x64 ego patch (H11), drivable bitmap staged in LDS
 //   rc_reset_kernel     masked reset from the centerline spawn table with Philox4x32-10 (H6)
 //
