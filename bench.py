@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-ftg", dest="no_cpu_baseline_ftg", action="store_true", help="skip the follow-the-gap secondary figure")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--raycast-variant", type=int, default=None)
+    ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiment knob passed to rc_debug_set (ray_threads, ray_split, ray_wg_per_cu, band_log2)")
     return ap.parse_args()
 
 
@@ -99,6 +101,9 @@ def main():
     if args.raycast_variant is not None:
         from racing_dreamer_amd import _lib as L
         L.check(env._lib.rc_set_raycast_variant(env._h, args.raycast_variant))
+    for kv in args.debug_knob:
+        name, _, val = kv.partition("=")
+        env.debug_set(name, int(val))
     env.reset(mode="random", seed=0)
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     gather_src = {"none": None, "full": env.slab, "summary": env.summary_slab}[gather_mode]

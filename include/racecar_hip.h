@@ -26,7 +26,9 @@
  *   - every function returns RC_OK (0) or a negative rc_status; the message of the last
  *     failure on the calling thread is rc_last_error().  No exception crosses the ABI.
  *   - one rc_env = one GPU + one HIP stream.  Calls on one handle must be serialised by the
- *     caller (the reference callers are single threaded); different handles are independent.
+ *     caller (the reference callers are single threaded); different handles are independent and
+ *     may be driven from different host threads: every entry point selects the handle's device
+ *     itself (hipSetDevice), whatever the calling thread's current device is.
  *   - the library owns all device buffers for the handle's lifetime unless the caller passes
  *     `external_arena`; rc_get() returns borrowed device pointers.
  *   - all work is stream-ordered on the handle's stream; rc_sync() waits for it.
@@ -198,6 +200,14 @@ int rc_reset_kernel_times(rc_env *env);
 /* Raycast implementation selector, 0..7 (all variants return identical results; 7, the default, is the
  * fastest: per-cell, per-quadrant free rectangles, one wave per car; 0 is the cell-by-cell reference traversal). */
 int rc_set_raycast_variant(rc_env *env, int32_t variant);
+
+/* Experiment / validation knobs of the scan - NOT part of the product interface; every knob is 0 in production and
+ * the library reads nothing from the process environment.  RAY_THREADS / RAY_SPLIT / RAY_WG_PER_CU: launch geometry
+ * sweeps (tools/knob_sweep.sh); BAND_LOG2 in [-40, -10]: width of the exact-count zone of the scan as
+ * max(w, h) * 2^value cells instead of 2^-21 - tests/test_gpu_parity.py narrows it to show that its corner-aimed rays
+ * detect a band below the rounding bound.  Takes effect immediately (also after rc_load_track). */
+enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, RC_DBG_BAND_LOG2 = 3, RC_DBG_COUNT = 4 };
+int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
 
 /* Host-only: the beam (cos, sin) and footprint tables the kernels use (float32 [1080][2], [34][2]). */
 void rc_spec_tables(float *beams_1080x2, float *footprint_34x2);

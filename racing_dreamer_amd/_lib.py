@@ -21,6 +21,11 @@ RC_MAX_CARS = 4
  F_PROGRESS, F_LAP, F_CHECKPOINT, F_DONE, F_TRUNCATED, F_WALL_COLLISION, F_OPPONENT_COLLISION, F_WRONG_WAY,
  F_FRESH, F_ACCELERATION, F_STEERING_ANGLE, F_ACTION_IN, F_COUNT) = range(23)
 
+# rc_debug_set knobs (experiments / validation only; all 0 in production)
+DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2 = range(4)
+DEBUG_KNOBS = {"ray_threads": DBG_RAY_THREADS, "ray_split": DBG_RAY_SPLIT, "ray_wg_per_cu": DBG_RAY_WG_PER_CU,
+               "band_log2": DBG_BAND_LOG2}
+
 K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_FTG, K_COUNT = range(7)
 KERNEL_NAMES = {K_DYNAMICS: "rc_dynamics_kernel", K_RAYCAST: "rc_raycast_kernel", K_PATCH: "rc_patch_kernel",
                 K_RESET: "rc_reset_kernel", K_ACTIONS: "rc_random_actions_kernel", K_FTG: "rc_ftg_kernel"}
@@ -63,6 +68,7 @@ SYMBOLS = {
     "rc_kernel_time": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_double), _P(C.c_uint64)]),
     "rc_reset_kernel_times": (C.c_int, [C.c_void_p]),
     "rc_set_raycast_variant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rc_debug_set": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rc_spec_tables": (None, [C.c_void_p, C.c_void_p]),
     "rc_set_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

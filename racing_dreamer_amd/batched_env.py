@@ -223,6 +223,12 @@ class BatchedRaceEnv:
         7 = the same with one wave per car (default).  All variants return identical results."""
         L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
 
+    def debug_set(self, knob: str, value: int) -> None:
+        """Experiment / validation knobs of the scan (`rc_debug_set`; 0 = production behaviour): ray_threads,
+        ray_split, ray_wg_per_cu, band_log2.  Used by tools/knob_sweep.sh and the band-sensitivity check of
+        tests/test_gpu_parity.py; the library itself reads nothing from the process environment."""
+        L.check(self._lib.rc_debug_set(self._h, L.DEBUG_KNOBS[knob], int(value)))
+
     def follow_the_gap(self, motor_straight: float = 0.6, motor_corner: float = 0.3) -> torch.Tensor:
         """Batched follow-the-gap agent (dreamer/dream.py:211-216 prefill): fills and returns `action_in`
         from the current LiDAR scans; pass None to step() to apply it."""

@@ -98,12 +98,14 @@ struct rc_env {
     std::vector<EventPair> free_events;
     double k_ms[RC_K_COUNT] = {0};
     uint64_t k_n[RC_K_COUNT] = {0};
+    int32_t dbg[RC_DBG_COUNT] = {0};   // rc_debug_set: experiment / validation knobs, all 0 = production behaviour
 };
 
 namespace {
 
 int drain_events(rc_env *env) {
     if (env->pending.empty()) return RC_OK;
+    HIP_TRY(hipSetDevice(env->cfg.device));
     HIP_TRY(hipStreamSynchronize(env->stream));
     for (EventPair &ep : env->pending) {
         float ms = 0.f;
@@ -168,10 +170,9 @@ void set_launch_geometry(rc_env *env) {
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
     li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
-    // tuning knobs for experiments (not part of the interface): workgroup size / workgroups per CU of the LDS-free scan
+    // tuning knobs for experiments (rc_debug_set; all zero in production): workgroup size / workgroups per CU of the LDS-free scan
     if (li.raycast_variant == 7) {
-        const char *e = getenv("RC_RAY_THREADS");
-        const int threads = e ? atoi(e) : 0;
+        const int threads = env->dbg[RC_DBG_RAY_THREADS];
         li.car_threads = (threads == 64 || threads == 128 || threads == 256) ? threads : 64;
         // one wave per car keeps the chip busy only with several waves per wave slot (8 per SIMD x 4 SIMDs x CUs) for the
         // dispatcher to balance; smaller batches split each car's 17 rounds over `split` waves (round k of a car goes to
@@ -179,25 +180,33 @@ void set_launch_geometry(rc_env *env) {
         // for split 1 / 2 / 3 / 4 / 9 / 17; 16 384 cars 0.0737 / 0.0799 / 0.0750 / 0.0869 ms for 1 / 2 / 3 / 4 - about
         // 48 waves per CU in total is the sweet spot (a wave's fixed cost, the car's state and first-trip line, is
         // paid once per wave).
-        e = getenv("RC_RAY_SPLIT");
-        int split = e ? atoi(e) : 0;
+        int split = env->dbg[RC_DBG_RAY_SPLIT];
         if (split < 1 || split > 17) {
             const long long want = 48LL * li.n_cu, n = env->n_cars;
             split = (int)std::min<long long>(17, std::max<long long>(1, (want + n - 1) / n));
         }
         li.car_split = split;
     } else if (li.raycast_variant >= 4) {
-        const char *e = getenv("RC_RAY_THREADS");
-        int threads = e ? atoi(e) : 0;
+        const int threads = env->dbg[RC_DBG_RAY_THREADS];
         if (threads >= 64 && threads <= 1024 && threads % 64 == 0) li.ray_threads = threads;
-        e = getenv("RC_RAY_WG_PER_CU");
-        const int per_cu = e ? atoi(e) : 0;
+        const int per_cu = env->dbg[RC_DBG_RAY_WG_PER_CU];
         if (threads || per_cu) {
             const long long chunks = (rays + li.ray_threads - 1) / li.ray_threads;
             const long long resident = (long long)li.n_cu * (per_cu > 0 ? per_cu : 2048 / li.ray_threads);
             li.ray_blocks = (int)std::min<long long>(chunks, per_cu < 0 ? chunks : resident);
         }
     }
+}
+
+// Half-width of the zone around a cell boundary in which the scan counts the other-axis cell exactly (derivation in
+// racecar_kernels.hip).  RC_DBG_BAND_LOG2 is the validation knob of tests/test_gpu_parity.py: a band below the
+// rounding bound must make the parity tests fail.
+void set_band(rc_env *env) {
+    RcTrackDev &t = env->params.trk;
+    const int l2 = env->dbg[RC_DBG_BAND_LOG2];
+    t.band = std::ldexp((float)(std::max(t.w, t.h) + 2), (l2 <= -10 && l2 >= -40) ? l2 : -21);
+    t.band_p1 = 1.0f + t.band;
+    t.band2 = 2.0f * t.band;
 }
 
 // Point every output field at `arena` (layout of make_layout).  The action input buffer is NOT part of this: it
@@ -415,6 +424,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
 
 void rc_destroy(rc_env *env) {
     if (!env) return;
+    (void)hipSetDevice(env->cfg.device);
     if (env->stream) (void)hipStreamSynchronize(env->stream);
     for (EventPair &ep : env->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (EventPair &ep : env->free_events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
@@ -562,13 +572,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
     t.tmax = RCS_MAX_RANGE * t.inv_res;
-    t.band = (float)(std::max(w, h) + 2) * 0x1p-21f;
-    if (const char *e = getenv("RC_RAY_BAND_LOG2")) {   // validation knob (tests/test_gpu_parity.py): a band below the
-        const int l2 = atoi(e);                         // rounding bound must make the parity tests fail
-        if (l2 <= -10 && l2 >= -40) t.band = std::ldexp((float)(std::max(w, h) + 2), l2);
-    }
-    t.band_p1 = 1.0f + t.band;
-    t.band2 = 2.0f * t.band;
+    set_band(env);
     // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
     RcLaunchInfo &li = env->launch;
     li.lds_bytes = fits_lds ? bm_bytes : 0;
@@ -620,6 +624,7 @@ int rc_step(rc_env *env, const float *actions_dev, int32_t repeat) {
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_step");
     if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
     if (repeat < 1) return fail(RC_ERR_INVALID, "repeat must be >= 1 (got %d)", repeat);
+    HIP_TRY(hipSetDevice(env->cfg.device));
     // the kernel only reads the caller's buffer (its actions pointer is written in random-action mode alone)
     float *act = actions_dev ? const_cast<float *>(actions_dev) : env->actions_in;
     const RcRandomActions none{0, 0u, 0u, 0u};
@@ -632,6 +637,7 @@ int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat) {
     if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before rc_step_random");
     if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
     if (repeat < 1) return fail(RC_ERR_INVALID, "repeat must be >= 1 (got %d)", repeat);
+    HIP_TRY(hipSetDevice(env->cfg.device));
     const RcRandomActions ra{1, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step};
     TIMED(env, RC_K_DYNAMICS, rck_launch_dynamics(env->params, env->actions_in, repeat, ra, env->stream));
     return observe(env);
@@ -640,6 +646,7 @@ int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat) {
 int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (!actions_host) return fail(RC_ERR_INVALID, "actions_host is NULL");
+    HIP_TRY(hipSetDevice(env->cfg.device));
     HIP_TRY(hipMemcpyAsync(env->actions_in, actions_host, (size_t)env->n_cars * 8, hipMemcpyHostToDevice, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
     return rc_step(env, nullptr, repeat);
@@ -662,12 +669,14 @@ int rc_set_pose(rc_env *env, const float *xyyaw_host) {
 int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+    HIP_TRY(hipSetDevice(env->cfg.device));
     TIMED(env, RC_K_FTG, rck_launch_ftg(env->params, env->actions_in, motor_straight, motor_corner, env->stream));
     return RC_OK;
 }
 
 int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    HIP_TRY(hipSetDevice(env->cfg.device));
     const uint32_t first_car = env->params.first_env * (uint32_t)env->cfg.cars_per_env;
     TIMED(env, RC_K_ACTIONS, rck_launch_random_actions(env->actions_in, env->n_cars, first_car, (uint32_t)(seed & 0xffffffffu),
                                                        (uint32_t)(seed >> 32), step, env->stream));
@@ -691,6 +700,7 @@ int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes) {
     if (rc) return rc;
     if (!host_dst) return fail(RC_ERR_INVALID, "host_dst is NULL");
     if (bytes != n) return fail(RC_ERR_INVALID, "field %d holds %zu bytes, caller asked for %zu", field, n, bytes);
+    HIP_TRY(hipSetDevice(env->cfg.device));
     HIP_TRY(hipMemcpyAsync(host_dst, src, n, hipMemcpyDeviceToHost, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
     return RC_OK;
@@ -705,6 +715,7 @@ int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes) {
 
 int rc_sync(rc_env *env) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    HIP_TRY(hipSetDevice(env->cfg.device));
     HIP_TRY(hipStreamSynchronize(env->stream));
     return RC_OK;
 }
@@ -747,6 +758,17 @@ int rc_set_arena(rc_env *env, void *arena, size_t bytes) {
         if ((uintptr_t)arena % 64) return fail(RC_ERR_INVALID, "arena must be 64-byte aligned");
     }
     bind_outputs(env, arena);
+    return RC_OK;
+}
+
+int rc_debug_set(rc_env *env, int32_t knob, int32_t value) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (knob < 0 || knob >= RC_DBG_COUNT) return fail(RC_ERR_INVALID, "unknown debug knob %d", knob);
+    env->dbg[knob] = value;
+    if (env->has_track) {
+        set_band(env);
+        set_launch_geometry(env);
+    }
     return RC_OK;
 }
 

@@ -185,3 +185,45 @@ def test_map_larger_than_the_lds_runs_the_default_scan_only():
         ov = ora.step(act, repeat=4)
         compare_outputs(dv, ov, n, 1, f"huge step {k}")
     env.close()
+
+
+def test_handle_created_on_one_thread_is_driven_from_another():
+    """include/racecar_hip.h: different handles may be driven from different host threads; every entry point selects
+    the handle's device itself.  A handle made on the main thread is reset / stepped / read back from a worker thread
+    (whose HIP context starts with its own current-device state) while a second handle runs on the main thread, and
+    both must match handles driven from their creating thread."""
+    import threading
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+
+    def rollout(env, out):
+        try:
+            env.reset(mode="random", seed=5)
+            for k in range(4):
+                env.step_random(seed=9, step=k, repeat=2)
+            env.set_profiling(True)
+            env.step_random(seed=9, step=4, repeat=2)
+            env.set_profiling(False)
+            out["times"] = env.kernel_times()
+            out["lidar"] = env.host("lidar").copy()
+            out["reward"] = env.host("reward").copy()
+        except Exception as e:          # noqa: BLE001 - reported to the main thread
+            out["error"] = repr(e)
+
+    a = BatchedRaceEnv("columbia", 256, 1, auto_reset=True)
+    b = BatchedRaceEnv("columbia", 256, 1, auto_reset=True)
+    ref = BatchedRaceEnv("columbia", 256, 1, auto_reset=True)
+    ra, rb, rr = {}, {}, {}
+    th = threading.Thread(target=rollout, args=(a, ra))
+    th.start()
+    rollout(b, rb)                      # concurrently on the main thread, its own handle and stream
+    th.join()
+    rollout(ref, rr)
+    for r in (ra, rb, rr):
+        assert "error" not in r, r.get("error")
+    assert ra["times"]["rc_raycast_kernel"]["launches"] == 1      # launch-attached timers are per thread
+    for k in ("lidar", "reward"):
+        assert np.array_equal(ra[k], rr[k]) and np.array_equal(rb[k], rr[k])
+    for e in (a, b, ref):
+        e.close()
+    torch.cuda.synchronize()
