@@ -8,10 +8,15 @@ car, resident in HBM (288 GB hold ~900 steps of 65 536 cars with full 1080-beam 
 output arena is re-pointed at the next slot (`rc_set_arena`), so the kernels write the record straight into the
 ring - no copy, no host - and `sample()` gathers `[batch, length, ...]` windows with one indexed read per field.
 
-Window semantics follow the reference's dataset: a window never crosses an episode boundary (an auto-reset inside
-a window would splice two episodes); a window that starts on the first record of an episode gets the reference's
-reset row there (action 0, reward 0, discount 1, progress -1, time 0 - wrappers.py:232-236).  `EpisodeRecorder` (trajectory.py) remains
-the way to write reference-format episode files for a subset of cars.
+Window semantics follow the reference's dataset (episode files sliced by `load_episodes`): a window never crosses
+an episode boundary.  With `auto_reset` the record of an episode's LAST step carries the terminal reward / discount 0
+/ done together with the first observation of the next episode (`fresh` = 1): such a record may END a window - it
+is the terminal transition the learner's discount head trains on (dreamer/models.py:103) - and then keeps its reward,
+discount, progress and time while its observation fields are replaced by the previous row's (the terminal
+observation is gone, as in vectorised gym envs; `EpisodeRecorder` does the same).  A window that STARTS on a fresh
+record gets the reference's reset row there (action 0, reward 0, discount 1, progress -1, time 0 -
+wrappers.py:232-236).  A fresh record anywhere else would splice two episodes, so such windows are rejected.
+`EpisodeRecorder` (trajectory.py) remains the way to write reference-format episode files for a subset of cars.
 """
 from __future__ import annotations
 
@@ -21,6 +26,8 @@ import torch
 
 DEFAULT_SAMPLE_FIELDS = ("lidar", "lidar_occupancy", "action", "reward", "discount", "progress_total", "time",
                          "speed", "done", "fresh")
+# the observation part of a record (what a terminal row borrows from the row before it)
+OBSERVATION_FIELDS = ("lidar", "lidar_occupancy", "pose", "velocity", "speed", "acceleration", "steering_angle")
 
 
 class TrajectoryRing:
@@ -63,7 +70,13 @@ class TrajectoryRing:
         self.steps_written += 1
 
     def reset(self, *args, **kwargs) -> Dict[str, torch.Tensor]:
-        """env.reset() recorded as the next ring record."""
+        """env.reset() of EVERY env recorded as the next ring record.  Masked resets are refused: the reset kernel
+        writes nothing for the envs that keep running, so their part of the new slot would hold whatever was there
+        `capacity` steps ago - record finished envs with `auto_reset=True` (the terminal transition and the new
+        episode's first observation then share one record, see `sample`)."""
+        mask = kwargs.get("mask", args[0] if args else None)
+        if mask is not None:
+            raise ValueError("TrajectoryRing.reset cannot record a masked reset; build the env with auto_reset=True")
         self._advance()
         return self.env.reset(*args, **kwargs)
 
@@ -89,8 +102,10 @@ class TrajectoryRing:
                generator: Optional[torch.Generator] = None, reset_rows: bool = True,
                max_tries: int = 16) -> Dict[str, torch.Tensor]:
         """`batch` windows of `length` consecutive records of one car each, uniformly over (time, env, car) among
-        the windows that contain no episode start after their first record.  Returns field -> [batch, length, ...]
-        (copies, on the ring's device) plus `env`, `car`, `t0` (ring age of the first record, 0 = oldest)."""
+        the windows that stay inside one episode: no fresh record strictly inside, and a fresh LAST record only if it
+        is the terminal transition of the window's episode (done = 1, written by auto-reset).  Returns field ->
+        [batch, length, ...] (copies, on the ring's device) plus `env`, `car`, `t0` (ring age of the first record,
+        0 = oldest) and `terminal` (bool [batch]: the last row is such a terminal transition)."""
         nstart = self.window_starts(length)
         if nstart <= 0:
             raise ValueError(f"ring holds {self.count} records, a window needs {length}")
@@ -98,7 +113,7 @@ class TrajectoryRing:
         dev = self.buffer.device
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
         ar = torch.arange(length, device=dev)
-        fresh = self.fields["fresh"]
+        fresh, done = self.fields["fresh"], self.fields["done"]
         keep_t, keep_e, keep_c, have = [], [], [], 0
         for _ in range(max_tries):
             m = max(2 * (batch - have), 16)
@@ -106,7 +121,11 @@ class TrajectoryRing:
             e = torch.randint(0, self.env.num_envs, (m,), device=dev, generator=generator)
             c = torch.randint(0, self.env.cars_per_env, (m,), device=dev, generator=generator)
             slots = (oldest + t0[:, None] + ar[None, :]) % self.capacity                    # [m, length]
-            ok = ~(fresh[slots[:, 1:], e[:, None], c[:, None]] != 0).any(1) if length > 1 else torch.ones(m, dtype=torch.bool, device=dev)
+            ok = torch.ones(m, dtype=torch.bool, device=dev)
+            if length > 2:
+                ok &= ~(fresh[slots[:, 1:-1], e[:, None], c[:, None]] != 0).any(1)
+            if length > 1:                                    # a fresh last record must be the episode's terminal one
+                ok &= (fresh[slots[:, -1], e, c] == 0) | (done[slots[:, -1], e, c] != 0)
             keep_t.append(t0[ok]); keep_e.append(e[ok]); keep_c.append(c[ok])
             have += int(ok.sum())
             if have >= batch:
@@ -116,6 +135,12 @@ class TrajectoryRing:
         t0 = torch.cat(keep_t)[:batch]; e = torch.cat(keep_e)[:batch]; c = torch.cat(keep_c)[:batch]
         slots = (oldest + t0[:, None] + ar[None, :]) % self.capacity
         out = {name: self.fields[name][slots, e[:, None], c[:, None]] for name in names}
+        terminal = torch.zeros(batch, dtype=torch.bool, device=dev)
+        if length > 1:
+            terminal = (fresh[slots[:, -1], e, c] != 0) & (done[slots[:, -1], e, c] != 0)
+            for name in OBSERVATION_FIELDS:                   # the new episode's observation is not this episode's
+                if name in out:
+                    out[name][terminal, -1] = out[name][terminal, -2]
         if reset_rows:
             first = self.fields["fresh"][slots[:, 0], e, c] != 0               # window starts an episode
             if "action" in out:
@@ -128,5 +153,5 @@ class TrajectoryRing:
                 out["time"][first, 0] = 0.0
             if "progress_total" in out:
                 out["progress_total"][first, 0] = -1.0
-        out["env"], out["car"], out["t0"] = e, c, t0
+        out["env"], out["car"], out["t0"], out["terminal"] = e, c, t0, terminal
         return out

@@ -15,7 +15,6 @@ views only, so it works on any mapping of field name -> tensor [num_envs, cars_p
 from __future__ import annotations
 
 import datetime
-import io
 import pathlib
 import uuid
 from typing import Callable, Dict, List, Optional, Sequence
@@ -103,22 +102,26 @@ class EpisodeRecorder:
 
 
 def save_episodes(directory, episodes) -> List[pathlib.Path]:
-    """Same files as dreamer/callbacks.py:41-53: `{timestamp}-{uuid}-{length}.npz`, np.savez_compressed."""
-    directory = pathlib.Path(directory).expanduser()
-    directory.mkdir(parents=True, exist_ok=True)
-    timestamp = datetime.datetime.now().strftime("%Y%m%dT%H%M%S")
-    paths = []
-    for episode in episodes:
-        identifier = str(uuid.uuid4().hex)
-        length = len(episode["reward"])
-        filename = directory / f"{timestamp}-{identifier}-{length}.npz"
-        with io.BytesIO() as f1:
-            np.savez_compressed(f1, **episode)
-            f1.seek(0)
-            with filename.open("wb") as f2:
-                f2.write(f1.read())
-        paths.append(filename)
-    return paths
+    """Write each episode dict as one compressed `.npz` the reference's dataset loader picks up.
+
+    What `dreamer/tools.py` relies on is only the file format: `load_episodes` globs `*.npz` and reads every key
+    (tools.py:240-246), `count_episodes` takes the number of steps from the file name's last `-`-separated field
+    (tools.py:224-228: `int(stem.rsplit('-', 1)[-1]) - 1`).  Names are `{timestamp}-{unique id}-{rows}.npz` like the
+    reference's writer (dreamer/callbacks.py:41-53); the file is written under a temporary name and renamed, so a
+    loader that rescans the directory while a rollout is running never sees a partial archive."""
+    out_dir = pathlib.Path(directory).expanduser()
+    out_dir.mkdir(parents=True, exist_ok=True)
+    stamp = datetime.datetime.now().strftime("%Y%m%dT%H%M%S")
+    written = []
+    for ep in episodes:
+        rows = int(np.shape(ep["reward"])[0])
+        final = out_dir / f"{stamp}-{uuid.uuid4().hex}-{rows}.npz"
+        partial = final.with_suffix(".npz.part")
+        with open(partial, "wb") as fh:
+            np.savez_compressed(fh, **ep)
+        partial.replace(final)
+        written.append(final)
+    return written
 
 
 def count_steps(directory) -> int:

@@ -20,6 +20,37 @@ def hip_lib():
     return _lib.load_library()
 
 
+REF = "/root/reference"
+
+
+@pytest.fixture()
+def ref_wrappers(monkeypatch):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    saved = {k: sys.modules.get(k) for k in ("gym", "gym.spaces", "gym.wrappers", "racecar_gym", "racecar_gym.envs",
+                                             "racecar_gym.envs.multi_agent_race", "wrappers")}
+    make_golden.install_stubs()                      # gym names only
+    for k in [m for m in sys.modules if m == "racecar_gym" or m.startswith("racecar_gym.")]:
+        del sys.modules[k]                           # the shim provides racecar_gym, not the stub
+    from racing_dreamer_amd import compat
+    compat.install()
+    import racecar_gym.envs.multi_agent_race as mar
+    from oracle_backend import OracleBackend
+    monkeypatch.setattr(mar, "_BACKEND", OracleBackend)
+    monkeypatch.chdir(os.path.join(REF, "dreamer"))  # RaceCarBaseEnv loads "scenarios/{task}/{track}.yml"
+    sys.path.insert(0, os.path.join(REF, "dreamer"))
+    sys.modules.pop("wrappers", None)
+    import wrappers as W
+    W.envs.clear()
+    yield W
+    sys.path.remove(os.path.join(REF, "dreamer"))
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
 @pytest.fixture(autouse=True, scope="session")
 def _band_knob_from_environment():
     """Validation hook of tools/band_validation.sh: RC_TEST_BAND_LOG2=<l2> narrows the scan's exact-count band on every

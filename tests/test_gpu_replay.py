@@ -2,7 +2,61 @@
 import numpy as np
 import pytest
 
+from helpers import EXACT_FLOAT, EXACT_INT
+
 pytestmark = pytest.mark.gpu
+
+
+def test_ring_records_equal_the_oracle_rollout_and_terminal_transitions_are_sampled():
+    """Every slot of the ring against the CPU oracle's rollout of the same seeds (not against a second HIP env), then
+    the learner-side property ADVICE r1 asked for: sampled batches contain the episodes' terminal transitions
+    (discount 0, collision reward) at the rate the ring holds them."""
+    import torch
+    from oracle import c_oracle, racecar_oracle as ro
+    from racing_dreamer_amd import spec
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.replay import TrajectoryRing
+    from racing_dreamer_amd.track_assets import load_track
+    track = load_track("columbia")
+    n, cap, steps = 192, 12, 30
+    env = BatchedRaceEnv(track, n, 1, obs_type="lidar_occupancy", auto_reset=True, action_repeat=4)
+    ora = c_oracle.COracleEnv(track.occ, track.drivable, track.progress, track.centerline, track.origin, track.resolution,
+                              ro.OracleConfig(num_envs=n, auto_reset=True, render_occupancy=True), threads=8)
+    ring = TrajectoryRing(env, capacity=cap)
+    ring.reset(mode="random", seed=4)
+    want = [ora.reset(mode=spec.RESET_RANDOM, seed=4)]
+    for k in range(steps):
+        act = ro.random_actions(21, k, n)
+        ring.step(torch.from_numpy(act).cuda().view(n, 1, 2), repeat=4)
+        want.append(ora.step(act, repeat=4))
+    torch.cuda.synchronize()
+    for age in range(cap):                                  # the newest `cap` records, oldest first
+        slot = (ring.head + 1 + age) % cap
+        rec = want[steps + 1 - cap + age]
+        for name in EXACT_FLOAT + EXACT_INT + ["lidar_occupancy"]:
+            got = ring.fields[name][slot].cpu().numpy().reshape(-1)
+            exp = np.asarray(rec[name]).reshape(-1)
+            assert np.array_equal(got, exp.astype(got.dtype)), (age, name)
+    # terminal transitions: windows of 4 ending on a done record
+    done = torch.stack([torch.from_numpy(w["done"].astype(np.uint8)) for w in want[-cap:]])      # [cap, n]
+    assert int(done.sum()) >= 10
+    g = torch.Generator(device="cuda").manual_seed(0)
+    batch = ring.sample(batch=4096, length=4, generator=g)
+    term = batch["terminal"]
+    assert int(term.sum()) > 0
+    assert torch.all(batch["discount"][term, -1] == 0.0) and torch.all(batch["done"][term, -1] == 1)
+    assert torch.all(batch["reward"][term, -1] < 0.0)               # progress gain of a crash step minus 1 (collision_reward)
+    assert torch.equal(batch["lidar"][term, -1], batch["lidar"][term, -2])
+    assert torch.all(batch["discount"][:, :-1][batch["fresh"][:, :-1] == 0] == 1.0)
+    assert not (batch["fresh"][:, 1:-1] != 0).any()
+    # rate: each terminal record at ring age >= 3 ends one window; valid windows = all (start, env) minus rejected ones
+    fresh = torch.stack([torch.from_numpy(w["fresh"].astype(np.uint8)) for w in want[-cap:]])
+    ok = torch.ones(cap - 3, n, dtype=torch.bool)
+    for t0 in range(cap - 3):
+        ok[t0] = ~(fresh[t0 + 1:t0 + 3] != 0).any(0) & ((fresh[t0 + 3] == 0) | (done[t0 + 3] != 0))
+    expected = float(((done[3:] != 0) & (fresh[3:] != 0) & ok).sum()) / float(ok.sum())
+    assert abs(float(term.float().mean()) - expected) < 0.25 * expected + 0.01
+    env.close()
 
 
 def test_ring_records_equal_a_plain_rollout_and_sampling_runs_on_device():
@@ -34,9 +88,11 @@ def test_ring_records_equal_a_plain_rollout_and_sampling_runs_on_device():
     batch = ring.sample(batch=128, length=4, generator=g)
     assert batch["lidar"].shape == (128, 4, 1080) and batch["lidar"].is_cuda
     assert batch["lidar_occupancy"].shape == (128, 4, 64, 64, 1) and batch["action"].shape == (128, 4, 2)
-    assert not (batch["fresh"][:, 1:] != 0).any()
+    assert not (batch["fresh"][:, 1:-1] != 0).any()
+    assert torch.equal(batch["fresh"][:, -1] != 0, batch["terminal"])
     t = batch["time"]
-    assert torch.allclose(t[:, 1:] - t[:, :-1], torch.full_like(t[:, 1:], 0.04), atol=1e-5)   # consecutive agent steps
+    inner = t[:, 1:-1] - t[:, :-2]
+    assert torch.allclose(inner, torch.full_like(inner, 0.04), atol=1e-5)                     # consecutive agent steps
     # detach: the env writes into its own arena again and the ring keeps its contents
     newest = ring.fields["reward"][ring.head].clone()
     ring.detach()

@@ -106,3 +106,117 @@ def test_shim_single_env_step_rate(tmp_path):
     print(f"shim single-env rate: {rate:.0f} steps/s")
     assert rate > 1000
     env.close()
+
+
+class _PortStack:
+    """The Dreamer wrapper order (dreamer/dream.py:134-140, 103-115) assembled from the pinned restatements in
+    oracle/wrappers_port.py - the reference's own classes cannot travel to the GPU box - over a shim env:
+    RaceCarWrapper (flat action -> dict, speed) -> ActionRepeat -> ReduceActionSpace -> FixedResetMode -> TimeLimit
+    -> Collect."""
+
+    def __init__(self, env, repeat, duration, mode, sink):
+        from oracle import wrappers_port as wp
+        self.wp, self.env, self.repeat, self.mode, self.sink = wp, env, repeat, mode, sink
+        self.limit, self.collect = wp.TimeLimit(duration), wp.Collect()
+
+    def _obs(self, obs, velocity):
+        o = dict(obs["A"])
+        o["speed"] = self.wp.speed(velocity)
+        return {"A": o}
+
+    def reset(self):
+        obs = self.env.reset(mode=self.mode)
+        self.limit.reset()
+        obs = self._obs(obs, np.zeros(6))
+        obs["A"]["speed"] = 0.0                                       # wrappers.py:74
+        self.collect.reset(obs["A"])
+        return obs
+
+    def step(self, actions):
+        a = self.wp.reduce_action(np.asarray(actions["A"], np.float64))
+        inner = lambda act: self.env.step({"A": {"motor": act[0], "steering": act[1]}})
+        obs, total, dones, info, _ = self.wp.action_repeat_dreamer(inner, ["A"], a, self.repeat)
+        dones = self.limit.step(dones)
+        obs = self._obs(obs, info["A"]["velocity"])
+        ep = self.collect.step(obs["A"], actions["A"], total["A"], dones["A"], info["A"])
+        if ep is not None:
+            self.sink.append(ep)
+        return obs, total, dones, info
+
+
+def test_caller_loop_on_the_hip_shim(tmp_path, monkeypatch):
+    """SURVEY.md H13 on the device: the rollout driver (oracle/caller_port.py = dreamer/tools.py:154-206) over the
+    wrapper order of dream.py on the shim, once with the HIP backend and once with the CPU oracle as backend: the
+    episodes the collector hands to its callbacks must be identical, value for value."""
+    from racing_dreamer_amd import compat
+    compat.install()
+    import racecar_gym.envs.multi_agent_race as mar
+    from oracle import caller_port as cp
+    from oracle_backend import OracleBackend
+
+    def policy(obs, done, state):
+        assert obs["lidar"].shape == (1, 1080) and done.shape == (1,)
+        scan = obs["lidar"][0]
+        steer = float(np.clip((scan[700:900].mean() - scan[180:380].mean()) * 0.4, -1, 1))
+        k = 0 if state is None else state + 1
+        return np.array([[0.3 + 0.1 * (k % 3), -steer]]), k
+
+    path = _scenario(tmp_path, "columbia")
+    runs = []
+    for backend in (None, OracleBackend):
+        if backend is not None:
+            monkeypatch.setattr(mar, "_BACKEND", backend)
+        eps = []
+        env = _PortStack(mar.MultiAgentRaceEnv(mar.MultiAgentScenario.from_spec(path)), repeat=4, duration=30,
+                         mode="random", sink=eps)
+        state, stats = cp.rollout([policy], env, ["A"], episodes=3)
+        state, stats2 = cp.rollout([policy], env, ["A"], steps=20, state=(0, 0) + state[2:])
+        runs.append((eps, stats, stats2, state[0]))
+        env.env.close()
+    (hip_eps, hip_stats, hip_stats2, hip_over), (ora_eps, ora_stats, ora_stats2, ora_over) = runs
+    assert len(hip_eps) == len(ora_eps) >= 4 and hip_over == ora_over
+    assert hip_stats["env_steps"] == ora_stats["env_steps"] and hip_stats["resets"] == 3
+    for a, b in zip(hip_eps, ora_eps):
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+    assert hip_stats["progress"] == ora_stats["progress"] and hip_stats["return"] == ora_stats["return"]
+
+
+def test_episode_recorder_on_the_hip_env_equals_the_oracle_recording(tmp_path):
+    """N1 on the device: EpisodeRecorder over BatchedRaceEnv views against the same recorder over the CPU oracle."""
+    import torch
+    from helpers import make_oracle
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    from racing_dreamer_amd.trajectory import EpisodeRecorder, count_steps
+    track, B = load_track("treitlstrasse_v2"), 48
+    picks = [0, 7, 31, 47]
+    env = BatchedRaceEnv(track, B, 1, obs_type="lidar_occupancy", auto_reset=True, time_limit_steps=15)
+    ora = make_oracle(track, num_envs=B, auto_reset=True, render_occupancy=True, time_limit_steps=15)
+    rec_d = EpisodeRecorder(B, 1, picks, directory=str(tmp_path / "hip"))
+    rec_o = EpisodeRecorder(B, 1, picks)
+
+    def oviews(out):
+        v = {}
+        for k, a in out.items():
+            a = np.asarray(a)
+            t = torch.from_numpy(a.reshape(B, 1, *a.shape[1:]).copy())
+            v[k] = t.unsqueeze(-1) if k == "lidar_occupancy" else t
+        return v
+
+    rec_d.on_reset(env.reset(mode="random", seed=6))
+    rec_o.on_reset(oviews(ora.reset(mode=ro.RESET_RANDOM, seed=6)))
+    eps_d, eps_o = [], []
+    for k in range(40):
+        act = ro.random_actions(3, k, B)
+        eps_d += rec_d.on_step(env.step(torch.from_numpy(act).cuda(), repeat=4))
+        eps_o += rec_o.on_step(oviews(ora.step(act, repeat=4)))
+    assert len(eps_d) == len(eps_o) >= 8
+    for a, b in zip(eps_d, eps_o):
+        assert sorted(a) == sorted(b)
+        for k in a:
+            assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
+    assert count_steps(tmp_path / "hip") == sum(len(e["reward"]) - 1 for e in eps_d)
+    env.close()

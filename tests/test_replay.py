@@ -11,7 +11,7 @@ class FakeEnv:
     """Writes recognisable values into whatever arena it is pointed at: lidar = step + env / 1000, reward = step,
     fresh = 1 on the steps listed per env."""
 
-    def __init__(self, num_envs=6, cars=2, fresh_at=()):
+    def __init__(self, num_envs=6, cars=2, fresh_at=(), done_at=()):
         self.num_envs, self.cars_per_env, self.device = num_envs, cars, torch.device("cpu")
         n = num_envs * cars
         self._host_layout, off = {}, 0
@@ -25,6 +25,7 @@ class FakeEnv:
         self.views = self.views_of(self.own)
         self.t = -1
         self.fresh_at = set(fresh_at)
+        self.done_at = set(done_at)          # (t, env): auto-reset record - terminal scalars + the next episode's first obs
         self.bound = []
 
     def views_of(self, arena):
@@ -48,6 +49,13 @@ class FakeEnv:
         for (t, e) in self.fresh_at:
             if t == self.t:
                 v["fresh"][e] = 1
+        for (t, e) in self.done_at:
+            if t == self.t:
+                v["fresh"][e] = 1
+                v["done"][e] = 1
+                v["discount"][e] = 0.0
+                v["reward"][e] = -1.0
+                v["lidar"][e] = -7.0          # the NEXT episode's first observation
         return v
 
     def reset(self, **kw):
@@ -109,6 +117,49 @@ def test_windows_never_contain_an_episode_start_after_their_first_record():
     assert torch.all(out["action"][~starts] == 0.5) and torch.all(out["discount"][:, 1:] == 0.9)
     raw = ring.sample(batch=64, length=4, generator=g, reset_rows=False)
     assert torch.all(raw["action"] == 0.5)
+
+
+def test_terminal_transitions_are_sampled_as_the_last_row_of_a_window():
+    """with auto-reset the terminal reward / discount 0 sit in a record that is also `fresh`; the
+    learner must see them (pcont trains on `discount`, dreamer/models.py:103).  Such a record may end a window, with
+    the previous row's observation; it may start one as a reset row; it may not sit inside one."""
+    done_at = {(5, 1), (8, 3), (6, 0)}
+    env = FakeEnv(done_at=done_at)
+    ring = TrajectoryRing(env, capacity=16)
+    ring.reset()
+    for _ in range(12):
+        ring.step()
+    g = torch.Generator().manual_seed(2)
+    out = ring.sample(batch=2048, length=4, generator=g)
+    term = out["terminal"]
+    assert term.any() and (~term).any()
+    assert not (out["fresh"][:, 1:-1] != 0).any()
+    assert torch.equal(out["fresh"][:, -1] != 0, term) and torch.all(out["done"][term, -1] == 1)
+    # terminal rows keep the step's scalars and borrow the observation of the row before
+    assert torch.all(out["discount"][term, -1] == 0.0) and torch.all(out["reward"][term, -1] == -1.0)
+    assert torch.equal(out["lidar"][term, -1], out["lidar"][term, -2]) and not (out["lidar"][:, 1:] == -7.0).any()
+    assert torch.all(out["discount"][~term, -1] == 0.9)
+    # expected rate: windows of 4 over 13 records have 10 start times per env; each terminal record ends exactly one
+    # window and rules out the two windows that hold it at row 1 or 2
+    t_last = out["t0"] + 3
+    hits = {(int(t), int(e)) for t, e, m in zip(t_last, out["env"], term) if m}
+    assert hits == done_at
+    valid = 10 * 6 - 2 * len(done_at)
+    assert abs(float(term.float().mean()) - len(done_at) / valid) < 0.03
+    # a window starting on the terminal record is the next episode's reset row
+    starts = out["fresh"][:, 0] != 0
+    assert starts.any()
+    assert torch.all(out["discount"][starts, 0] == 1.0) and torch.all(out["reward"][starts, 0] == 0.0)
+    assert torch.all(out["lidar"][starts, 0] == -7.0)
+
+
+def test_masked_reset_is_refused():
+    env = FakeEnv()
+    ring = TrajectoryRing(env, capacity=4)
+    ring.reset()
+    with pytest.raises(ValueError, match="masked reset"):
+        ring.reset(mask=np.ones(6, np.uint8))
+    assert ring.steps_written == 1
 
 
 def test_errors():
