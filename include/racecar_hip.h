@@ -60,7 +60,10 @@ typedef enum rc_status {
     RC_ERR_NOMEM = -5
 } rc_status;
 
-enum { RC_TASK_MAX_PROGRESS = 0, RC_TASK_MAX_SPEED = 1 };           /* scenario yml task_name; tasks.py:4-22 */
+enum { RC_TASK_MAX_PROGRESS = 0, RC_TASK_MAX_SPEED = 1,             /* scenario yml task_name; tasks.py:4-22 */
+       RC_TASK_N_STEP_PROGRESS = 2 };  /* secondary agents, baselines/scenarios/max_progress/columbia.yml:17-18: reward =
+                                          100 x total progress gained over the last n_steps sub-steps; never done */
+#define RC_NSTEP_MAX 16
 enum { RC_RESET_GRID = 0, RC_RESET_RANDOM = 1, RC_RESET_RANDOM_BALL = 2 };  /* dream.py:105-108,120 */
 enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1 };              /* dream.py obs_type */
 /* what RC_F_LIDAR holds: metres, or the caller-side scaling fused into the scan's store */
@@ -122,6 +125,8 @@ typedef struct rc_config {
     void    *external_arena;       /* optional caller-owned device memory for the output arena */
     size_t   external_arena_bytes; /*   must be >= rc_arena_bytes(cfg)                         */
     void    *stream;               /* optional hipStream_t to run on; NULL = library creates one */
+    int32_t  car_task[RC_MAX_CARS];/* task of car slot a (agents A, B, C, D of a scenario yml); -1 = `task`          */
+    int32_t  n_steps;              /* RC_TASK_N_STEP_PROGRESS window in sub-steps, 1..RC_NSTEP_MAX (yml n_steps: 10) */
 } rc_config;
 
 /* Fill `cfg` with the defaults of the reference's max_progress scenario. */

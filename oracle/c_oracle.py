@@ -32,7 +32,8 @@ class OcCfg(C.Structure):
                 ("laps", C.c_int32), ("terminate_on_collision", C.c_int32), ("remap_actions", C.c_int32),
                 ("time_limit_steps", C.c_int32), ("auto_reset", C.c_int32), ("time_limit", C.c_float),
                 ("collision_reward", C.c_float), ("act_lo", C.c_float * 2), ("act_hi", C.c_float * 2),
-                ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32)]
+                ("reset_mode", C.c_int32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+                ("car_task", C.c_int32 * 4), ("n_steps", C.c_int32)]
 
 
 _STATE_F = ["x", "y", "theta", "ct", "st", "v", "delta", "omega", "accel", "progress"]
@@ -48,7 +49,8 @@ class OcState(C.Structure):
     _fields_ = ([(n, _fp) for n in _STATE_F] + [(n, _ip) for n in _STATE_I] + [(n, _bp) for n in _STATE_B]
                 + [(n, _ip) for n in _ENV_I] + [("episode", _up)]
                 + [(n, _fp) for n in ["reward", "discount", "progress_total", "time", "action"]]
-                + [("out_progress", _fp)] + [(n, _ip) for n in _RES_I] + [(n, _bp) for n in _RES_B])
+                + [("out_progress", _fp)] + [(n, _ip) for n in _RES_I] + [(n, _bp) for n in _RES_B]
+                + [("nstep_hist", _fp)])
 
 
 def build_library() -> str:
@@ -109,7 +111,9 @@ class COracleEnv:
         self.ccfg = OcCfg(self.B, self.A, cfg.first_env & 0xFFFFFFFF, cfg.task, cfg.laps,
                           int(cfg.terminate_on_collision), int(cfg.remap_actions), cfg.time_limit_steps,
                           int(cfg.auto_reset), cfg.time_limit, cfg.collision_reward,
-                          (C.c_float * 2)(*cfg.action_low), (C.c_float * 2)(*cfg.action_high), 0, 0, 0)
+                          (C.c_float * 2)(*cfg.action_low), (C.c_float * 2)(*cfg.action_high), 0, 0, 0,
+                          (C.c_int32 * 4)(*[(-1 if cfg.car_tasks is None or a >= len(cfg.car_tasks) else int(cfg.car_tasks[a]))
+                                            for a in range(4)]), int(cfg.n_steps))
         self.arr = {}
         st = OcState()
         for name in _STATE_F:
@@ -127,6 +131,7 @@ class COracleEnv:
             self.arr[name] = np.zeros(n, np.int32)
         for name in _RES_B:
             self.arr[name] = np.zeros(n, np.uint8)
+        self.arr["nstep_hist"] = np.zeros(n * ro.NSTEP_MAX, np.float32)
         for name, typ in OcState._fields_:
             setattr(st, name, _ptr(self.arr[name], typ))
         self.state = st

@@ -45,6 +45,7 @@
 #define PATCH_WINDOW 110.0f
 #define BALL_GAP 12
 #define GRID_LEAD 8
+#define NSTEP_MAX 16
 #define PI_F 3.14159274101257324f
 #define TWO_PI_F 6.28318548202514648f
 
@@ -67,6 +68,8 @@ typedef struct {
     float time_limit, collision_reward, act_lo[2], act_hi[2];
     int32_t reset_mode;
     uint32_t seed_lo, seed_hi;
+    int32_t car_task[4];     /* task per car slot, -1 = `task` */
+    int32_t n_steps;         /* window of task 2 (n_step_progress), 1..NSTEP_MAX sub-steps */
 } oc_cfg;
 
 typedef struct {
@@ -80,6 +83,7 @@ typedef struct {
     float *out_progress;
     int32_t *out_lap, *out_cp;
     uint8_t *out_done, *out_trunc, *out_wall, *out_opp, *out_wrong;
+    float *nstep_hist;       /* [n_cars][NSTEP_MAX]: total progress at sub-step s in slot s % n_steps */
 } oc_state;
 
 static inline float clampf(float d, float lo, float hi) { return d < lo ? lo : (d > hi ? hi : d); }
@@ -165,6 +169,7 @@ static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
         s->wall[i] = s->opp[i] = s->wrong[i] = s->done[i] = s->trunc[i] = 0;
         s->lap[i] = 1;
         s->fresh[i] = 1;
+        for (int k = 0; k < NSTEP_MAX; ++k) s->nstep_hist[(size_t)i * NSTEP_MAX + k] = pr;
     }
     s->steps[e] = 0;
     s->agent_steps[e] = 0;
@@ -307,7 +312,14 @@ void oc_step_range(const oc_track *t, const oc_cfg *c, oc_state *s, const float 
                     const int collided = s->wall[i] | s->opp[i];
                     float r;
                     int done;
-                    if (c->task == 0) {
+                    const int task = c->car_task[a] < 0 ? c->task : c->car_task[a];
+                    if (task == 2) {      /* n_step_progress: progress over the last n_steps sub-steps, never done */
+                        float *h = s->nstep_hist + (size_t)i * NSTEP_MAX + (s->steps[e] % c->n_steps);
+                        const float total = (float)(lap - 1) + p_new;
+                        r = (total - *h) * PROGRESS_REWARD;
+                        *h = total;
+                        done = 0;
+                    } else if (task == 0) {
                         const float delta = (float)(lap - lap_old) + (p_new - p_old);
                         r = delta * PROGRESS_REWARD + (collided ? c->collision_reward : 0.0f);
                         done = (collided && c->terminate_on_collision) || lap > c->laps || time > c->time_limit;

@@ -75,7 +75,8 @@ PI = f32(3.14159274101257324)
 TWO_PI = f32(6.28318548202514648)
 INF = f32(np.inf)
 
-TASK_MAX_PROGRESS, TASK_MAX_SPEED = 0, 1
+TASK_MAX_PROGRESS, TASK_MAX_SPEED, TASK_N_STEP_PROGRESS = 0, 1, 2
+NSTEP_MAX = 16                   # longest n_step_progress window [sub-steps]
 RESET_GRID, RESET_RANDOM, RESET_RANDOM_BALL = 0, 1, 2
 
 
@@ -205,9 +206,20 @@ class OracleConfig:
     def __init__(self, num_envs=1, cars_per_env=1, laps=10, time_limit=180.0,
                  terminate_on_collision=True, collision_reward=-1.0, task=TASK_MAX_PROGRESS,
                  remap_actions=False, action_low=(0.005, -1.0), action_high=(1.0, 1.0),
-                 time_limit_steps=0, auto_reset=False, first_env=0, render_occupancy=False):
+                 time_limit_steps=0, auto_reset=False, first_env=0, render_occupancy=False,
+                 car_tasks=None, n_steps=10):
+        """car_tasks: task id per car slot (None / -1 entries = `task`); n_steps: window of TASK_N_STEP_PROGRESS, the
+        task of the secondary agents B-D in baselines/scenarios/max_progress/columbia.yml:17-18,25-26,33-34 (its law
+        lives in the un-vendored racecar_gym, so the spec fixes one: reward = PROGRESS_REWARD x the total progress
+        (lap - 1 + progress) gained over the last n_steps sub-steps - since the reset while the episode is younger -
+        no collision term, never done)."""
         self.__dict__.update(locals())
         del self.__dict__["self"]
+        assert 1 <= n_steps <= NSTEP_MAX
+
+    def task_of(self, a):
+        t = -1 if self.car_tasks is None or a >= len(self.car_tasks) else int(self.car_tasks[a])
+        return self.task if t < 0 else t
 
 
 class OracleRaceEnv:
@@ -240,6 +252,7 @@ class OracleRaceEnv:
         self.wall, self.opp, self.wrong_way = z(np.uint8), z(np.uint8), z(np.uint8)
         self.done, self.truncated, self.fresh = z(np.uint8), z(np.uint8), z(np.uint8)
         self.reward = z(f32)
+        self.nstep_hist = np.zeros((n, NSTEP_MAX), f32)      # total progress at sub-step s, slot s % n_steps
         self.action = np.zeros((n, 2), f32)
         self.steps = np.zeros(self.B, i32)         # sub-steps since reset
         self.agent_steps = np.zeros(self.B, i32)   # step() calls since reset
@@ -301,6 +314,7 @@ class OracleRaceEnv:
             self.lap[cars] = 1
             self.fresh[cars] = 1
             self.action[cars] = f32(0.0)
+            self.nstep_hist[cars, :] = p[:, None]
         self.steps[envs] = 0
         self.agent_steps[envs] = 0
         self.needs_reset[envs] = False
@@ -369,7 +383,14 @@ class OracleRaceEnv:
             self.cp[c] = np.where(fwd | bwd, cp_new, cp_old)
             self.lap[c], self.progress[c] = lap, p_new
             collided = (self.wall[c] | self.opp[c]).astype(bool)
-            if cfg.task == TASK_MAX_PROGRESS:
+            task = cfg.task_of(a)
+            if task == TASK_N_STEP_PROGRESS:
+                slot = self.steps[envs] % cfg.n_steps
+                total = (lap - 1).astype(f32) + p_new
+                r = (total - self.nstep_hist[c, slot]) * PROGRESS_REWARD
+                self.nstep_hist[c, slot] = total
+                done = np.zeros(envs.size, bool)
+            elif task == TASK_MAX_PROGRESS:
                 delta = (lap - lap_old).astype(f32) + (p_new - p_old)
                 r = delta * PROGRESS_REWARD + np.where(collided, f32(cfg.collision_reward), f32(0.0))
                 done = (collided & bool(cfg.terminate_on_collision)) | (lap > cfg.laps) | (time > tlim)

@@ -40,6 +40,7 @@ class RcConfig(C.Structure):
         ("time_limit_steps", C.c_int32), ("auto_reset", C.c_int32), ("lidar_transform", C.c_int32),
         ("external_arena", C.c_void_p),
         ("external_arena_bytes", C.c_size_t), ("stream", C.c_void_p),
+        ("car_task", C.c_int32 * 4), ("n_steps", C.c_int32),
     ]
 
 

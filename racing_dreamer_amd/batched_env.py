@@ -54,7 +54,7 @@ OBS_TYPES = {"lidar": 0, "lidar_occupancy": 1}
 # scaling fused into the scan's store: metres | dreamer (x/15 - 0.5, tools.py:274) | unit (x/15, single_agent.py:92-99)
 LIDAR_TRANSFORMS = {"metres": 0, "dreamer": 1, "unit": 2}
 TASKS = {"maximize_progress": spec.TASK_MAX_PROGRESS, "max_progress": spec.TASK_MAX_PROGRESS,
-         "max_speed": spec.TASK_MAX_SPEED}
+         "max_speed": spec.TASK_MAX_SPEED, "n_step_progress": spec.TASK_N_STEP_PROGRESS}
 
 
 class BatchedRaceEnv:
@@ -64,7 +64,10 @@ class BatchedRaceEnv:
                  terminate_on_collision: bool = True, collision_reward: float = -1.0,
                  remap_actions: bool = False, action_low=spec.ACTION_LOW, action_high=spec.ACTION_HIGH,
                  time_limit_steps: int = 0, auto_reset: bool = False, profiling: bool = False,
-                 lidar_transform: str = "metres"):
+                 lidar_transform: str = "metres", car_tasks=None, n_steps: int = 10):
+        """car_tasks: optional task name per car slot (agents A, B, ... of a scenario yml; None entries = `task`), e.g.
+        ["maximize_progress", "n_step_progress", ...] for baselines/scenarios/max_progress/columbia.yml; n_steps: the
+        window of `n_step_progress` in sub-steps."""
         if obs_type not in OBS_TYPES:
             raise ValueError(f"obs_type must be one of {sorted(OBS_TYPES)}, got {obs_type!r}")
         if task not in TASKS:
@@ -88,6 +91,12 @@ class BatchedRaceEnv:
         cfg.action_low[:] = [float(v) for v in action_low]
         cfg.action_high[:] = [float(v) for v in action_high]
         cfg.time_limit_steps, cfg.auto_reset = int(time_limit_steps), int(auto_reset)
+        for a, name in enumerate(car_tasks or ()):
+            if name is not None:
+                if name not in TASKS:
+                    raise ValueError(f"car_tasks[{a}] must be one of {sorted(TASKS)}, got {name!r}")
+                cfg.car_task[a] = TASKS[name]
+        cfg.n_steps = int(n_steps)
         if lidar_transform not in LIDAR_TRANSFORMS:
             raise ValueError(f"lidar_transform must be one of {sorted(LIDAR_TRANSFORMS)}, got {lidar_transform!r}")
         cfg.lidar_transform = LIDAR_TRANSFORMS[lidar_transform]

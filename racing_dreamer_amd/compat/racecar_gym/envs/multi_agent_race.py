@@ -56,6 +56,14 @@ class MultiAgentRaceEnv:
                   collision_reward=float(params.get("collision_reward", 0.0)))
         if not builtin:   # a host-side Task object decides reward/done: the device must not end the episode
             kw = dict(laps=2 ** 30, time_limit=3.0e38, terminate_on_collision=False, collision_reward=0.0)
+        # per-agent device tasks: e.g. A maximize_progress, B-D n_step_progress {n_steps: 10}
+        # (baselines/scenarios/max_progress/columbia.yml:9-10,17-18)
+        names = {0: "maximize_progress", 2: "n_step_progress"}
+        kw["car_tasks"] = [names[task_registry.BUILTIN_TASKS[a.task_name]] if a.task_name in task_registry.BUILTIN_TASKS
+                           else None for a in scenario.agents]
+        nsteps = [int(a.task_params["n_steps"]) for a in scenario.agents if "n_steps" in (a.task_params or {})]
+        if nsteps:
+            kw["n_steps"] = nsteps[0]
         self._env = _BACKEND(scenario.world.track, 1, len(self._ids), obs_type="lidar", device=device,
                                    seed=seed, **kw)
         self.observation_space = DictSpace({a.id: DictSpace({s: _SENSOR_SPACES[s]() for s in a.sensors})

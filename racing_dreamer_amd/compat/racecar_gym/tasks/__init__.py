@@ -16,7 +16,7 @@ class Task:
 
 
 # tasks evaluated on the device by the HIP kernels (name -> rc task id)
-BUILTIN_TASKS = {"maximize_progress": 0, "max_progress": 0, "n_step_progress": 0}
+BUILTIN_TASKS = {"maximize_progress": 0, "max_progress": 0, "n_step_progress": 2}
 _registry = {}
 
 

@@ -260,8 +260,13 @@ int check_cfg(const rc_config *cfg) {
         return fail(RC_ERR_INVALID, "unknown obs_type %d", cfg->obs_type);
     if (cfg->lidar_transform < RC_LIDAR_METRES || cfg->lidar_transform > RC_LIDAR_UNIT)
         return fail(RC_ERR_INVALID, "unknown lidar_transform %d", cfg->lidar_transform);
-    if (cfg->task != RC_TASK_MAX_PROGRESS && cfg->task != RC_TASK_MAX_SPEED)
+    if (cfg->task < RC_TASK_MAX_PROGRESS || cfg->task > RC_TASK_N_STEP_PROGRESS)
         return fail(RC_ERR_INVALID, "unknown task %d", cfg->task);
+    for (int a = 0; a < RC_MAX_CARS; ++a)
+        if (cfg->car_task[a] < -1 || cfg->car_task[a] > RC_TASK_N_STEP_PROGRESS)
+            return fail(RC_ERR_INVALID, "unknown car_task[%d] = %d", a, cfg->car_task[a]);
+    if (cfg->n_steps < 1 || cfg->n_steps > RC_NSTEP_MAX)
+        return fail(RC_ERR_INVALID, "n_steps must be in 1..%d (got %d)", RC_NSTEP_MAX, cfg->n_steps);
     return RC_OK;
 }
 
@@ -332,6 +337,8 @@ void rc_default_config(rc_config *cfg) {
     cfg->action_low[1] = -1.0f;
     cfg->action_high[0] = 1.0f;
     cfg->action_high[1] = 1.0f;
+    for (int a = 0; a < RC_MAX_CARS; ++a) cfg->car_task[a] = -1;      // every car runs `task`
+    cfg->n_steps = 10;                   // baselines/scenarios/max_progress/columbia.yml:18
 }
 
 size_t rc_arena_bytes(const rc_config *cfg) {
@@ -377,7 +384,13 @@ int rc_create(const rc_config *cfg, rc_env **out) {
 
     // simulator state: 10 float + 2 int + 6 byte arrays per car, 2 int + 1 uint per env
     const size_t nc = (size_t)align_up(n, 64), ne = (size_t)align_up(cfg->num_envs, 64);
-    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6) + ne * 12;
+    bool any_nstep = false;
+    for (int a = 0; a < RC_MAX_CARS; ++a) {
+        env->params.car_task[a] = cfg->car_task[a] < 0 ? cfg->task : cfg->car_task[a];
+        any_nstep |= a < cfg->cars_per_env && env->params.car_task[a] == RC_TASK_N_STEP_PROGRESS;
+    }
+    env->params.n_steps = cfg->n_steps;
+    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0);
     HIP_TRY_FREE(hipMalloc(&env->state_mem, state_bytes));
     HIP_TRY_FREE(hipMemsetAsync(env->state_mem, 0, state_bytes, env->stream));
     HIP_TRY_FREE(hipMalloc((void **)&env->mask_dev, ne));
@@ -393,6 +406,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         s.episode = (uint32_t *)m; m += ne * 4;
         uint8_t **bp[] = {&s.wall, &s.opp, &s.wrong, &s.done, &s.trunc, &s.fresh};
         for (uint8_t **b : bp) { *b = (uint8_t *)m; m += nc; }
+        s.nstep_hist = any_nstep ? (float *)m : nullptr;      // (nc * (48 + 6) + ne * 12 bytes in: 4-byte aligned)
     }
     bind_outputs(env, env->arena);
     env->actions_in = (float *)((char *)env->arena + env->layout.offset[RC_F_ACTION_IN]);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define RC_NSTEP_MAX 16                        // longest n_step_progress window (sub-steps)
 #define RC_FIRST_BINS 32                       // bins of |dy / dx|: four per octave over 2^-4 .. 2^4 (outer bins open-ended)
 #define RC_FIRST_SHIFT 21                      // slope bits >> 21 = (exponent << 2) | two mantissa bits
 #define RC_FIRST_BIAS (123u << 2)              // ... of 2^-4
@@ -40,6 +41,8 @@ struct RcStateDev {              // persistent per-car / per-env simulator state
     uint8_t *wall, *opp, *wrong, *done, *trunc, *fresh;
     int32_t *steps, *agent_steps;   // per env
     uint32_t *episode;              // per env
+    float *nstep_hist;              // [n_cars][RC_NSTEP_MAX] total progress at sub-step s in slot s % n_steps; null unless
+                                    // some car runs RC_TASK_N_STEP_PROGRESS
 };
 
 struct RcOutDev {                // output arena sections (see rc_field)
@@ -63,6 +66,8 @@ struct RcParams {
     float act_lo0, act_lo1, act_hi0, act_hi1;
     int32_t reset_mode;
     uint32_t seed_lo, seed_hi;
+    int32_t car_task[4];         // task per car slot (resolved: never -1)
+    int32_t n_steps;             // window of RC_TASK_N_STEP_PROGRESS [sub-steps]
 };
 
 struct RcLaunchInfo {            // per-handle launch geometry decided at rc_load_track

@@ -124,6 +124,10 @@ __device__ __forceinline__ void reset_env(const RcParams &p, int e, Car (&car)[A
         c.wall = c.opp = c.wrong = c.done = c.trunc = 0;
         c.lap = 1;
         c.fresh = 1;
+        if (p.car_task[a] == 2) {                 // n_step_progress: the window starts at the spawn progress
+            float *h = p.st.nstep_hist + (size_t)(e * A + a) * RC_NSTEP_MAX;
+            for (int k = 0; k < RC_NSTEP_MAX; ++k) h[k] = pr;
+        }
     }
     steps = 0;
     agent_steps = 0;
@@ -296,7 +300,16 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
                 const bool collided = (c.wall | c.opp) != 0;
                 float r;
                 bool done;
-                if (p.task == 0) {
+                const int task = p.car_task[a];
+                if (task == 2) {
+                    // n_step_progress, the secondary agents' task of baselines/scenarios/max_progress/columbia.yml:17-18:
+                    // total progress gained over the last n_steps sub-steps, no collision term, never done
+                    float *h = p.st.nstep_hist + (size_t)(e * A + a) * RC_NSTEP_MAX + (steps % p.n_steps);
+                    const float total = (float)(lap - 1) + p_new;
+                    r = (total - *h) * RCS_PROGRESS_REWARD;
+                    *h = total;
+                    done = false;
+                } else if (task == 0) {
                     const float delta = (float)(lap - lap_old) + (p_new - p_old);
                     r = delta * RCS_PROGRESS_REWARD + (collided ? p.collision_reward : 0.0f);
                     done = (collided && p.terminate_on_collision) || lap > p.laps || time > p.time_limit;

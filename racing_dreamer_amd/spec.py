@@ -34,7 +34,8 @@ FOOTPRINT_LONG_PTS, FOOTPRINT_SHORT_PTS = 12, 5
 # --- task (dreamer/scenarios/max_progress/columbia.yml:9-10) ------------------------
 N_CHECKPOINTS = 20            # (free)
 PROGRESS_REWARD = 100.0       # (free; racecar_gym default)
-TASK_MAX_PROGRESS, TASK_MAX_SPEED = 0, 1
+TASK_MAX_PROGRESS, TASK_MAX_SPEED, TASK_N_STEP_PROGRESS = 0, 1, 2
+NSTEP_MAX = 16                   # longest n_step_progress window [sub-steps]
 
 # --- lidar_occupancy patch (dreamer/wrappers.py:374-378,398-405) --------------------
 PATCH = 64

@@ -9,7 +9,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _run_pair(track_name, num_envs, cars, steps, repeat, obs_type="lidar", mode="random", seed=7, auto_reset=True,
-              time_limit_steps=0, task="maximize_progress", remap=False, act_seed=11):
+              time_limit_steps=0, task="maximize_progress", remap=False, act_seed=11, car_tasks=None, n_steps=10):
     import torch
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
     from racing_dreamer_amd.track_assets import load_track
@@ -17,10 +17,13 @@ def _run_pair(track_name, num_envs, cars, steps, repeat, obs_type="lidar", mode=
     track = load_track(track_name)
     occ = obs_type == "lidar_occupancy"
     env = BatchedRaceEnv(track, num_envs, cars, obs_type=obs_type, auto_reset=auto_reset,
-                         time_limit_steps=time_limit_steps, task=task, remap_actions=remap)
+                         time_limit_steps=time_limit_steps, task=task, remap_actions=remap, car_tasks=car_tasks,
+                         n_steps=n_steps)
+    ids = {None: -1, "maximize_progress": 0, "max_speed": 1, "n_step_progress": 2}
     ora = make_oracle(track, num_envs=num_envs, cars_per_env=cars, auto_reset=auto_reset, render_occupancy=occ,
                       time_limit_steps=time_limit_steps, task=spec.TASK_MAX_SPEED if task == "max_speed" else 0,
-                      remap_actions=remap)
+                      remap_actions=remap, car_tasks=None if car_tasks is None else [ids[t] for t in car_tasks],
+                      n_steps=n_steps)
     dv = env.reset(mode=mode, seed=seed)
     ov = ora.reset(mode=spec.RESET_MODES[mode], seed=seed)
     compare_outputs(dv, ov, num_envs, cars, f"{track_name} reset")
@@ -68,6 +71,13 @@ def test_four_cars():
 def test_grid_reset_no_autoreset_time_limit_and_remap():
     _run_pair("columbia", num_envs=32, cars=1, steps=30, repeat=4, mode="grid", auto_reset=False,
               time_limit_steps=20, remap=True)
+
+
+def test_secondary_agents_run_n_step_progress():
+    """The 4-agent scenario of baselines/scenarios/max_progress/columbia.yml: A maximize_progress, B-D n_step_progress."""
+    _run_pair("columbia", num_envs=40, cars=4, steps=25, repeat=2, mode="random_ball",
+              car_tasks=["maximize_progress", "n_step_progress", "n_step_progress", "n_step_progress"])
+    _run_pair("austria", num_envs=33, cars=2, steps=12, repeat=4, car_tasks=[None, "n_step_progress"], n_steps=7)
 
 
 def test_max_speed_task():

@@ -199,6 +199,32 @@ def test_c_oracle_max_speed_task_matches():
         assert np.array_equal(oa["reward"], ob["reward"]) and np.all(oa["done"] == 0)
 
 
+def test_n_step_progress_task_of_the_secondary_agents():
+    """baselines/scenarios/max_progress/columbia.yml:17-18: agents B-D run `n_step_progress {n_steps: 10}`.  Spec:
+    reward = 100 x total progress gained over the last n sub-steps (since the reset while younger), never done, no
+    collision term; car A keeps maximize_progress.  Known answer from the recorded progress, and C == NumPy."""
+    t = load_track("columbia")
+    cfg = ro.OracleConfig(num_envs=6, cars_per_env=3, car_tasks=[-1, ro.TASK_N_STEP_PROGRESS, ro.TASK_N_STEP_PROGRESS],
+                          n_steps=10, terminate_on_collision=False)
+    a = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg)
+    b = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg)
+    oa, ob = a.reset(mode=0), b.reset(mode=0)
+    totals = [oa["progress_total"].astype(np.float32).copy()]
+    for k in range(25):
+        act = np.tile(np.array([[0.7, 0.02 * (k % 3)]], np.float32), (18, 1))
+        oa, ob = a.step(act), b.step(act)
+        for name in ("reward", "done", "progress_total", "pose"):
+            assert np.array_equal(oa[name], ob[name]), (name, k)
+        totals.append(oa["progress_total"].copy())
+        back = totals[max(k + 1 - 10, 0)]
+        want = (totals[-1] - back) * np.float32(100.0)
+        sec = np.arange(18) % 3 != 0
+        assert np.array_equal(oa["reward"][sec], want[sec]) and not oa["done"][sec].any()
+        first = oa["reward"][~sec]
+        assert np.allclose(first, (totals[-1] - totals[-2])[~sec] * 100.0, atol=1e-4)
+    assert (totals[-1] - totals[-11] > 0).all() and (oa["reward"][sec] > 0).all()      # the cars did move
+
+
 def test_two_cars_see_and_hit_each_other():
     t = synthetic_track()
     env = make_oracle(t, num_envs=1, cars_per_env=2)
