@@ -8,8 +8,11 @@
 A "step" is one pass of the hot path over one batch: random actions (Philox, on device) ->
 integrator + collision + progress/reward/done + auto-reset -> 1080-beam LiDAR scan, for 65 536 envs
 per GPU (weak scaling), action_repeat 1, so one step = one simulator sub-step (dt = 0.01 s) of every
-env.  For N > 1 every step's record also goes into the overlapped RCCL all-gather of the trajectory slab.
-Prints ONE JSON line on rank 0.
+env.  For N > 1 every step's trajectory record also goes into the overlapped RCCL all-gather; the
+payload is named in config.workload (`full-u16` by default: the whole record with the LiDAR row as
+uint16 written by the scan - never the LiDAR-less `summary` unless asked for).
+Prints ONE JSON line on rank 0; at N = 1 the line also carries the other single-GPU configurations
+of BASELINE.json (`configs`) and the CPU baseline.
 """
 from __future__ import annotations
 
@@ -27,6 +30,7 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 RAYCAST_BYTES_PER_CAR = 4 * 1080 + 16       # lidar row written + (x, y, cos, sin) read, DESIGN.md §5
 STEP_BYTES_PER_CAR = 4 * 1080 + 159         # whole env-step, obs_type=lidar
 PATCH_BYTES_PER_CAR = 4096
+GATHER_MODES = ("full-u16", "full", "summary", "none")
 
 
 def parse_args():
@@ -41,20 +45,28 @@ def parse_args():
                     help="BASELINE.json configs[4]: rank r runs track [columbia, austria, barcelona][r mod 3]")
     ap.add_argument("--obs-type", default="lidar", choices=["lidar", "lidar_occupancy"])
     ap.add_argument("--repeat", type=int, default=1, help="action repeat (sub-steps per step)")
-    ap.add_argument("--gather", default="summary", choices=["summary", "full", "none"],
-                    help="N>1: what the per-step RCCL all-gather carries. summary = the transition record without "
-                         "the LiDAR row (pose, velocity, speed, action, reward, discount, progress, time: 76 B/car; "
-                         "the scans stay sharded in each rank's HBM); full = the whole 4 396 B/car record (xGMI-bound: "
-                         "DESIGN.md §6); none = no collective")
-    ap.add_argument("--gather-every", type=int, default=4,
-                    help="N>1: steps per all-gather (each collective carries that many per-step records; same bytes, fewer launches)")
+    ap.add_argument("--gather", default="full-u16", choices=GATHER_MODES,
+                    help="N>1: what the per-step RCCL all-gather carries. full-u16 (default) = the whole transition record "
+                         "with the LiDAR row as uint16 written by the scan's store path (2 236 B/car); full = the fp32 "
+                         "record (4 396 B/car); summary = the record without the LiDAR row (76 B/car, the scans stay "
+                         "sharded in each rank's HBM); none = no collective.  All but `none` are xGMI-bound at this "
+                         "simulation rate: DESIGN.md §6 has the table")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="N>1: steps per all-gather (each collective carries that many per-step records: same bytes, "
+                         "fewer launches; needs staging copies, so 1 - no copy, the collective reads the record in "
+                         "place - is the default)")
+    ap.add_argument("--gather-via", default="torch", choices=["torch", "abi"],
+                    help="transport of the collective: torch.distributed (RCCL inside PyTorch) or the C-ABI's own "
+                         "rc_gather_trajectory (RCCL bound by libracecar_hip.so; unique id passed through torch.distributed)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
+    ap.add_argument("--no-gather-modes", action="store_true", help="N>1: skip the short legs that time the other gather modes")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for functional tests on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ftg", dest="no_cpu_baseline_ftg", action="store_true", help="skip the follow-the-gap secondary figure")
+    ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations of BASELINE.json")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
     ap.add_argument("--raycast-variant", type=int, default=None)
     ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
@@ -66,6 +78,86 @@ def cpu_baseline(track, cars, obs_type, repeat, n_envs):
     """The CPU oracle timed on this host's cores on a bounded sample of the same workload."""
     from oracle import cpu_baseline as cb
     return cb.run(track, cars=cars, occupancy=(obs_type == "lidar_occupancy"), repeat=repeat, n_envs=n_envs)
+
+
+class Gatherer:
+    """One gather mode of the N > 1 run: where the record lies, how it is sent, what it costs on the links."""
+
+    def __init__(self, env, mode, every, via, dist_mod):
+        from racing_dreamer_amd.distributed import TrajectoryGather, gather_link_model
+        self.env, self.mode, self.via = env, mode, via
+        self.world = dist_mod.get_world_size()
+        if mode == "full-u16" and getattr(env, "compact", None) is None:
+            env.enable_compact(buffers=2)
+        src = env.gather_source(mode)
+        self.bytes = int(src.numel())
+        self.model = gather_link_model(self.bytes, self.world)
+        self.in_place = every == 1 and mode == "full-u16"       # double-buffered source: no staging copy
+        self.tg = None
+        if via == "torch":
+            self.tg = TrajectoryGather(src, every=every, stage=not self.in_place)
+        else:
+            import torch
+            self.dst = torch.empty(self.world * self.bytes, dtype=torch.uint8, device=env.device)
+
+    def after_step(self):
+        env = self.env
+        if self.via == "abi":
+            env.gather_wait(host_sync=False)            # the previous collective wrote `dst`; order behind it
+            env.gather(self.mode, self.dst)
+        else:
+            self.tg.launch(env.gather_source(self.mode))
+        if self.mode == "full-u16":
+            env.rotate_compact()
+
+    def wait(self):
+        if self.via == "abi":
+            self.env.gather_wait(host_sync=True)
+        else:
+            self.tg.wait()
+
+
+def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="random"):
+    """One of BASELINE.json's other single-GPU configurations on the current device: ms per step, per-kernel times
+    from launch-attached HIP events, whole-step and per-kernel HBM-roofline fractions."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv(track_name, envs, cars, obs_type=obs_type, auto_reset=True)
+    env.reset(mode=mode, seed=0)
+    torch.cuda.set_stream(env.stream)
+    for k in range(warmup):
+        env.step_random(seed=1, step=k)
+    env.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step_random(seed=1, step=warmup + k)
+    env.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    env.reset_kernel_times()
+    env.set_profiling(True)
+    for k in range(min(steps, 40)):
+        env.step_random(seed=1, step=warmup + steps + k)
+    env.sync()
+    env.set_profiling(False)
+    kt = {k: round(v["avg_ms"], 4) for k, v in env.kernel_times().items() if v["launches"]}
+    env.close()
+    n_cars = envs * cars
+    step_bytes = (STEP_BYTES_PER_CAR + (PATCH_BYTES_PER_CAR if obs_type == "lidar_occupancy" else 0)) * n_cars
+    ms = dt / steps * 1e3
+    out = {"workload": name, "envs": envs, "cars_per_env": cars, "track": track_name, "obs_type": obs_type,
+           "steps": steps, "ms_per_step": ms, "env_steps_per_s": envs * steps / dt, "kernels_ms": kt,
+           "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                        "step_bytes": step_bytes, "step_achieved": step_bytes / (ms * 1e-3) / 1e9,
+                        "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+    if kt.get("rc_raycast_kernel"):
+        a = RAYCAST_BYTES_PER_CAR * n_cars / (kt["rc_raycast_kernel"] * 1e-3) / 1e9
+        out["roofline"]["raycast_achieved"], out["roofline"]["raycast_frac"] = a, a / HBM_PEAK_GBS
+    if kt.get("rc_patch_kernel"):
+        a = PATCH_BYTES_PER_CAR * n_cars / (kt["rc_patch_kernel"] * 1e-3) / 1e9
+        out["roofline"]["patch_achieved"], out["roofline"]["patch_frac"] = a, a / HBM_PEAK_GBS
+    return out
 
 
 def main():
@@ -89,8 +181,9 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    from racing_dreamer_amd import _lib as L
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
-    from racing_dreamer_amd.distributed import TrajectoryGather, shard_envs
+    from racing_dreamer_amd.distributed import gather_link_model, shard_envs
     from racing_dreamer_amd.track_assets import load_track
 
     track_name = ["columbia", "austria", "barcelona"][rank % 3] if args.mixed_tracks else args.track
@@ -99,24 +192,32 @@ def main():
     env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
                          device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
     if args.raycast_variant is not None:
-        from racing_dreamer_amd import _lib as L
         L.check(env._lib.rc_set_raycast_variant(env._h, args.raycast_variant))
     for kv in args.debug_knob:
         name, _, val = kv.partition("=")
         env.debug_set(name, int(val))
     env.reset(mode="random", seed=0)
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
-    gather_src = {"none": None, "full": env.slab, "summary": env.summary_slab}[gather_mode]
-    gather = TrajectoryGather(gather_src, every=max(1, args.gather_every)) if gather_src is not None else None
+    via = args.gather_via
+    if distributed and via == "abi":
+        if args.backend != "nccl":
+            via = "torch"                       # RCCL wants one GPU per rank; the gloo functional tests share one
+        else:
+            ids = [BatchedRaceEnv.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            env.comm_init(ids[0], rank, world)
+    every = max(1, args.gather_every)
+    gather = Gatherer(env, gather_mode, every, via, dist) if gather_mode != "none" else None
 
     # the rollout loop works on the env's own stream (no cross-stream event waits between the step's kernels and
-    # the staging copy of the gather); `barrier()` synchronises the whole device
+    # the collective's dependency on them); `barrier()` synchronises the whole device
     torch.cuda.set_stream(env.stream)
 
-    def one_step(k, repeat=None):
+    def one_step(k, repeat=None, g=None):
         env.step_random(seed=1, step=k, repeat=repeat)        # actions drawn inside the dynamics kernel (Philox, on device)
-        if gather is not None:
-            gather.launch(gather_src)
+        g = gather if g is None else g
+        if g:
+            g.after_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,7 +231,6 @@ def main():
         gather.wait()
     env.sync()
     env.reset_kernel_times()
-    from racing_dreamer_amd import _lib as L
     # start / stop timestamps attached to every launch of the DOMINANT kernel (the scan) on the stream it runs on;
     # timing the two small kernels as well would cost the timed region 6 us per step, so they get a pass of their
     # own after it
@@ -158,6 +258,31 @@ def main():
     for name, v in env.kernel_times().items():
         if name != "rc_raycast_kernel":
             ktimes[name] = v
+    step_no = args.warmup + 2 * args.steps
+
+    # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
+    # sequence): what the headline's choice of payload costs, measured rather than argued
+    mode_legs = {}
+    if distributed and not args.no_gather_modes:
+        n_leg = max(args.steps // 4, 5)
+        for m in GATHER_MODES:
+            if m == gather_mode:
+                continue
+            g = Gatherer(env, m, every, via, dist) if m != "none" else False
+            for k in range(3):
+                one_step(step_no + k, g=g)
+            if g:
+                g.wait()
+            barrier()
+            t1 = time.perf_counter()
+            for k in range(n_leg):
+                one_step(step_no + 3 + k, g=g)
+            if g:
+                g.wait()
+            env.sync()
+            barrier()
+            mode_legs[m] = [time.perf_counter() - t1, n_leg]
+            step_no += 3 + n_leg
 
     # secondary figure: the reference's own setting, action_repeat 4 with the scan once per agent step
     # (dreamer/dream.py:55) - a quarter of the steps, same barriers
@@ -165,7 +290,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     for k in range(r4_steps):
-        one_step(args.warmup + 2 * args.steps + k, repeat=4)
+        one_step(step_no + k, repeat=4)
     if gather is not None:
         gather.wait()
     env.sync()
@@ -204,15 +329,20 @@ def main():
                        "line, long rays) instead of random actions; includes the agent's kernel"}
 
     if distributed:
-        tmax = torch.tensor([dt, dt4], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        times = [dt, dt4] + [v[0] for v in mode_legs.values()]
+        tmax = torch.tensor(times, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt, dt4 = float(tmax[0].item()), float(tmax[1].item())
+        times = [float(v) for v in tmax.tolist()]
+        dt, dt4 = times[0], times[1]
+        for (m, v), t in zip(mode_legs.items(), times[2:]):
+            v[0] = t
 
     total_envs = args.envs * world
     env_steps = total_envs * args.steps * args.repeat
     value = env_steps / dt
+    n_cars = shard.num_envs * args.cars
+    out = None
     if rank == 0:
-        n_cars = shard.num_envs * args.cars
         ray = ktimes["rc_raycast_kernel"]
         # the symbol rocprofv3 lists: the default scan (variant 7) is rc_raycast_car_kernel<A>, variants 0-6 rc_raycast_kernel<A, V>
         variant = 7 if args.raycast_variant is None else args.raycast_variant
@@ -226,6 +356,15 @@ def main():
                 prof = json.load(f)
             traffic = prof.get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
             valu = prof.get("_valu_wave_insts", {}).get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
+        if not distributed:
+            gather_txt = "no collective (one rank)"
+        elif gather is None:
+            gather_txt = "NO trajectory gather (--gather none)"
+        else:
+            gather_txt = (f"every step's trajectory record all-gathered over RCCL as `{gather_mode}` ({gather.bytes} B per GPU "
+                          f"per step, {'read in place from a double-buffered slab' if gather.in_place else 'from staging copies'}, "
+                          f"one collective per {every} step{'s' if every > 1 else ''}, transport {via}, overlapped with the "
+                          f"following step; the gathered buffer is overwritten by the next collective - no consumer in this benchmark)")
         out = {
             "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -235,14 +374,11 @@ def main():
                 "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
                             f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
                             f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
-                            f"auto-reset, action_repeat {args.repeat}",
+                            f"auto-reset, action_repeat {args.repeat}; {gather_txt}",
                 "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
                 "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
                 "obs_type": args.obs_type, "action_repeat": args.repeat,
-                "parallelism": f"env-sharded x{world}" + ("" if gather is None else
-                                f" + overlapped RCCL all-gather of the {gather_mode} trajectory record of every step, "
-                                f"one collective per {max(1, args.gather_every)} steps ({gather_src.numel()} B per GPU per step)"),
-                "gather": gather_mode,
+                "parallelism": f"env-sharded x{world}", "gather": gather_mode,
             },
             "roofline": {
                 "bound": "hbm", "kernel": ray_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
@@ -262,12 +398,36 @@ def main():
                                 "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
                                 "note": "same workload with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55)"},
         }
+        if distributed:
+            # every payload next to its link bound (xGMI full mesh, 7 links x 76.8 GB/s inbound per GPU)
+            sizes = {"full": int(env.slab.numel()), "summary": int(env.summary_slab.numel()),
+                     "full-u16": int(env._lib.rc_compact_bytes(env._cfg)), "none": 0}
+            table = {}
+            for m in GATHER_MODES:
+                e = gather_link_model(sizes[m], world)
+                if m == gather_mode:
+                    e.update(ms_per_step=dt / args.steps * 1e3, env_steps_per_s=value, steps=args.steps, headline=True)
+                elif m in mode_legs:
+                    t, n = mode_legs[m]
+                    e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n)
+                table[m] = e
+            out["gather_modes"] = table
         if ftg is not None:
             out["follow_the_gap"] = ftg
+    env.close()
+    if rank == 0:
+        if world == 1 and not args.no_configs:
+            # BASELINE.json configs[1..3], each a few ms of GPU time (configs[0] is the CPU plumbing case, configs[4]
+            # the 8-GPU run: `--gpus 8 --mixed-tracks`)
+            cfgs = [("configs[1]: 4 096 envs, columbia, 1080-beam lidar", "columbia", 4096, 1, "lidar", 400, 40, "random"),
+                    ("configs[2]: 65 536 envs, austria, obs_type=lidar_occupancy (64x64 render)", "austria", 65536, 1,
+                     "lidar_occupancy", 100, 10, "random"),
+                    ("configs[3]: 32 768 envs x 2 cars, treitlstrasse_v2, inter-car raycast + collision",
+                     "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
+            out["configs"] = [time_config(*c) for c in cfgs]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
         print(json.dumps(out), flush=True)
-    env.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

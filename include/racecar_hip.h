@@ -21,6 +21,10 @@
  *   RC_F_OCCUPANCY .............. OccupancyMapObs.step                     dreamer/wrappers.py:390-408
  *   rc_trajectory_slab .......... the per-step transition Collect.step records
  *                                 dreamer/wrappers.py:213-219 (+ dreamer/callbacks.py:41-53)
+ *   rc_gather_trajectory ........ the concatenation of those records over all envs, which in the reference is
+ *                                 one process appending to one episode list (dreamer/wrappers.py:220-226,
+ *                                 dreamer/tools.py:235-264 reads them back); here the envs live on several GPUs
+ *                                 and the concat is an RCCL all-gather
  *
  * Conventions
  *   - every function returns RC_OK (0) or a negative rc_status; the message of the last
@@ -57,7 +61,8 @@ typedef enum rc_status {
     RC_ERR_HIP = -2,          /* a HIP runtime call failed            */
     RC_ERR_NO_TRACK = -3,     /* rc_load_track has not been called    */
     RC_ERR_NEEDS_RESET = -4,  /* step before reset ("Must reset environment.", wrappers.py:148) */
-    RC_ERR_NOMEM = -5
+    RC_ERR_NOMEM = -5,
+    RC_ERR_COMM = -6          /* RCCL could not be loaded or a collective call failed */
 } rc_status;
 
 enum { RC_TASK_MAX_PROGRESS = 0, RC_TASK_MAX_SPEED = 1,             /* scenario yml task_name; tasks.py:4-22 */
@@ -185,6 +190,39 @@ int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes);
 /* The trajectory record of the last step as one contiguous device slab (fields LIDAR..TIME,
  * plus OCCUPANCY when enabled): the source buffer of the multi-GPU all-gather. */
 int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes);
+
+/* ---- Half-size record and multi-GPU gather -------------------------------------------------------
+ * The record of a step is 4 396 B per car, 4 320 of them the fp32 LiDAR row.  rc_set_compact_slab makes the scan
+ * store a second copy of the row as uint16 - q = rne((v + off) * scale) with (off, scale) = (0, 65535/15) for
+ * RC_LIDAR_METRES, (0.5, 65535) for RC_LIDAR_DREAMER, (0, 65535) for RC_LIDAR_UNIT: 0.23 mm per count, below the
+ * 0.05 m map cell by two orders of magnitude - into a caller-owned device buffer, followed by a copy of the arena's
+ * POSE..TIME sections (76 B per car): 2 236 B per car, the payload of RC_GATHER_FULL_U16.  Layout of the buffer:
+ * uint16 [n][1080], padding to 64 B, then the POSE..TIME sections exactly as they lie in the arena
+ * (rc_compact_layout gives the offsets).  NULL switches it off.  Alternate two buffers to overlap a gather with
+ * the next step. */
+size_t rc_compact_bytes(const rc_config *cfg);
+int rc_set_compact_slab(rc_env *env, void *slab, size_t bytes);
+int rc_compact_layout(rc_env *env, size_t *lidar_u16_bytes, size_t *summary_offset, size_t *summary_bytes);
+
+/* The communicator: one rank per handle (= per GPU).  Rank 0 calls rc_comm_unique_id and hands the 128 bytes to the
+ * other ranks by any means (file, socket, MPI, torch.distributed store); every rank then calls rc_comm_init.  RCCL is
+ * bound at run time: the first of librccl.so.1 / librccl.so / /opt/rocm/lib that is already loaded in the process or
+ * can be loaded, or the path given to rc_comm_library before the first use. */
+int rc_comm_library(const char *path);
+int rc_comm_unique_id(void *out_128_bytes, size_t bytes);
+int rc_comm_init(rc_env *env, const void *unique_id, size_t bytes, int32_t rank, int32_t world);
+
+/* All-gather of the last step's record over the communicator: dev_dst receives world x rc_gather_bytes(mode) bytes,
+ * rank r's record at r * rc_gather_bytes(mode).  RC_GATHER_FULL = the rc_trajectory_slab bytes (fp32 LiDAR),
+ * RC_GATHER_FULL_U16 = the compact slab, RC_GATHER_SUMMARY = POSE..TIME only (the scans stay on their GPU).
+ * Asynchronous: queued behind the work already on the handle's stream, runs on a stream of its own so that the next
+ * steps overlap it - the caller must not let them overwrite the source (rc_set_arena / rc_set_compact_slab to the
+ * other buffer of a pair) nor reuse dev_dst before rc_gather_wait.  rc_gather_wait orders the handle's stream behind
+ * the collective; with host_sync != 0 it also blocks the host until the gathered bytes are there. */
+enum { RC_GATHER_FULL = 0, RC_GATHER_FULL_U16 = 1, RC_GATHER_SUMMARY = 2 };
+size_t rc_gather_bytes(rc_env *env, int32_t mode);
+int rc_gather_trajectory(rc_env *env, int32_t mode, void *dev_dst, size_t dst_bytes);
+int rc_gather_wait(rc_env *env, int32_t host_sync);
 
 /* Re-point the output fields (everything rc_get returns except RC_F_ACTION_IN, which stays where it is) at
  * another device buffer of at least rc_arena_bytes(), 64-byte aligned; NULL = back to the handle's own arena.

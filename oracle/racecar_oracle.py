@@ -173,6 +173,15 @@ def random_actions(seed, step, n_cars, first_car=0):
     return (u * f32(2.0) - f32(1.0)).astype(f32)
 
 
+def quantise_lidar_u16(lidar, transform=0):
+    """The uint16 copy of a LiDAR row in the half-size trajectory record (include/racecar_hip.h, rc_set_compact_slab):
+    q = rne(fl(fl(v + off) * scale)), (off, scale) = (0, 65535/15) for metres, (0.5, 65535) for the Dreamer scaling
+    (dreamer/tools.py:274), (0, 65535) for the unit scaling (single_agent.py:92-99)."""
+    off, scale = {0: (f32(0.0), f32(65535.0) / f32(15.0)), 1: (f32(0.5), f32(65535.0)), 2: (f32(0.0), f32(65535.0))}[transform]
+    t = (np.asarray(lidar, f32) + off) * scale
+    return np.rint(t).astype(np.uint16)        # np.rint rounds half to even, like the kernel's 2^23 add
+
+
 def follow_the_gap(lidar, motor_straight=0.6, motor_corner=0.3):
     """Batched follow-the-gap (fp32 spec of racing_dreamer_amd's rc_follow_the_gap; interface of
     agents.gap_follower.GapFollower used by dreamer/dream.py:211-216): float32 [n, 2] = (motor, steering)."""

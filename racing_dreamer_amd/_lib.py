@@ -21,6 +21,9 @@ RC_MAX_CARS = 4
  F_PROGRESS, F_LAP, F_CHECKPOINT, F_DONE, F_TRUNCATED, F_WALL_COLLISION, F_OPPONENT_COLLISION, F_WRONG_WAY,
  F_FRESH, F_ACCELERATION, F_STEERING_ANGLE, F_ACTION_IN, F_COUNT) = range(23)
 
+GATHER_FULL, GATHER_FULL_U16, GATHER_SUMMARY = range(3)
+GATHER_MODES = {"full": GATHER_FULL, "full-u16": GATHER_FULL_U16, "summary": GATHER_SUMMARY}
+
 # rc_debug_set knobs (experiments / validation only; all 0 in production)
 DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2 = range(4)
 DEBUG_KNOBS = {"ray_threads": DBG_RAY_THREADS, "ray_split": DBG_RAY_SPLIT, "ray_wg_per_cu": DBG_RAY_WG_PER_CU,
@@ -70,6 +73,15 @@ SYMBOLS = {
     "rc_reset_kernel_times": (C.c_int, [C.c_void_p]),
     "rc_set_raycast_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "rc_debug_set": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rc_compact_bytes": (C.c_size_t, [_P(RcConfig)]),
+    "rc_set_compact_slab": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rc_compact_layout": (C.c_int, [C.c_void_p, _P(C.c_size_t), _P(C.c_size_t), _P(C.c_size_t)]),
+    "rc_comm_library": (C.c_int, [C.c_char_p]),
+    "rc_comm_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rc_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32]),
+    "rc_gather_bytes": (C.c_size_t, [C.c_void_p, C.c_int32]),
+    "rc_gather_trajectory": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
+    "rc_gather_wait": (C.c_int, [C.c_void_p, C.c_int32]),
     "rc_spec_tables": (None, [C.c_void_p, C.c_void_p]),
     "rc_set_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

@@ -232,6 +232,72 @@ class BatchedRaceEnv:
         7 = the same with one wave per car (default).  All variants return identical results."""
         L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
 
+    # ------------------------------------------------------------------ half-size record + multi-GPU gather
+    def enable_compact(self, buffers: int = 2) -> None:
+        """Make the scan also store the LiDAR row as uint16, followed by the 76 B/car summary (`rc_set_compact_slab`):
+        the 2 236 B/car record of the `full-u16` gather.  `buffers` slabs take turns (`rotate_compact`), so a gather
+        of slab k overlaps the step that fills slab k + 1."""
+        nbytes = self._lib.rc_compact_bytes(C.byref(self._cfg))
+        self._compact = []
+        for _ in range(max(1, int(buffers))):
+            raw = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
+            pad = (-raw.data_ptr()) % 64
+            self._compact.append((raw, raw[pad:pad + nbytes]))
+        self._compact_k = 0
+        a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        L.check(self._lib.rc_compact_layout(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        self.compact_layout = (a.value, b.value, c.value)       # uint16 bytes, summary offset, summary bytes
+        self.compact = self._compact[0][1]
+        L.check(self._lib.rc_set_compact_slab(self._h, self.compact.data_ptr(), nbytes))
+
+    def rotate_compact(self) -> torch.Tensor:
+        """Point the next step's compact record at the next slab of the set; returns the slab just completed."""
+        done = self.compact
+        self._compact_k = (self._compact_k + 1) % len(self._compact)
+        self.compact = self._compact[self._compact_k][1]
+        L.check(self._lib.rc_set_compact_slab(self._h, self.compact.data_ptr(), self.compact.numel()))
+        return done
+
+    def disable_compact(self) -> None:
+        L.check(self._lib.rc_set_compact_slab(self._h, None, 0))
+        self.compact = None
+
+    def gather_source(self, mode: str) -> torch.Tensor:
+        """The bytes one gather mode sends: 'full' (fp32 record), 'full-u16' (compact slab), 'summary' (pose..time)."""
+        if mode == "full":
+            return self.slab
+        if mode == "summary":
+            return self.summary_slab
+        if mode == "full-u16":
+            if getattr(self, "compact", None) is None:
+                raise L.RacecarHipError("gather mode 'full-u16' needs enable_compact() first")
+            return self.compact
+        raise ValueError(f"unknown gather mode {mode!r}")
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        """RCCL communicator of this handle (`rc_comm_init`); `unique_id` from `comm_unique_id()` on rank 0."""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        L.check(self._lib.rc_comm_init(self._h, buf, 128, int(rank), int(world)))
+        self.comm_world = int(world)
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        lib = L.load_library()
+        buf = C.create_string_buffer(128)
+        L.check(lib.rc_comm_unique_id(buf, 128))
+        return buf.raw
+
+    def gather(self, mode: str, dst: torch.Tensor) -> None:
+        """`rc_gather_trajectory`: asynchronous RCCL all-gather of the last step's record into `dst` (uint8,
+        world x gather_bytes(mode))."""
+        L.check(self._lib.rc_gather_trajectory(self._h, L.GATHER_MODES[mode], dst.data_ptr(), dst.numel()))
+
+    def gather_bytes(self, mode: str) -> int:
+        return int(self._lib.rc_gather_bytes(self._h, L.GATHER_MODES[mode]))
+
+    def gather_wait(self, host_sync: bool = True) -> None:
+        L.check(self._lib.rc_gather_wait(self._h, int(bool(host_sync))))
+
     def debug_set(self, knob: str, value: int) -> None:
         """Experiment / validation knobs of the scan (`rc_debug_set`; 0 = production behaviour): ray_threads,
         ray_split, ray_wg_per_cu, band_log2.  Used by tools/knob_sweep.sh and the band-sensitivity check of

@@ -1,6 +1,7 @@
 // C-ABI of libracecar_hip.so (declared in include/racecar_hip.h): handle, device buffers,
 // stream-ordered launches.  No exceptions cross the boundary; errors are codes + rc_last_error().
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -39,6 +40,8 @@ int fail(int code, const char *fmt, ...) {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+struct RcUid { char internal[128]; };      // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
+
 // bytes per car of every rc_field, in arena order
 const size_t kFieldBytes[RC_F_COUNT] = {
     RC_N_BEAMS * 4, 24, 24, 4, 8, 4, 4, 4, 4, RC_PATCH * RC_PATCH,   // LIDAR .. OCCUPANCY
@@ -66,6 +69,35 @@ Layout make_layout(int n_cars, bool occupancy) {
     l.total = off;
     return l;
 }
+
+// The half-size trajectory record (rc_set_compact_slab): uint16 LiDAR rows, then a copy of the arena's POSE..TIME
+// sections (same relative layout, 64-byte aligned sections).
+struct CompactLayout {
+    size_t lidar_bytes;      // n * 1080 * 2, rounded up to 64
+    size_t summary_src_off;  // offset of RC_F_POSE in the arena
+    size_t summary_bytes;    // RC_F_POSE .. end of RC_F_TIME
+    size_t total;
+};
+
+CompactLayout make_compact(const Layout &l, int n_cars) {
+    CompactLayout c{};
+    c.lidar_bytes = align_up((size_t)n_cars * RC_N_BEAMS * 2, 64);
+    c.summary_src_off = l.offset[RC_F_POSE];
+    c.summary_bytes = l.offset[RC_F_TIME] + l.bytes[RC_F_TIME] - l.offset[RC_F_POSE];
+    c.total = align_up(c.lidar_bytes + c.summary_bytes, 64);
+    return c;
+}
+
+// ---- RCCL, bound at run time (rc_comm_init): the library has no link-time dependency on it, so single-GPU clients
+// need no RCCL installed, and a process that already holds a copy (PyTorch bundles one) keeps using that copy.
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ struct RcUid, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
 
 struct EventPair {
     hipEvent_t a, b;
@@ -99,6 +131,14 @@ struct rc_env {
     double k_ms[RC_K_COUNT] = {0};
     uint64_t k_n[RC_K_COUNT] = {0};
     int32_t dbg[RC_DBG_COUNT] = {0};   // rc_debug_set: experiment / validation knobs, all 0 = production behaviour
+    // half-size record + multi-GPU gather
+    CompactLayout compact{};
+    void *compact_slab = nullptr;      // caller-owned device buffer of compact.total bytes, or null
+    void *comm = nullptr;              // ncclComm_t
+    int comm_rank = 0, comm_world = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
+    bool gather_pending = false;
 };
 
 namespace {
@@ -244,7 +284,68 @@ int observe(rc_env *env) {
     TIMED(env, RC_K_RAYCAST, rck_launch_raycast(env->params, env->launch, env->stream));
     if (env->params.render_patch)
         TIMED(env, RC_K_PATCH, rck_launch_patch(env->params, env->launch, env->stream));
+    if (env->compact_slab)      // the scan has written the uint16 rows; the 76 B/car summary follows them
+        HIP_TRY(hipMemcpyAsync((char *)env->compact_slab + env->compact.lidar_bytes,
+                               (const char *)env->out_arena + env->compact.summary_src_off, env->compact.summary_bytes,
+                               hipMemcpyDeviceToDevice, env->stream));
     return RC_OK;
+}
+
+Rccl g_rccl;
+std::string g_rccl_path;
+
+int load_rccl() {
+    if (g_rccl.handle) return RC_OK;
+    void *h = nullptr;
+    if (!g_rccl_path.empty()) {
+        h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) return fail(RC_ERR_COMM, "dlopen(%s) failed: %s", g_rccl_path.c_str(), dlerror());
+    } else {
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names)                       // a copy the process already holds wins
+            if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+        if (!h)
+            for (const char *n : names)
+                if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (!h) return fail(RC_ERR_COMM, "RCCL not found (tried librccl.so.1, librccl.so, /opt/rocm/lib): %s", dlerror());
+    }
+    Rccl r;
+    r.handle = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
+        return fail(RC_ERR_COMM, "the RCCL library lacks an expected symbol");
+    g_rccl = r;
+    return RC_OK;
+}
+
+#define NCCL_TRY(expr)                                                                                     \
+    do {                                                                                                   \
+        int _r = (expr);                                                                                   \
+        if (_r != 0) return fail(RC_ERR_COMM, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));          \
+    } while (0)
+
+// source pointer and size of what one gather mode sends
+int gather_source(rc_env *env, int mode, const void **src, size_t *bytes) {
+    switch (mode) {
+    case RC_GATHER_FULL:
+        *src = env->out_arena;
+        *bytes = env->layout.slab_bytes;
+        return RC_OK;
+    case RC_GATHER_SUMMARY:
+        *src = (const char *)env->out_arena + env->compact.summary_src_off;
+        *bytes = env->compact.summary_bytes;
+        return RC_OK;
+    case RC_GATHER_FULL_U16:
+        if (!env->compact_slab) return fail(RC_ERR_INVALID, "RC_GATHER_FULL_U16 needs rc_set_compact_slab first");
+        *src = env->compact_slab;
+        *bytes = env->compact.total;
+        return RC_OK;
+    }
+    return fail(RC_ERR_INVALID, "unknown gather mode %d", mode);
 }
 
 int check_cfg(const rc_config *cfg) {
@@ -362,6 +463,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     const int n = env->n_cars = cfg->num_envs * cfg->cars_per_env;
     const bool occ = cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY;
     env->layout = make_layout(n, occ);
+    env->compact = make_compact(env->layout, n);
 #define FAIL_FREE(code_expr) do { int _c = (code_expr); rc_destroy(env); return _c; } while (0)
 #define HIP_TRY_FREE(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) FAIL_FREE(fail(RC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
     if (cfg->stream) {
@@ -440,6 +542,11 @@ void rc_destroy(rc_env *env) {
     if (!env) return;
     (void)hipSetDevice(env->cfg.device);
     if (env->stream) (void)hipStreamSynchronize(env->stream);
+    if (env->comm_stream) (void)hipStreamSynchronize(env->comm_stream);
+    if (env->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(env->comm);
+    if (env->ev_ready) (void)hipEventDestroy(env->ev_ready);
+    if (env->ev_gathered) (void)hipEventDestroy(env->ev_gathered);
+    if (env->comm_stream) (void)hipStreamDestroy(env->comm_stream);
     for (EventPair &ep : env->pending) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     for (EventPair &ep : env->free_events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (env->own_arena && env->arena) (void)hipFree(env->arena);
@@ -775,6 +882,109 @@ int rc_set_arena(rc_env *env, void *arena, size_t bytes) {
     return RC_OK;
 }
 
+size_t rc_compact_bytes(const rc_config *cfg) {
+    if (!cfg || cfg->num_envs < 1 || cfg->cars_per_env < 1) return 0;
+    const int n = cfg->num_envs * cfg->cars_per_env;
+    return make_compact(make_layout(n, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY), n).total;
+}
+
+int rc_set_compact_slab(rc_env *env, void *slab, size_t bytes) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (slab) {
+        if (bytes < env->compact.total) return fail(RC_ERR_INVALID, "compact slab too small: %zu < %zu", bytes, env->compact.total);
+        if ((uintptr_t)slab % 64) return fail(RC_ERR_INVALID, "compact slab must be 64-byte aligned");
+        if (env->has_track && env->launch.raycast_variant != 7)
+            return fail(RC_ERR_INVALID, "the uint16 LiDAR copy is written by the default scan only (raycast variant 7)");
+    }
+    env->compact_slab = slab;
+    env->params.out.lidar_u16 = (uint16_t *)slab;
+    return RC_OK;
+}
+
+int rc_compact_layout(rc_env *env, size_t *lidar_u16_bytes, size_t *summary_offset, size_t *summary_bytes) {
+    if (!env || !lidar_u16_bytes || !summary_offset || !summary_bytes) return fail(RC_ERR_INVALID, "NULL argument");
+    *lidar_u16_bytes = (size_t)env->n_cars * RC_N_BEAMS * 2;
+    *summary_offset = env->compact.lidar_bytes;
+    *summary_bytes = env->compact.summary_bytes;
+    return RC_OK;
+}
+
+int rc_comm_library(const char *path) {
+    if (g_rccl.handle) return fail(RC_ERR_INVALID, "RCCL is already loaded");
+    g_rccl_path = path ? path : "";
+    return RC_OK;
+}
+
+int rc_comm_unique_id(void *out, size_t bytes) {
+    if (!out || bytes < sizeof(RcUid)) return fail(RC_ERR_INVALID, "unique id buffer must hold %zu bytes", sizeof(RcUid));
+    int rc = load_rccl();
+    if (rc) return rc;
+    NCCL_TRY(g_rccl.GetUniqueId(out));
+    return RC_OK;
+}
+
+int rc_comm_init(rc_env *env, const void *unique_id, size_t bytes, int32_t rank, int32_t world) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!unique_id || bytes < sizeof(RcUid)) return fail(RC_ERR_INVALID, "unique id must hold %zu bytes", sizeof(RcUid));
+    if (world < 1 || rank < 0 || rank >= world) return fail(RC_ERR_INVALID, "rank %d outside world of %d", rank, world);
+    if (env->comm) return fail(RC_ERR_INVALID, "the handle already has a communicator");
+    int rc = load_rccl();
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    RcUid id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    NCCL_TRY(g_rccl.CommInitRank(&env->comm, world, id, rank));
+    env->comm_rank = rank;
+    env->comm_world = world;
+    HIP_TRY(hipStreamCreateWithFlags(&env->comm_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&env->ev_ready, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&env->ev_gathered, hipEventDisableTiming));
+    return RC_OK;
+}
+
+size_t rc_gather_bytes(rc_env *env, int32_t mode) {
+    if (!env) return 0;
+    switch (mode) {
+    case RC_GATHER_FULL: return env->layout.slab_bytes;
+    case RC_GATHER_FULL_U16: return env->compact.total;
+    case RC_GATHER_SUMMARY: return env->compact.summary_bytes;
+    }
+    return 0;
+}
+
+int rc_gather_trajectory(rc_env *env, int32_t mode, void *dev_dst, size_t dst_bytes) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->comm) return fail(RC_ERR_INVALID, "rc_comm_init has not been called on this handle");
+    if (!dev_dst) return fail(RC_ERR_INVALID, "dev_dst is NULL");
+    const void *src;
+    size_t n;
+    int rc = gather_source(env, mode, &src, &n);
+    if (rc) return rc;
+    if (dst_bytes < n * (size_t)env->comm_world)
+        return fail(RC_ERR_INVALID, "gather destination too small: %zu < %d x %zu", dst_bytes, env->comm_world, n);
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    // ordered after everything queued on the env's stream (the step that produced the record), but on a stream of
+    // its own: the following steps' kernels overlap the collective
+    HIP_TRY(hipEventRecord(env->ev_ready, env->stream));
+    HIP_TRY(hipStreamWaitEvent(env->comm_stream, env->ev_ready, 0));
+    NCCL_TRY(g_rccl.AllGather(src, dev_dst, n, /* ncclUint8 */ 1, env->comm, env->comm_stream));
+    HIP_TRY(hipEventRecord(env->ev_gathered, env->comm_stream));
+    env->gather_pending = true;
+    return RC_OK;
+}
+
+int rc_gather_wait(rc_env *env, int32_t host_sync) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->gather_pending) return RC_OK;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(hipStreamWaitEvent(env->stream, env->ev_gathered, 0));     // later work on the env's stream sees the result
+    if (host_sync) {
+        HIP_TRY(hipEventSynchronize(env->ev_gathered));
+        env->gather_pending = false;
+    }
+    return RC_OK;
+}
+
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (knob < 0 || knob >= RC_DBG_COUNT) return fail(RC_ERR_INVALID, "unknown debug knob %d", knob);
@@ -796,6 +1006,8 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant) {
         return fail(RC_ERR_INVALID, "variant 3 needs the packed 4x4 block table in the 160 KiB LDS; this track is too large");
     if ((variant == 1 || variant == 2) && env->launch.lds_bytes_skip == 0)
         return fail(RC_ERR_INVALID, "variants 1/2 need bitmap + free-block table in the 160 KiB LDS; this track is too large");
+    if (variant != 7 && env->compact_slab)
+        return fail(RC_ERR_INVALID, "the uint16 LiDAR copy (rc_set_compact_slab) is written by variant 7 only");
     env->launch.raycast_variant = variant;
     set_launch_geometry(env);
     return RC_OK;

@@ -52,6 +52,7 @@ struct RcOutDev {                // output arena sections (see rc_field)
     int32_t *lap, *cp;
     uint8_t *done, *trunc, *wall, *opp, *wrong, *fresh;
     float *accel, *steer;
+    uint16_t *lidar_u16;         // optional [n][1080] uint16 copy of the LiDAR row (rc_set_compact_slab), else null
 };
 
 struct RcParams {

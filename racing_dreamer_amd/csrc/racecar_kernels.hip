@@ -1128,6 +1128,14 @@ __global__ __launch_bounds__(1024) void rc_raycast_kernel(RcParams p, int total_
 // still in L1.  No persistent loop: 65 536 independent waves are balanced by the hardware dispatcher, where
 // equal shares of chunks per resident workgroup left the slowest workgroup's tail exposed.
 // `split` waves share a car (wave part k takes rounds k, k + split, ...): small batches still fill the chip.
+// Two values of a LiDAR row as uint16: q = rne(fl(fl(v + off) * scale)), one IEEE operation per operator like the rest
+// of the spec (oracle: racecar_oracle.quantise_lidar_u16).  Adding 2^23 rounds the product to an integer (ties to
+// even) in the float's low mantissa bits; the product is <= 65 535 < 2^23.
+__device__ __forceinline__ uint32_t quantise_pair(float a, float b, float off, float scale) {
+    const float ta = (a + off) * scale + 8388608.0f, tb = (b + off) * scale + 8388608.0f;
+    return (__float_as_uint(ta) & 0xffffu) | (__float_as_uint(tb) << 16);
+}
+
 constexpr unsigned kCarLdsBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges
 
 template <int A>
@@ -1218,6 +1226,13 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // store's acknowledgement from L2 (the scan ran 11 % faster with the stores removed).  Staged in LDS (its own
     // counter), the 17 rows go out back to back at the end and nothing waits for them.
     char *out_bytes = reinterpret_cast<char *>(out);
+    // Optional second copy of the row as uint16 (rc_set_compact_slab: the half-size record of the multi-GPU gather):
+    // q = rne((value + q_off) * q_scale), 0 .. 65535 over the row's value range - taken from the same LDS row, so it
+    // costs the scan 2 160 more bytes of stores per car and ~30 instructions.
+    char *out16 = reinterpret_cast<char *>(p.out.lidar_u16);            // wave-uniform, null when not asked for
+    if (out16 != nullptr) out16 += (size_t)car * (2 * RC_N_BEAMS);
+    const float q_off = p.lidar_transform == 1 ? 0.5f : 0.0f;
+    const float q_scale = p.lidar_transform == 0 ? 65535.0f / RCS_MAX_RANGE : 65535.0f;
     if (split == 1) {                   // the whole row is this wave's: 270 16-byte vectors, 5 stores of 1 KB
 #pragma unroll
         for (int k = 0; k < (RC_N_BEAMS / 4 + 63) / 64; ++k) {
@@ -1225,11 +1240,20 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
             if (o < 4u * RC_N_BEAMS) {
                 const v4u val = *reinterpret_cast<const v4u *>(lds_row + o);
                 __builtin_nontemporal_store(val, reinterpret_cast<v4u *>(out_bytes + o));    // streamed: leaves the tables in L2 (1 % faster)
+                if (out16 != nullptr) {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u q = {quantise_pair(__uint_as_float(val.x), __uint_as_float(val.y), q_off, q_scale),
+                                   quantise_pair(__uint_as_float(val.z), __uint_as_float(val.w), q_off, q_scale)};
+                    __builtin_nontemporal_store(q, reinterpret_cast<v2u *>(out16 + (o >> 1)));
+                }
             }
         }
     } else {
-        for (unsigned o = lane * 4u + 256u * part; o < 4u * RC_N_BEAMS; o += 256u * (unsigned)split)
-            *reinterpret_cast<float *>(out_bytes + o) = *reinterpret_cast<const float *>(lds_row + o);
+        for (unsigned o = lane * 4u + 256u * part; o < 4u * RC_N_BEAMS; o += 256u * (unsigned)split) {
+            const float v = *reinterpret_cast<const float *>(lds_row + o);
+            *reinterpret_cast<float *>(out_bytes + o) = v;
+            if (out16 != nullptr) *reinterpret_cast<uint16_t *>(out16 + (o >> 1)) = (uint16_t)quantise_pair(v, v, q_off, q_scale);
+        }
     }
 }
 

@@ -42,47 +42,76 @@ def shard_envs(total_envs: int, rank: int, world_size: int) -> Shard:
 class TrajectoryGather:
     """All-gather of equally sized per-rank slabs, overlapped with the steps that follow.
 
-    ``launch(slab)`` snapshots the slab into a staging buffer (so the producer may overwrite it); every ``every``-th
-    call starts ONE asynchronous collective over the ``every`` snapshots taken since the last one (same bytes on the
-    links, 1 / every of the launches: at 0.2 ms per step a collective per step is mostly fixed cost).  Two staging
-    buffers take turns, so a collective has ``every`` steps to finish before its buffer is written again.
-    ``wait()`` flushes a partial batch, waits, and returns the gathered buffer of the last collective:
-    ``[world_size, slab_bytes]`` for ``every == 1``, else ``[world_size, n_snapshots, slab_bytes]``.
+    ``launch(slab)`` hands over one record.  With ``stage=True`` (default) it is first snapshot into a staging buffer,
+    so the producer may overwrite it at once, and every ``every``-th call starts ONE asynchronous collective over the
+    ``every`` snapshots taken since the last one (same bytes on the links, 1 / every of the launches); two staging
+    buffers take turns, so a collective has ``every`` steps to finish before its buffer is written again.  With
+    ``stage=False`` (``every`` must be 1) the collective reads ``slab`` IN PLACE - no copy - and the caller alternates
+    between two source buffers (`BatchedRaceEnv.rotate_compact`, `TrajectoryRing`): the collective of buffer A is
+    waited for before the one of buffer B is issued, i.e. before the step that writes A again is queued.
+    ``consumer(view)``, if given, receives every completed batch (``[world, slab_bytes]`` for ``every == 1``, else
+    ``[world, n_snapshots, slab_bytes]``) before its buffer is reused: the two ``gathered`` buffers take turns too.
+    ``wait()`` flushes a partial batch, waits, and returns the gathered buffer of the last collective.
     """
 
-    def __init__(self, slab_like: torch.Tensor, group: Optional[dist.ProcessGroup] = None, every: int = 1):
+    def __init__(self, slab_like: torch.Tensor, group: Optional[dist.ProcessGroup] = None, every: int = 1,
+                 stage: bool = True, consumer=None):
         if every < 1:
             raise ValueError("every must be >= 1")
+        if not stage and every != 1:
+            raise ValueError("in-place gathers (stage=False) carry one record per collective")
         self.group = group
         self.every = int(every)
+        self.stage = bool(stage)
+        self.consumer = consumer
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         flat = slab_like.reshape(-1)
         self.slab_numel = flat.numel()
-        self.staging = [torch.empty(self.every * flat.numel(), dtype=flat.dtype, device=flat.device) for _ in range(2)]
-        self.gathered = torch.empty(self.world * self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
+        self.staging = [torch.empty(self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
+                        for _ in range(2)] if stage else None
+        self.gathered2 = [torch.empty(self.world * self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
+                          for _ in range(2)]
         self._work = None
         self._cur = 0            # staging buffer being filled
         self._k = 0              # snapshots in it
+        self._g = 0              # gathered buffer the NEXT collective writes
+        self._done_view = None   # view of the batch the pending / last collective produces
         self._last_n = self.every
+
+    @property
+    def gathered(self) -> torch.Tensor:
+        return self.gathered2[self._g ^ 1]        # the buffer of the most recently issued collective
 
     def launch(self, slab: torch.Tensor) -> None:
         n = self.slab_numel
+        if not self.stage:
+            self._issue(slab.reshape(-1), 1)
+            return
         self.staging[self._cur][self._k * n:(self._k + 1) * n].copy_(slab.reshape(-1), non_blocking=True)
         self._k += 1
         if self._k == self.every:
-            self._issue()
+            k = self._k
+            src = self.staging[self._cur][:k * n]
+            self._cur ^= 1
+            self._k = 0
+            self._issue(src, k)
 
-    def _issue(self) -> None:
-        if self._work is not None:       # the previous collective (it read the OTHER staging buffer, wrote `gathered`)
+    def _finish(self) -> None:
+        if self._work is not None:
             self._work.wait()
             self._work = None
-        n, k = self.slab_numel, self._k
-        src = self.staging[self._cur][:k * n]
-        dst = self.gathered[:self.world * k * n]
+        if self._done_view is not None and self.consumer is not None:
+            self.consumer(self._done_view)
+        self._done_view = None
+
+    def _issue(self, src: torch.Tensor, k: int) -> None:
+        self._finish()                       # the previous collective: its source and the OTHER gathered buffer are free again
+        n = self.slab_numel
+        dst = self.gathered2[self._g][:self.world * k * n]
+        self._g ^= 1
         self._last_n = k
-        self._cur ^= 1
-        self._k = 0
+        self._done_view = dst.view(self.world, -1) if self.every == 1 else dst.view(self.world, k, -1)
         if dist.get_backend(self.group) == "gloo" and src.is_cuda:
             # gloo has no device all-gather: stage through the host (functional tests only)
             host = src.cpu()
@@ -93,13 +122,67 @@ class TrajectoryGather:
         self._work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
 
     def wait(self) -> torch.Tensor:
-        if self._k:
-            self._issue()                # a partial batch (every rank holds the same number of snapshots)
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
-        g = self.gathered[:self.world * self._last_n * self.slab_numel]
-        return g.view(self.world, -1) if self.every == 1 else g.view(self.world, self._last_n, -1)
+        if self.stage and self._k:           # a partial batch (every rank holds the same number of snapshots)
+            k, n = self._k, self.slab_numel
+            src = self.staging[self._cur][:k * n]
+            self._cur ^= 1
+            self._k = 0
+            self._issue(src, k)
+        view = self._done_view
+        self._finish()
+        if view is None:
+            g = self.gathered[:self.world * self._last_n * self.slab_numel]
+            view = g.view(self.world, -1) if self.every == 1 else g.view(self.world, self._last_n, -1)
+        return view
+
+
+SUMMARY_FIELDS = [("pose", 24, torch.float32, (6,)), ("velocity", 24, torch.float32, (6,)),
+                  ("speed", 4, torch.float32, ()), ("action", 8, torch.float32, (2,)), ("reward", 4, torch.float32, ()),
+                  ("discount", 4, torch.float32, ()), ("progress_total", 4, torch.float32, ()),
+                  ("time", 4, torch.float32, ())]
+
+# uint16 LiDAR code -> value in the row's own units: q / scale - off (include/racecar_hip.h, rc_set_compact_slab)
+LIDAR_U16_CODE = {"metres": (0.0, 65535.0 / 15.0), "dreamer": (0.5, 65535.0), "unit": (0.0, 65535.0)}
+
+
+def dequantise_lidar(q: torch.Tensor, transform: str = "metres") -> torch.Tensor:
+    off, scale = LIDAR_U16_CODE[transform]
+    wide = q.view(torch.int16).to(torch.int32) & 0xFFFF        # (uint16 arithmetic is not implemented on every device)
+    return wide.to(torch.float32) / scale - off
+
+
+def _sections(buf: torch.Tensor, n_cars: int, fields, off: int = 0) -> dict:
+    out = {}
+    for name, per_car, dtype, tail in fields:
+        nb = per_car * n_cars
+        out[name] = buf[off:off + nb].view(dtype).view(n_cars, *tail)
+        off = (off + nb + 63) // 64 * 64
+    return out
+
+
+def summary_field_views(summary_rank: torch.Tensor, n_cars: int) -> dict:
+    """Typed views of one rank's POSE..TIME bytes (gather mode 'summary')."""
+    return _sections(summary_rank, n_cars, SUMMARY_FIELDS)
+
+
+def compact_field_views(compact_rank: torch.Tensor, n_cars: int) -> dict:
+    """Typed views of one rank's compact slab (gather mode 'full-u16'): `lidar_u16` uint16 [n, 1080] + the summary."""
+    from . import _lib as L
+    nb = n_cars * L.RC_N_BEAMS * 2
+    out = {"lidar_u16": compact_rank[:nb].view(torch.uint16).view(n_cars, L.RC_N_BEAMS)}
+    out.update(_sections(compact_rank, n_cars, SUMMARY_FIELDS, (nb + 63) // 64 * 64))
+    return out
+
+
+def gather_link_model(bytes_per_gpu_per_step: int, world: int, link_gbs: float = 76.8, links: int = 7) -> dict:
+    """Lower bound of an all-gather on the xGMI full mesh: every GPU receives (world - 1) shards, at best one per link
+    in parallel (MI355X: 7 links x 153.6 GB/s bidirectional = 76.8 GB/s inbound each), so the step cannot be shorter
+    than shard bytes / link rate however the collective is scheduled."""
+    peers = max(world - 1, 0)
+    inbound = bytes_per_gpu_per_step * peers
+    t = bytes_per_gpu_per_step / (link_gbs * 1e9) * max(1.0, peers / links) if peers else 0.0
+    return {"bytes_per_gpu_per_step": int(bytes_per_gpu_per_step), "inbound_bytes_per_gpu_per_step": int(inbound),
+            "link_bound_ms_per_step": t * 1e3, "assumed_link_GBps_inbound": link_gbs, "links": links}
 
 
 def slab_field_views(slab_rank: torch.Tensor, n_cars: int, occupancy: bool) -> dict:

@@ -81,6 +81,20 @@ def _worker(rank, world, port, total_envs, q):
                     assert int(gb[r, j, 0]) == 16 * j + r and (r != rank or torch.equal(gb[r, j, 8:], slab[8:]))
     gb = batched.wait()
     assert gb.shape[:2] == (world, 1) and all(int(gb[r, 0, 0]) == 32 + r for r in range(world))
+    # in-place form (no staging copy) with a consumer: every batch is handed over exactly once, in order, before its
+    # gathered buffer is reused (49 of 50 batches used to be unobservable)
+    seen = []
+    inplace = TrajectoryGather(slab, stage=False, consumer=lambda v: seen.append(v[:, 0].clone()))
+    bufs = [slab.clone(), slab.clone()]
+    for k in range(5):
+        b = bufs[k % 2]
+        b[0] = 40 + k + rank
+        inplace.launch(b)
+    last = inplace.wait()
+    assert [t.tolist() for t in seen] == [[40 + k + r for r in range(world)] for k in range(5)]
+    assert last[:, 0].tolist() == [44 + r for r in range(world)]
+    with pytest.raises(ValueError):
+        TrajectoryGather(slab, every=2, stage=False)
     views = [slab_field_views(g[r], sh.num_envs, False) for r in range(world)]
     lidar = torch.cat([v["lidar"] for v in views]).numpy()
     reward = torch.cat([v["reward"] for v in views]).numpy()
@@ -115,3 +129,38 @@ def test_two_rank_gather_equals_single_rank_run():
     for rank, ok, lidar, reward in results:
         assert ok
         assert np.array_equal(lidar, out["lidar"]) and np.array_equal(reward, out["reward"])
+
+
+def test_compact_and_summary_views_parse_the_documented_layout():
+    """include/racecar_hip.h, rc_set_compact_slab: uint16 [n][1080], padding to 64 B, then POSE..TIME as in the arena."""
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.distributed import (compact_field_views, dequantise_lidar, gather_link_model,
+                                                summary_field_views, SUMMARY_FIELDS)
+    n = 37                                               # 37 * 2160 is not a multiple of 64: the padding matters
+    rng = np.random.default_rng(0)
+    lidar = rng.uniform(0, 15, (n, 1080)).astype(np.float32)
+    lidar[0, :3] = [0.0, 15.0, 7.5]
+    q = ro.quantise_lidar_u16(lidar)
+    assert q.dtype == np.uint16 and q[0, 0] == 0 and q[0, 1] == 65535 and q[0, 2] == 32768   # 32767.5 -> even
+    fields = {name: rng.standard_normal((n,) + tail).astype(np.float32) for name, _, _, tail in SUMMARY_FIELDS}
+    parts = [q.tobytes()]
+    parts[0] += b"\0" * ((-len(parts[0])) % 64)
+    summary = b""
+    for name, per_car, _, _ in SUMMARY_FIELDS:
+        b = fields[name].tobytes()
+        assert len(b) == per_car * n
+        summary += b + b"\0" * ((-len(b)) % 64)
+    buf = torch.frombuffer(bytearray(parts[0] + summary), dtype=torch.uint8)
+    v = compact_field_views(buf, n)
+    assert np.array_equal(v["lidar_u16"].numpy(), q)
+    s = summary_field_views(torch.frombuffer(bytearray(summary), dtype=torch.uint8), n)
+    for name in fields:
+        assert np.array_equal(v[name].numpy(), fields[name]) and np.array_equal(s[name].numpy(), fields[name])
+    back = dequantise_lidar(v["lidar_u16"]).numpy()
+    assert np.abs(back - lidar).max() <= 15.0 / 65535 / 2 * 1.001
+    assert sum(p for _, p, _, _ in SUMMARY_FIELDS) == 76
+    # link model: the full fp32 record of 65 536 cars over 7 links
+    m = gather_link_model(65536 * 4396, 8)
+    assert m["inbound_bytes_per_gpu_per_step"] == 7 * 65536 * 4396 and 3.5 < m["link_bound_ms_per_step"] < 4.0
+    assert gather_link_model(65536 * 4396, 1)["link_bound_ms_per_step"] == 0.0
+    assert gather_link_model(65536 * 76, 2)["link_bound_ms_per_step"] == pytest.approx(65536 * 76 / 76.8e9 * 1e3)

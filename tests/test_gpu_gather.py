@@ -1,0 +1,181 @@
+"""The multi-GPU leg on one GPU: what the trajectory gather carries, checked against the CPU oracle.
+
+  * the half-size record (uint16 LiDAR written by the scan's store path + the 76 B/car summary) against the oracle's
+    quantiser, bit for bit;
+  * `rc_gather_trajectory` - RCCL bound at run time inside the C-ABI library - with a one-rank communicator, every mode;
+  * two ranks sharing the GPU (gloo between them: RCCL wants one GPU per rank), each stepping its own HIP shard with
+    global-id RNG streams and gathering `full`, `full-u16` and `summary` records: every rank's gathered buffer, parsed
+    with the public view helpers, equals the oracle's UNSHARDED run field by field (dreamer/wrappers.py:213-219 record).
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RECORD = ("pose", "velocity", "speed", "action", "reward", "discount", "progress_total", "time")
+
+
+def _oracle_rollout(track_name, total, steps, repeat, seed=4, act_seed=1):
+    from helpers import make_oracle
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.track_assets import load_track
+    ref = make_oracle(load_track(track_name), num_envs=total, auto_reset=True)
+    ref.reset(mode=ro.RESET_RANDOM, seed=seed)
+    outs = []
+    for k in range(steps):
+        outs.append(ref.step(ro.random_actions(act_seed, k, total), repeat=repeat))
+    return outs
+
+
+@pytest.mark.parametrize("transform", ["metres", "dreamer", "unit"])
+def test_compact_record_is_the_quantised_scan_plus_the_summary(transform):
+    import torch
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv, LIDAR_TRANSFORMS
+    from racing_dreamer_amd.distributed import compact_field_views, dequantise_lidar
+    n = 300                                   # split > 1 path of the scan
+    for n_envs in (n, 3000):                  # ... and one wave per car
+        env = BatchedRaceEnv("columbia", n_envs, 1, auto_reset=True, lidar_transform=transform)
+        env.enable_compact(buffers=2)
+        env.reset(mode="random", seed=2)
+        for k in range(3):
+            env.step_random(seed=5, step=k, repeat=2)
+            done = env.rotate_compact()
+        env.sync()
+        v = compact_field_views(done, n_envs)
+        lidar = env.views["lidar"].cpu().numpy().reshape(n_envs, 1080)
+        want = ro.quantise_lidar_u16(lidar, LIDAR_TRANSFORMS[transform])
+        got = v["lidar_u16"].cpu().numpy()
+        assert got.dtype == np.uint16 and np.array_equal(got, want)
+        assert want.max() > 40000 and want.min() < 3000                      # the code range is used
+        back = dequantise_lidar(v["lidar_u16"], transform).cpu().numpy()
+        assert np.abs(back - lidar).max() <= (15.0 if transform == "metres" else 1.0) / 65535 * 0.5001 + 1e-6
+        for name in RECORD:
+            assert torch.equal(v[name], env.views[name].reshape(v[name].shape)), name
+        # the slab that was filled one step earlier still holds that step's record (nothing wrote into it since)
+        assert env.compact.data_ptr() != done.data_ptr()
+        env.disable_compact()
+        env.step_random(seed=5, step=9)
+        env.sync()
+        assert torch.equal(compact_field_views(done, n_envs)["reward"], v["reward"])
+        env.close()
+
+
+def test_compact_slab_needs_the_default_scan():
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv("columbia", 64, 1)
+    env.enable_compact(1)
+    with pytest.raises(L.RacecarHipError, match="variant 7 only"):
+        env.set_raycast_variant(5)
+    env.disable_compact()
+    env.set_raycast_variant(5)
+    with pytest.raises(L.RacecarHipError, match="default scan only"):
+        env.enable_compact(1)
+    with pytest.raises(L.RacecarHipError, match="enable_compact"):
+        env.gather_source("full-u16")
+    env.close()
+
+
+def test_rc_gather_trajectory_over_rccl_with_one_rank():
+    """The C-ABI collective itself: RCCL is dlopen'ed by the library, communicator of one rank, all three payloads."""
+    import torch
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv("austria", 512, 1, auto_reset=True)
+    with pytest.raises(L.RacecarHipError, match="rc_comm_init has not been called"):
+        env.gather("full", torch.zeros(8, dtype=torch.uint8, device="cuda"))
+    env.comm_init(BatchedRaceEnv.comm_unique_id(), 0, 1)
+    env.enable_compact(2)
+    env.reset(mode="random", seed=1)
+    dst = {m: torch.zeros(env.gather_bytes(m), dtype=torch.uint8, device="cuda") for m in ("full", "full-u16", "summary")}
+    assert env.gather_bytes("full") == env.slab.numel() and env.gather_bytes("summary") == env.summary_slab.numel()
+    assert env.gather_bytes("full-u16") == env.compact.numel() < 0.52 * env.gather_bytes("full")
+    for k in range(3):
+        env.step_random(seed=3, step=k)
+        for m in dst:
+            env.gather(m, dst[m])
+        env.gather_wait(host_sync=True)
+        for m in dst:
+            assert torch.equal(dst[m], env.gather_source(m)), (k, m)
+    with pytest.raises(L.RacecarHipError, match="destination too small"):
+        env.gather("full", dst["summary"])
+    env.close()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank(rank, world, port, total, steps, repeat, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from racing_dreamer_amd.batched_env import BatchedRaceEnv
+        from racing_dreamer_amd.distributed import TrajectoryGather, shard_envs
+        sh = shard_envs(total, rank, world)
+        env = BatchedRaceEnv("columbia", sh.num_envs, 1, auto_reset=True, first_env=sh.first_env)   # the HIP env
+        env.enable_compact(buffers=2)
+        env.reset(mode="random", seed=4)
+        gathers = {m: TrajectoryGather(env.gather_source(m)) for m in ("full", "full-u16", "summary")}
+        got = {m: [] for m in gathers}
+        for k in range(steps):
+            env.step_random(seed=1, step=k, repeat=repeat)
+            for m, g in gathers.items():
+                g.launch(env.gather_source(m))
+                got[m].append(g.wait().cpu().numpy().copy())
+            env.rotate_compact()
+        q.put((rank, sh.num_envs, got))
+        env.close()
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, -1, repr(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_hip_shards_gather_the_unsharded_oracle_run():
+    import torch
+    import torch.multiprocessing as mp
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.distributed import compact_field_views, slab_field_views, summary_field_views
+    total, steps, repeat, world = 96, 3, 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, world, port, total, steps, repeat, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = _oracle_rollout("columbia", total, steps, repeat)
+    for rank, n, got in results:
+        assert n == total // world, got
+        for k in range(steps):
+            o = want[k]
+            parse = {"full": lambda b: slab_field_views(b, n, False), "full-u16": lambda b: compact_field_views(b, n),
+                     "summary": lambda b: summary_field_views(b, n)}
+            for mode, fn in parse.items():
+                g = torch.from_numpy(got[mode][k])                  # [world, bytes]: rank r's record at row r
+                assert g.shape[0] == world
+                views = [fn(g[r]) for r in range(world)]
+                for name in RECORD:
+                    cat = torch.cat([v[name] for v in views]).numpy()
+                    assert np.array_equal(cat, np.asarray(o[name], np.float32).reshape(cat.shape)), (rank, k, mode, name)
+                if mode == "full":
+                    lidar = torch.cat([v["lidar"] for v in views]).numpy()
+                    assert np.array_equal(lidar, o["lidar"]), (rank, k)
+                if mode == "full-u16":
+                    q16 = torch.cat([v["lidar_u16"] for v in views]).numpy()
+                    assert np.array_equal(q16, ro.quantise_lidar_u16(o["lidar"])), (rank, k)
