@@ -90,9 +90,9 @@ def _worker(rank, world, port, total_envs, q):
         b = bufs[k % 2]
         b[0] = 40 + k + rank
         inplace.launch(b)
-    last = inplace.wait()
+    final = inplace.wait()
     assert [t.tolist() for t in seen] == [[40 + k + r for r in range(world)] for k in range(5)]
-    assert last[:, 0].tolist() == [44 + r for r in range(world)]
+    assert final[:, 0].tolist() == [44 + r for r in range(world)]
     with pytest.raises(ValueError):
         TrajectoryGather(slab, every=2, stage=False)
     views = [slab_field_views(g[r], sh.num_envs, False) for r in range(world)]
