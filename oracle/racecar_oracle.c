@@ -43,6 +43,8 @@
 #define PROGRESS_REWARD 100.0f
 #define PATCH_CELLS 3.125f
 #define PATCH_WINDOW 110.0f
+#define PATCH_WINDOW_I 110
+#define PATCH_STEP_Q16 204800.0f   /* 3.125 cells per pixel in 16.16 fixed point */
 #define BALL_GAP 12
 #define GRID_LEAD 8
 #define NSTEP_MAX 16
@@ -414,22 +416,25 @@ void oc_raycast_range(const oc_track *t, const oc_cfg *c, const oc_state *s, flo
     }
 }
 
-/* lidar_occupancy patches of cars [c0, c1) (dreamer/wrappers.py:390-408, see racecar_oracle.py). */
+/* lidar_occupancy patches of cars [c0, c1) (dreamer/wrappers.py:390-408): the fixed-point tap walk described in
+ * racecar_oracle.py, render_patch. */
 void oc_patch_range(const oc_track *t, const oc_state *s, uint8_t *patch, int c0, int c1) {
     for (int car = c0; car < c1; ++car) {
         uint8_t *out = patch + (size_t)car * PATCH * PATCH;
         if (s->fresh[car]) { memset(out, 0, PATCH * PATCH); continue; }
-        const float ct = s->ct[car], st = s->st[car];
+        const int32_t a = (int32_t)rintf(s->ct[car] * PATCH_STEP_Q16), b = (int32_t)rintf(s->st[car] * PATCH_STEP_Q16);
         int icx, icy;
         cell_of(t, s->x[car], s->y[car], &icx, &icy);
+        const int32_t x00 = (63 * (-a - b)) >> 1, y00 = (63 * (a - b)) >> 1;      /* arithmetic shifts (gcc): floor */
         for (int row = 0; row < PATCH; ++row) {
-            const float v = -(((float)row + (0.5f - 32.0f)) * PATCH_CELLS);
+            int32_t X = x00 + row * b, Y = y00 - row * a;
             for (int col = 0; col < PATCH; ++col) {
-                const float u = ((float)col + (0.5f - 32.0f)) * PATCH_CELLS;
-                const float ox = u * ct - v * st, oy = u * st + v * ct;
-                const int inwin = ox >= -PATCH_WINDOW && ox < PATCH_WINDOW && oy >= -PATCH_WINDOW && oy < PATCH_WINDOW;
-                const int ix = icx + (int)floorf(ox), iy = (icy + 1) + (int)floorf(oy);
+                const int fx = X >> 16, fy = Y >> 16;
+                const int inwin = fx >= -PATCH_WINDOW_I && fx < PATCH_WINDOW_I && fy >= -PATCH_WINDOW_I && fy < PATCH_WINDOW_I;
+                const int ix = icx + fx, iy = (icy + 1) + fy;
                 out[row * PATCH + col] = (inwin && inb(t, ix, iy)) ? t->drv[(size_t)iy * t->w + ix] : 0;
+                X += a;
+                Y += b;
             }
         }
     }

@@ -238,17 +238,17 @@ class BatchedRaceEnv:
         the 2 236 B/car record of the `full-u16` gather.  `buffers` slabs take turns (`rotate_compact`), so a gather
         of slab k overlaps the step that fills slab k + 1."""
         nbytes = self._lib.rc_compact_bytes(C.byref(self._cfg))
-        self._compact = []
+        slabs = []
         for _ in range(max(1, int(buffers))):
             raw = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
             pad = (-raw.data_ptr()) % 64
-            self._compact.append((raw, raw[pad:pad + nbytes]))
-        self._compact_k = 0
+            slabs.append((raw, raw[pad:pad + nbytes]))
+        L.check(self._lib.rc_set_compact_slab(self._h, slabs[0][1].data_ptr(), nbytes))
         a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
         L.check(self._lib.rc_compact_layout(self._h, C.byref(a), C.byref(b), C.byref(c)))
         self.compact_layout = (a.value, b.value, c.value)       # uint16 bytes, summary offset, summary bytes
-        self.compact = self._compact[0][1]
-        L.check(self._lib.rc_set_compact_slab(self._h, self.compact.data_ptr(), nbytes))
+        self._compact, self._compact_k = slabs, 0
+        self.compact = slabs[0][1]
 
     def rotate_compact(self) -> torch.Tensor:
         """Point the next step's compact record at the next slab of the set; returns the slab just completed."""

@@ -1275,35 +1275,41 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
 // heading = +col, 3.125 cells per pixel, 1 = drivable.  Direct inverse map of the reference's
 // crop -> rotate -> centre-crop -> resize chain: centred on the north-west corner of the car's cell,
 // one nearest-cell tap per pixel, taps outside the reference's 220-cell crop window read 0.
-// One lane renders 16 adjacent pixels of a row (a quarter row) and stores them as one 16-byte vector; the
-// tap is branch-free: a rejected tap reads cell (0, 0) and its result is masked.
-__device__ __forceinline__ uint32_t select64u(bool cond, uint32_t a, uint32_t b) {
-    uint32_t r;
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(cond);
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-    return r;
-}
-
-__device__ __forceinline__ unsigned long long cmp_le_u32(uint32_t a, uint32_t b) {      // lane mask of a <= b
-    unsigned long long m;
-    asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
-    return m;
-}
-__device__ __forceinline__ uint32_t select_mask(unsigned long long m, uint32_t a, uint32_t b) {   // m ? a : b
-    uint32_t r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
-    return r;
-}
+//
+// Tap positions are the spec's 16.16 fixed-point walk (oracle/racecar_oracle.py, render_patch): with
+// (a, b) = rne(3.125 * 65536 * (cos, sin)) pixel (row r, col c) taps cell offset (X >> 16, Y >> 16),
+// X = X00 + c a + r b, Y = Y00 + c b - r a.  One lane renders 16 adjacent pixels of a row (a quarter row) and stores
+// them as one 16-byte vector; per pixel that is two integer adds, and because the start cell is folded into X and Y the
+// byte address of the tap in the LDS bitmap is one shift and one 16 x 16-bit multiply-add that reads Y's high half
+// directly: add, add, shift, mad, bit index, LDS byte read, bit extract, pack = 7 vector instructions per pixel
+// (20 in the fp32 form this replaces).  The window / grid test is hoisted out of the pixel loop: the valid taps of a
+// run lie in the rectangle window-intersected-with-grid, which is convex, so a run whose two end taps are valid
+// is valid throughout - a wave whose 64 runs all pass that test takes the test-free loop; the others (runs that
+// cross a rotated corner of the window or leave the map) take the loop that tests every tap (14 per pixel).
 __device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t offset, uint32_t width) {       // offset, width mod 32
     uint32_t r;
     asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(offset), "v"(width));
     return r;
 }
-__device__ __forceinline__ uint32_t lshl_add(uint32_t a, int sh, uint32_t c) { return (a << sh) + c; }
 __device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t c) { return (a << sh) | c; }
 __device__ __forceinline__ int mad_i24(int a, int b, int c) {
     int r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad_hi16(uint32_t y, uint32_t pitch, uint32_t c) {           // (y >> 16) * pitch + c
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(y), "s"(pitch), "v"(c));
+    return r;
+}
+__device__ __forceinline__ unsigned long long cmp_le_u32(uint32_t a, uint32_t b) {      // lane mask of a <= b
+    unsigned long long m;
+    asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
+    return m;
+}
+__device__ __forceinline__ uint32_t select_mask(unsigned long long m, uint32_t a, uint32_t b) {   // m ? a : b
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
 
@@ -1313,9 +1319,15 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     const int nwords = t.h * t.pitch;
     stage_bitmap(lds_words, t.drv_words, nwords + 1);        // + the all-zero word behind the bitmap (rc_load_track)
     const uint32_t zero_addr = (uint32_t)nwords * 4u;        // where rejected taps read
-    uint4 *out128 = reinterpret_cast<uint4 *>(p.out.patch);
-    const int wm1 = t.w - 1, hm1 = t.h - 1, pitch4 = t.pitch * 4;
-    const char *lds_bytes = reinterpret_cast<const char *>(lds_words);
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    v4u_t *out128 = reinterpret_cast<v4u_t *>(p.out.patch);
+    const int wm1 = t.w - 1, hm1 = t.h - 1;
+    const uint32_t pitch_b = (uint32_t)t.pitch * 4u;         // bytes per bitmap row (<= 512)
+    // The bitmap is the kernel's only LDS object, so it starts at LDS address 0 (checked on the host: rck_set_lds_limits
+    // refuses a build in which the kernel has static LDS) and a tap's byte offset IS its LDS address: indexing a
+    // null-based LDS pointer saves the add of the (zero) base the compiler otherwise emits per tap.
+    typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
+    const lds_u8_ptr lds_bytes = (lds_u8_ptr)(uint32_t)0;
     for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
         const unsigned q = base + threadIdx.x;
         if (q >= (unsigned)total_items) break;
@@ -1323,41 +1335,55 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
         // unit (its own counter) - as vector loads they shared the in-order counter with the previous item's store and
         // every item waited for that store's acknowledgement
         const unsigned car = __builtin_amdgcn_readfirstlane(q >> 8);
-        const unsigned row = (q >> 2) & 63u;
-        const unsigned c0 = (q & 3u) * 16u;
+        const int row = (int)((q >> 2) & 63u);
+        const int c0 = (int)(q & 3u) * 16;
         uint32_t words[4] = {0u, 0u, 0u, 0u};
         if (!p.st.fresh[car]) {                  // reset observation is all zeros, dreamer/wrappers.py:413
-            const float ct = p.st.ct[car], st = p.st.st[car];
+            const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.ct[car] * RCS_PATCH_STEP_Q16));
+            const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.st[car] * RCS_PATCH_STEP_Q16));
             int icx, icy;
             cell_of(t, p.st.x[car], p.st.y[car], icx, icy);
-            icy += 1;
-            const float v = -(((float)row + (0.5f - 32.0f)) * RCS_PATCH_CELLS);
-            const float vst = v * st, vct = v * ct;
-            float u = ((float)c0 + (0.5f - 32.0f)) * RCS_PATCH_CELLS;     // exact; + 3.125 per pixel stays exact
-            // a tap at cell offset (fx, fy) counts iff it is inside the reference's [-110, 110) crop window AND
-            // inside the grid: one unsigned range test per axis on the offset itself
-            int lox = max(-110, -icx), hix = min(109, wm1 - icx);
-            int loy = max(-110, -icy), hiy = min(109, hm1 - icy);
-            if (hix < lox) { lox = 0x40000000; hix = lox; }                // empty range: nothing passes
-            if (hiy < loy) { loy = 0x40000000; hiy = loy; }
-            const unsigned spanx = (unsigned)(hix - lox), spany = (unsigned)(hiy - loy);
-            const int rowbase = icy * pitch4;                              // only used by accepted taps
+            icx = __builtin_amdgcn_readfirstlane(icx);
+            icy = __builtin_amdgcn_readfirstlane(icy) + 1;
+            // tap of this run's first pixel, in cells << 16, the start cell folded in: (X >> 16, Y >> 16) = (ix, iy)
+            const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;
+            int X = x00 + c0 * a + row * b, Y = y00 + c0 * b - row * a;
+            // valid cells: the reference's [-110, 110) crop window around the start cell, clipped to the grid
+            const int lx = max(icx - RCS_PATCH_WINDOW_I, 0), hx = min(icx + RCS_PATCH_WINDOW_I - 1, wm1);
+            const int ly = max(icy - RCS_PATCH_WINDOW_I, 0), hy = min(icy + RCS_PATCH_WINDOW_I - 1, hm1);
+            const bool none = hx < lx || hy < ly;                          // (a car far outside the map)
+            const uint32_t sx = (uint32_t)(hx - lx), sy = (uint32_t)(hy - ly);
+            const int Xe = X + 15 * a, Ye = Y + 15 * b;
+            const bool ends_ok = (uint32_t)((X >> 16) - lx) <= sx && (uint32_t)((Y >> 16) - ly) <= sy &&
+                                 (uint32_t)((Xe >> 16) - lx) <= sx && (uint32_t)((Ye >> 16) - ly) <= sy;
+            if (none) {
+                // nothing to sample
+            } else if (__builtin_amdgcn_ballot_w64(!ends_ok) == 0) {
+                // every tap of every run of the wave is inside window and grid: (ix, iy) are valid, non-negative
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const float ox = u * ct - vst;
-                const float oy = u * st + vct;
-                const int fx = floor_to_int(ox), fy = floor_to_int(oy);
-                // both range tests into SGPR pairs, ANDed on the scalar unit, one e64 select (no i1 round trip
-                // through a VGPR, no VCC-reading e32 select)
-                const unsigned long long ok = cmp_le_u32((unsigned)(fx - lox), spanx) & cmp_le_u32((unsigned)(fy - loy), spany);
-                const int ix = icx + fx;
-                const uint32_t addr = lshl_add(bfe_u32((uint32_t)ix, 5, 16), 2, (uint32_t)mad_i24(fy, pitch4, rowbase));
-                const uint32_t w = *reinterpret_cast<const uint32_t *>(lds_bytes + select_mask(ok, addr, zero_addr));
-                words[k >> 2] = lshl_or(bfe_u32(w, (uint32_t)ix, 1), 8 * (k & 3), words[k >> 2]);   // bfe uses ix & 31
-                u += RCS_PATCH_CELLS;
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t addr = mad_hi16((uint32_t)Y, pitch_b, (uint32_t)X >> 19);     // iy * pitch + ix / 8
+                    const uint32_t byte = lds_bytes[addr];
+                    const uint32_t bit = bfe_u32(byte, bfe_u32((uint32_t)X, 16, 3), 1);          // bit ix % 8
+                    words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
+                    X += a;
+                    Y += b;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const int ix = X >> 16, iy = Y >> 16;
+                    const unsigned long long ok = cmp_le_u32((uint32_t)(ix - lx), sx) & cmp_le_u32((uint32_t)(iy - ly), sy);
+                    const uint32_t addr = (uint32_t)mad_i24(iy, (int)pitch_b, ix >> 3);
+                    const uint32_t byte = lds_bytes[select_mask(ok, addr, zero_addr)];
+                    const uint32_t bit = bfe_u32(byte, bfe_u32((uint32_t)X, 16, 3), 1);
+                    words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
+                    X += a;
+                    Y += b;
+                }
             }
         }
-        out128[q] = make_uint4(words[0], words[1], words[2], words[3]);
+        __builtin_nontemporal_store(v4u_t{words[0], words[1], words[2], words[3]}, out128 + q);
     }
 }
 
@@ -1603,6 +1629,11 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<4, 6>))
     SET(rc_patch_kernel)
 #undef SET
+    // rc_patch_kernel addresses its dynamic LDS from LDS address 0: true only while it has no static LDS
+    hipFuncAttributes fa;
+    e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(rc_patch_kernel));
+    if (e != hipSuccess) return e;
+    if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
     return hipSuccess;
 }
 

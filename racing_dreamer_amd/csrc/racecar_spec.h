@@ -19,6 +19,8 @@
 #define RCS_PROGRESS_REWARD 100.0f
 #define RCS_PATCH_CELLS 3.125f    // 200 cells / 64 px            (dreamer/wrappers.py:402-405)
 #define RCS_PATCH_WINDOW 110.0f   // neigh_size + 10 cells        (dreamer/wrappers.py:398-399)
+#define RCS_PATCH_WINDOW_I 110
+#define RCS_PATCH_STEP_Q16 204800.0f   // 3.125 cells per pixel in 16.16 fixed point
 #define RCS_BALL_GAP_BINS 12      // 1.2 m between the cars of one env at reset
 #define RCS_GRID_LEAD_BINS 8      // grid mode: the last car starts 0.8 m after the start line
 #define RCS_N_FOOTPRINT 34

@@ -322,18 +322,30 @@ def gen_patches(W, out):
     for name in ("austria", "treitlstrasse_v2", "columbia"):
         t = load_track(name)
         gm = FullFrameMap(t)
-        n = 48
-        idx = rng.integers(0, len(t.centerline), n)
+        # >= 64 poses per track: 64 along the track with lateral / heading jitter, 24 pushed up to and
+        # past the track border (the patch then shows mostly wall), 8 fixed yaws incl. both ends of the (-pi, pi] range
+        n, n_border = 160, 60                    # candidates; the first 64 + 24 + 8 whose crop window fits are kept
+        idx = rng.integers(0, len(t.centerline), n + n_border + 8)
         poses = t.centerline[idx, :3].astype(np.float64)
-        poses[:, 0] += rng.uniform(-0.3, 0.3, n)
-        poses[:, 1] += rng.uniform(-0.3, 0.3, n)
-        poses[:, 2] += rng.uniform(-0.6, 0.6, n)
-        poses[:8, 2] = [0.0, np.pi / 4, np.pi / 2, np.pi - 1e-3, -np.pi / 2, 2.0, -2.5, 1.0]
+        poses[:n, 0] += rng.uniform(-0.3, 0.3, n)
+        poses[:n, 1] += rng.uniform(-0.3, 0.3, n)
+        poses[:n, 2] += rng.uniform(-0.6, 0.6, n)
+        side = rng.choice([-1.0, 1.0], n_border) * rng.uniform(0.5, 1.3, n_border)      # metres off the centre line
+        th = poses[n:n + n_border, 2]
+        poses[n:n + n_border, 0] += -np.sin(th) * side
+        poses[n:n + n_border, 1] += np.cos(th) * side
+        poses[n:n + n_border, 2] += rng.uniform(-3.14, 3.14, n_border)
+        poses[n + n_border:, 2] = [0.0, np.pi / 4, np.pi / 2, np.pi, -np.pi + 1e-6, -np.pi / 2, np.pi - 1e-3, -2.5]
+        poses[:, 2] = (poses[:, 2] + np.pi) % (2 * np.pi) - np.pi
+        poses[n + n_border + 3, 2] = np.pi
         ok = []
         for p in poses:   # the reference slices without bounds handling: keep poses whose window fits
             pr, pc = gm.to_pixel(p)
             ok.append(110 <= pr < gm._map.shape[0] - 110 and 110 <= pc < gm._map.shape[1] - 110)
-        poses = poses[np.array(ok)]
+        ok = np.array(ok)
+        keep = np.concatenate([np.nonzero(ok[:n])[0][:64], n + np.nonzero(ok[n:n + n_border])[0][:24],
+                               n + n_border + np.nonzero(ok[n + n_border:])[0]])
+        poses = poses[keep]
         patches = []
         for p in poses:
             pose6 = np.array([p[0], p[1], 0, 0, 0, p[2]])

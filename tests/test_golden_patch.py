@@ -23,15 +23,73 @@ def _render(track, poses):
     return env.render_patch()
 
 
+def _nonconstant(img, rad=1):
+    """True where the (2 rad + 1)^2 neighbourhood of a pixel holds both values: within `rad` pixels of an edge."""
+    from scipy import ndimage
+    k = 2 * rad + 1
+    return ndimage.maximum_filter(img, size=(1, k, k), mode="nearest") != ndimage.minimum_filter(img, size=(1, k, k), mode="nearest")
+
+
 @pytest.mark.parametrize("name", ["austria", "treitlstrasse_v2", "columbia"])
 def test_patch_agrees_with_reference(name):
+    """>= 64 poses per track along the track, 24 pushed to and past the track border, yaws at both ends of (-pi, pi]
+    (tests/golden/make_golden.py).  Beyond the pixel agreement, WHERE the sampler and the reference differ is pinned:
+    only along drivable / non-drivable edges (the reference's spline rotation + antialiased resize blur an edge over
+    about a pixel; a nearest-cell tap cannot), never in the interior of a region, and without a systematic shift."""
     poses = G[name + "_poses"]
+    assert len(poses) >= 88
     want = np.unpackbits(G[name + "_patches"], axis=-2)[..., 0]
     assert int(G[name + "_raw_max"]) == 1                      # reference patches are 0/1 uint8
     got = _render(load_track(name), poses)
     agree = (got == want).mean(axis=(1, 2))
     assert agree.mean() >= 0.985, agree.mean()
-    assert agree.min() >= 0.97, agree.min()
+    assert agree.min() >= 0.975, agree.min()
+    # (1) every disagreeing pixel lies within 1 output pixel of an edge of the reference patch or of the rendered one
+    #     (the second catches the one-pixel-wide features the reference's resize erased) ...
+    bad = got != want
+    assert not (bad & ~(_nonconstant(want) | _nonconstant(got))).any()
+    # (2) ... and all but a handful per patch of an edge of the REFERENCE patch itself
+    off_edge = (bad & ~_nonconstant(want)).sum(axis=(1, 2))
+    assert off_edge.max() <= 8 and off_edge.sum() <= 0.02 * bad.sum(), (off_edge.max(), off_edge.sum(), bad.sum())
+    # (3) registration: the disagreement is smallest with no shift, by a wide margin, and the parabola through the
+    #     errors at shifts -1, 0, +1 pixel puts the best alignment within 0.15 pixel of zero on both axes
+    #     (a half-pixel geometry regression lands at 0.5 and fails here while still above 98.5 % agreement)
+    def err(dr, dc):
+        a = got[:, max(dr, 0):64 + min(dr, 0), max(dc, 0):64 + min(dc, 0)]
+        b = want[:, max(-dr, 0):64 + min(-dr, 0), max(-dc, 0):64 + min(-dc, 0)]
+        return float((a != b).mean())
+    e0 = err(0, 0)
+    for axis in ((1, 0), (0, 1)):
+        em, ep = err(-axis[0], -axis[1]), err(axis[0], axis[1])
+        assert e0 <= 0.45 * min(em, ep), (axis, em, e0, ep)
+        assert abs(0.5 * (em - ep) / (em - 2 * e0 + ep)) <= 0.15, (axis, em, e0, ep)
+
+
+def test_fixed_point_walk_matches_the_real_valued_sampler():
+    """The spec's 16.16 fixed-point tap walk (render_patch) against the plain real-valued form of the same inverse map
+    (pixel centre rotated by the heading, floor): the two may differ only where a tap lands within 1e-3 cell of a cell
+    boundary - a few pixels per thousand patches."""
+    t = load_track("austria")
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, len(t.centerline), 400)
+    poses = t.centerline[idx, :3].astype(np.float64)
+    poses[:, :2] += rng.uniform(-0.4, 0.4, (400, 2))
+    poses[:, 2] = rng.uniform(-np.pi, np.pi, 400)
+    got = _render(t, poses)
+    env = make_oracle(t, num_envs=len(poses), render_occupancy=True)
+    env.x[:], env.y[:], env.theta[:] = poses[:, 0], poses[:, 1], poses[:, 2]
+    st, ct = ro.sincos32(env.theta)
+    icx, icy = env._cell(env.x, env.y)
+    c = (np.arange(64) - 31.5)[None, None, :] * 3.125
+    r = (np.arange(64) - 31.5)[None, :, None] * 3.125
+    ct, st = ct.astype(np.float64)[:, None, None], st.astype(np.float64)[:, None, None]
+    ox, oy = c * ct + r * st, c * st - r * ct
+    fx, fy = np.floor(ox).astype(np.int32), np.floor(oy).astype(np.int32)
+    inwin = (fx >= -110) & (fx < 110) & (fy >= -110) & (fy < 110)
+    ref = (env._lookup(env.drv, icx[:, None, None] + fx, icy[:, None, None] + 1 + fy, False) & inwin).astype(np.uint8)
+    near = (np.abs(ox - np.rint(ox)) < 1e-3) | (np.abs(oy - np.rint(oy)) < 1e-3)
+    assert not ((got != ref) & ~near).any()
+    assert (got != ref).mean() < 1e-4
 
 
 def test_patch_known_answer_forward_marker():

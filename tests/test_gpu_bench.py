@@ -39,6 +39,15 @@ def test_bench_single_gpu_contract():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 8
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # the other single-GPU configurations of BASELINE.json ride in the same line
+    cfgs = d["configs"]
+    assert [c["envs"] * c["cars_per_env"] for c in cfgs] == [4096, 65536, 65536]
+    assert cfgs[1]["obs_type"] == "lidar_occupancy" and "rc_patch_kernel" in cfgs[1]["kernels_ms"]
+    assert cfgs[2]["cars_per_env"] == 2 and cfgs[2]["track"] == "treitlstrasse_v2"
+    for c in cfgs:
+        r = c["roofline"]
+        assert c["ms_per_step"] > 0 and 0 < r["step_frac"] < 1 and 0 < r["raycast_frac"] < 1
+        assert r["step_bytes"] == c["envs"] * c["cars_per_env"] * (4479 + (4096 if c["obs_type"] == "lidar_occupancy" else 0))
 
 
 def test_bench_two_ranks_functional():
@@ -49,4 +58,12 @@ def test_bench_two_ranks_functional():
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["scaling"] == "weak"
-    assert d["config"]["gather"] == "summary" and "cpu_baseline" not in d
+    # the headline of an N > 1 run carries the whole record (uint16 LiDAR), and says so; the other payloads are timed beside it
+    assert d["config"]["gather"] == "full-u16" and "full-u16" in d["config"]["workload"] and "cpu_baseline" not in d
+    gm = d["gather_modes"]
+    assert set(gm) == {"full-u16", "full", "summary", "none"} and gm["full-u16"]["headline"] is True
+    assert gm["full-u16"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 2236, rel=0.01)
+    assert gm["full"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 4396, rel=0.01)
+    assert gm["summary"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 76, rel=0.05)
+    assert all(gm[m]["ms_per_step"] > 0 for m in gm) and gm["none"]["link_bound_ms_per_step"] == 0.0
+    assert gm["full"]["link_bound_ms_per_step"] == pytest.approx(2 * gm["full-u16"]["link_bound_ms_per_step"], rel=0.02)
