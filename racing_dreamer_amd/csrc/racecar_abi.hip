@@ -484,7 +484,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     }
     HIP_TRY_FREE(hipMemsetAsync(env->arena, 0, env->layout.total, env->stream));
 
-    // simulator state: 10 float + 2 int + 6 byte arrays per car, 2 int + 1 uint per env
+    // simulator state: packed scan pose, 10 float + 2 int + 6 byte arrays per car, 2 int + 1 uint per env
     const size_t nc = (size_t)align_up(n, 64), ne = (size_t)align_up(cfg->num_envs, 64);
     bool any_nstep = false;
     for (int a = 0; a < RC_MAX_CARS; ++a) {
@@ -492,13 +492,14 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         any_nstep |= a < cfg->cars_per_env && env->params.car_task[a] == RC_TASK_N_STEP_PROGRESS;
     }
     env->params.n_steps = cfg->n_steps;
-    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0);
+    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6 + 16) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0);
     HIP_TRY_FREE(hipMalloc(&env->state_mem, state_bytes));
     HIP_TRY_FREE(hipMemsetAsync(env->state_mem, 0, state_bytes, env->stream));
     HIP_TRY_FREE(hipMalloc((void **)&env->mask_dev, ne));
     {
         char *m = (char *)env->state_mem;
         RcStateDev &s = env->params.st;
+        s.scan_pose = (float4 *)m; m += nc * 16;                // first: 16-byte aligned
         float **fp[] = {&s.x, &s.y, &s.theta, &s.ct, &s.st, &s.v, &s.delta, &s.omega, &s.accel, &s.progress};
         for (float **f : fp) { *f = (float *)m; m += nc * 4; }
         s.lap = (int32_t *)m; m += nc * 4;

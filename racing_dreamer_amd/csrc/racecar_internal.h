@@ -41,6 +41,8 @@ struct RcStateDev {              // persistent per-car / per-env simulator state
     uint8_t *wall, *opp, *wrong, *done, *trunc, *fresh;
     int32_t *steps, *agent_steps;   // per env
     uint32_t *episode;              // per env
+    float4 *scan_pose;              // [n_cars] (x, y, cos, sin) once more, packed: the scan fetches a car's state with ONE
+                                    // scalar 16-byte load (four separate words cost it a second serial round trip)
     float *nstep_hist;              // [n_cars][RC_NSTEP_MAX] total progress at sub-step s in slot s % n_steps; null unless
                                     // some car runs RC_TASK_N_STEP_PROGRESS
 };

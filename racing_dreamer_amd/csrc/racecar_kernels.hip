@@ -160,6 +160,7 @@ __device__ __forceinline__ void store_state_and_obs(const RcParams &p, int e, co
         p.st.progress[i] = c.pr; p.st.lap[i] = c.lap; p.st.cp[i] = c.cp;
         p.st.wall[i] = c.wall; p.st.opp[i] = c.opp; p.st.wrong[i] = c.wrong;
         p.st.done[i] = c.done; p.st.trunc[i] = c.trunc; p.st.fresh[i] = c.fresh;
+        p.st.scan_pose[i] = make_float4(c.x, c.y, c.ct, c.st);
         // observation of the current state (post auto-reset)
         float *pose = p.out.pose + 6 * i, *vel = p.out.velocity + 6 * i;
         pose[0] = c.x; pose[1] = c.y; pose[2] = 0.0f; pose[3] = 0.0f; pose[4] = 0.0f; pose[5] = c.th;
@@ -1142,16 +1143,25 @@ template <int A>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
                                          const unsigned lane, char *lds_row) {
     const RcTrackDev &t = p.trk;
-    float ct = p.st.ct[car], st = p.st.st[car];
+    // the wave's first beam pair does not depend on the car: requested before the car's state, so the two round trips
+    // overlap (a wave's start-up - state, start cell, first-trip line - is serial latency that nothing else hides)
+    const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
+    unsigned boff = lane * 8u + 512u * part;                             // byte offset of this lane's beam pair
+    float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
+    // all four state words in one scalar 16-byte load
+    const float4 sp = p.st.scan_pose[car];
+    float ct = sp.z, st = sp.w;
+    const float car_x = sp.x, car_y = sp.y;
     // One check per car instead of a clamp per ray: a heading whose (cos, sin) pair is
     // not finite, not of magnitude <= 2 or not at least 0.5 in one component (a diverged car state; sincos32 never
     // produces one from a finite angle) is replaced by heading 0 - the scan of such a car is unspecified, it only
     // has to terminate.  With a legal pair and the beam table's entries all non-zero (checked at rc_load_track) at
     // least one of the two products in dx = ct cb - st sb and in dy = st cb + ct sb is non-zero, so neither
     // component can be -0.0, which the spec would step as +.
-    if (!(fabsf(ct) <= 2.0f && fabsf(st) <= 2.0f && (fabsf(ct) >= 0.5f || fabsf(st) >= 0.5f))) { ct = 1.0f; st = 0.0f; }
-    const float lx = p.st.x[car] + RCS_LIDAR_X * ct;
-    const float ly = p.st.y[car] + RCS_LIDAR_X * st;
+    const bool legal = (fabsf(ct) <= 2.0f) & (fabsf(st) <= 2.0f) & ((fabsf(ct) >= 0.5f) | (fabsf(st) >= 0.5f));
+    if (!legal) { ct = 1.0f; st = 0.0f; }
+    const float lx = car_x + RCS_LIDAR_X * ct;
+    const float ly = car_y + RCS_LIDAR_X * st;
     const float gx = (lx - t.org_x) * t.inv_res;
     const float gy = (ly - t.org_y) * t.inv_res;
     float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
@@ -1160,10 +1170,8 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     const char *first_line = nullptr;
     if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
         first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * RC_FIRST_BIAS;
-    const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
     const unsigned bstep = 512u * (unsigned)split;
-    unsigned boff = lane * 8u + 512u * part;                             // byte offset of this lane's beam pair
     unsigned obyte = lane * 4u + 256u * part;                            // ... and of its range in the car's output row
     // Software pipeline over the rounds: while round r is traversed, round r + 1's direction, reciprocals, sign masks
     // and first-trip entry are already computed / in flight (and round r + 2's beam pair is being fetched), so no
@@ -1181,7 +1189,6 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
         r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
     };
-    float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
     // one round: prepare `nxt` for round + split, traverse `cur`, store.  false: this lane has no beam in the round
     auto stage = [&](int round, const Ray &cur, Ray &nxt) -> bool {
         if (obyte >= 4u * RC_N_BEAMS) return false;                       // last round: 56 of 64 lanes
@@ -1511,6 +1518,7 @@ __global__ __launch_bounds__(256) void rc_set_pose_kernel(RcParams p, const floa
     float sn, cs;
     sincos32(th, sn, cs);
     p.st.x[i] = x; p.st.y[i] = y; p.st.theta[i] = th; p.st.st[i] = sn; p.st.ct[i] = cs;
+    p.st.scan_pose[i] = make_float4(x, y, cs, sn);
     p.st.fresh[i] = 0;
     p.out.fresh[i] = 0;
     float *pose = p.out.pose + 6 * i;

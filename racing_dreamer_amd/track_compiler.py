@@ -83,8 +83,9 @@ def start_pixel(shape, origin, resolution, world_start=(0.0, 0.0)):
     return int(g[0]), int(g[1])
 
 
-def bfs_from_start(free: np.ndarray, start_col: int, start_row: int):
-    """Finish-line blocking + 8-connected BFS (generate-costmap.py:131-224, forward direction).
+def bfs_from_start(free: np.ndarray, start_col: int, start_row: int, forward: bool = True):
+    """Finish-line blocking + 8-connected BFS (generate-costmap.py:131-224; `forward=False` blocks the column in
+    front of the start pixel instead of the one behind it, :159-161, which yields the distance TO the line).
 
     Returns (steps int32 [-1 where unreached], finish_line bool, drivable bool, n_iter).
     ``steps`` of finish-line pixels is the final counter value, as in the reference.
@@ -99,8 +100,9 @@ def bfs_from_start(free: np.ndarray, start_col: int, start_row: int):
             finish[row, col] = True
             row += step
 
-    block(start_row, start_col - 1, +1)
-    block(start_row - 1, start_col - 1, -1)
+    col = start_col - 1 if forward else start_col + 1
+    block(start_row, col, +1)
+    block(start_row - 1, col, -1)
 
     steps = np.full(free.shape, -1, np.int32)
     reached = np.zeros_like(free)
@@ -183,17 +185,36 @@ def build_centerline(steps, drivable, edt_sq, max_steps, resolution, origin):
     return np.concatenate([xy, heading[:, None], prog[:, None]], axis=1).astype(np.float32)
 
 
-def compile_track(name: str, maps_dir: str, world_start=(0.0, 0.0)) -> CompiledTrack:
+class TrackCompileError(ValueError):
+    """The map cannot be compiled with this start position - the reference's generator fails on it too."""
+
+
+def _load_map(name: str, maps_dir: str, world_start):
     map_name = TRACK_TO_MAP.get(name, name)
     with open(os.path.join(maps_dir, map_name + ".yaml")) as f:
         props = yaml.safe_load(f)
     res = float(props["resolution"])
-    gray = load_gray(os.path.join(maps_dir, props["image"]))
+    image_path = os.path.join(maps_dir, props["image"])
+    if not os.path.exists(image_path):
+        raise TrackCompileError(f"{name}: image {props['image']} is not in the checkout (.MISSING_LARGE_BLOBS)")
+    gray = load_gray(image_path)
     norm = gray / np.amax(gray)
     free = norm > props["occupied_thresh"]
     sc, sr = start_pixel(gray.shape, props["origin"], res, world_start)
-    assert free[sr, sc], f"{name}: start pixel ({sc},{sr}) is not free"
+    h, w = free.shape
+    if not (1 <= sc < w - 1 and 1 <= sr < h):
+        raise TrackCompileError(f"{name}: start position {tuple(world_start)} maps to pixel ({sc}, {sr}) outside the "
+                                f"{h}x{w} image (generate-costmap.py:49-52 indexes out of range there too); pass a start position")
+    if not free[sr, sc]:
+        raise TrackCompileError(f"{name}: start pixel ({sc}, {sr}) of world {tuple(world_start)} is occupied; pass a start position")
+    return map_name, props, res, gray, free, sc, sr
+
+
+def compile_track(name: str, maps_dir: str, world_start=(0.0, 0.0)) -> CompiledTrack:
+    map_name, props, res, gray, free, sc, sr = _load_map(name, maps_dir, world_start)
     steps, finish, drivable, max_steps = bfs_from_start(free, sc, sr)
+    if max_steps < 4 * CENTERLINE_BIN * CENTERLINE_TANGENT:
+        raise TrackCompileError(f"{name}: only {max_steps} cells reachable from the start pixel - not a closed track")
     edt = ndimage.distance_transform_edt(drivable)
     edt_sq = np.rint(edt * edt).astype(np.int32)
 
@@ -216,6 +237,39 @@ def compile_track(name: str, maps_dir: str, world_start=(0.0, 0.0)) -> CompiledT
                          np.array([r0, c0, fh, fw], np.int32), np.array([sc, sr], np.int32), cl)
 
 
+def export_maps_npz(name: str, maps_dir: str, out_path: str, world_start=(0.0, 0.0)) -> dict:
+    """Write the racecar_gym-style `maps.npz` of a track: the keys and value conventions of the reference's costmap
+    generator (generate-costmap.py:410-425), full source-image frame, row 0 = top of the image - what
+    `GridMap(np.load(maps)[key], origin, resolution)` consumers read (dreamer/plotting/plot_trajectories.py:26-37:
+    'norm_distance_from_start', 'norm_distance_to_obstacle', 'drivable_area').
+
+      properties ................. [world start x, y, grid start col, row, image centre 0, 1, occupied_thresh,
+                                   min(image), max(image), image rows, cols, resolution]      (:410-421)
+      drivable_area .............. bool: reached from the start pixel, finish line included    (:223)
+      norm_distance_from_start ... BFS distance x resolution / its maximum, 0 outside          (:198-222)
+      norm_distance_to_obstacle .. EDT(drivable_area) x resolution / its maximum               (:380-382)
+      norm_distance_to ........... the same BFS run against the driving direction (:374-375 forward_direction=False);
+                                   the reference adds Gaussian-blurred copies of it when `use_blurred_factor` is set
+                                   (:262-263), an attribute its __init__ never defines - the plain distance is written.
+    Returns the dict that was saved."""
+    map_name, props, res, gray, free, sc, sr = _load_map(name, maps_dir, world_start)
+    steps, finish, drivable, n_fwd = bfs_from_start(free, sc, sr, forward=True)
+    back, _, _, n_back = bfs_from_start(free, sc, sr, forward=False)
+    dist_from = np.where(steps >= 0, steps, 0).astype(np.float64) * res
+    dist_to = np.where(back >= 0, back, 0).astype(np.float64) * res
+    edt = ndimage.distance_transform_edt(drivable).astype(np.float64) * res
+    center = (np.asarray(gray.shape) + np.asarray(props["origin"][:2], np.float64) / res).astype(int)
+    data = dict(
+        properties=np.array([world_start[0], world_start[1], sc, sr, center[0], center[1], props["occupied_thresh"],
+                             np.amin(gray), np.amax(gray), gray.shape[0], gray.shape[1], res], np.float64),
+        drivable_area=drivable,
+        norm_distance_from_start=dist_from / np.amax(dist_from),
+        norm_distance_to=dist_to / np.amax(dist_to),
+        norm_distance_to_obstacle=edt / np.amax(edt))
+    np.savez(out_path, **data)
+    return data
+
+
 def save_track(t: CompiledTrack, out_path: str) -> None:
     h, w = t.occ.shape
     steps16 = np.where(t.steps < 0, 0xFFFF, t.steps).astype(np.uint16)
@@ -233,13 +287,48 @@ def save_track(t: CompiledTrack, out_path: str) -> None:
     )
 
 
+def compile_all(maps_dir: str, out_dir: str) -> dict:
+    """Every map yaml of `maps_dir` with the generator's default start position (world (0, 0),
+    generate-costmap.py:463-464): assets for those that compile, the reason for those that do not, `index.json` with
+    both.  Maps that already have a track name (TRACK_TO_MAP) are stored under that name."""
+    import glob
+    import json
+    by_map = {v: k for k, v in TRACK_TO_MAP.items()}
+    index = {}
+    for path in sorted(glob.glob(os.path.join(maps_dir, "*.yaml"))):
+        map_name = os.path.basename(path)[:-5]
+        name = by_map.get(map_name, map_name)
+        try:
+            t = compile_track(name, maps_dir)
+        except (TrackCompileError, AssertionError) as e:
+            index[name] = {"map": map_name, "status": "not compiled", "reason": str(e) or "empty centre-line bin (open track)"}
+            continue
+        if t.max_steps >= 0xFFFF or t.edt_sq.max() >= 0xFFFF:
+            index[name] = {"map": map_name, "status": "not compiled",
+                           "reason": "the start pixel lies in an open area wider than 12.8 m: not a track"}
+            continue
+        save_track(t, os.path.join(out_dir, name + ".npz"))
+        h, w = t.occ.shape
+        index[name] = {"map": map_name, "status": "ok", "cells": [int(h), int(w)], "max_steps": int(t.max_steps),
+                       "track_length_m": round(t.max_steps * t.resolution, 2)}
+    with open(os.path.join(out_dir, "index.json"), "w") as f:
+        json.dump(index, f, indent=1, sort_keys=True)
+    return index
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--maps", default="/root/reference/docs/maps/maps")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "tracks"))
+    ap.add_argument("--all", action="store_true", help="compile every map yaml of --maps (default start position)")
+    ap.add_argument("--maps-npz", metavar="PATH", help="also write the racecar_gym-style maps.npz of the (single) track given")
     ap.add_argument("tracks", nargs="*", default=list(TRACK_TO_MAP))
     args = ap.parse_args(argv)
     os.makedirs(args.out, exist_ok=True)
+    if args.all:
+        for name, e in compile_all(args.maps, args.out).items():
+            print(f"{name:38s} {e['status']:13s} {e.get('cells', e.get('reason', ''))}")
+        return
     for name in args.tracks:
         t = compile_track(name, args.maps)
         path = os.path.join(args.out, name + ".npz")
@@ -247,6 +336,8 @@ def main(argv=None):
         h, w = t.occ.shape
         print(f"{name:18s} {h}x{w} cells  max_steps={t.max_steps}  centerline={len(t.centerline)}"
               f"  bits={h * ((w + 31) // 32) * 4} B  file={os.path.getsize(path)} B")
+    if args.maps_npz:
+        export_maps_npz(args.tracks[0], args.maps, args.maps_npz)
 
 
 if __name__ == "__main__":

@@ -10,24 +10,71 @@ from racing_dreamer_amd import track_compiler as tc
 REF_MAPS = "/root/reference/docs/maps/maps"
 
 
+BASELINE_TRACKS = ("columbia", "austria", "barcelona", "treitlstrasse_v2", "gbr")
+
+
 def test_assets_present_and_sane():
+    """Every compiled map of docs/maps/maps (29 of the 36 yaml files compile with the generator's default start
+    position; tracks/index.json lists the other 7 with the reason)."""
+    import json
     names = ta.available_tracks()
-    for n in ("columbia", "austria", "barcelona", "treitlstrasse_v2"):       # the tracks BASELINE.json names
+    index = json.load(open(os.path.join(ta.TRACK_DIR, "index.json")))
+    assert set(names) == {n for n, e in index.items() if e["status"] == "ok"} and len(names) >= 29
+    assert sum(e["status"] != "ok" for e in index.values()) == 7 and all(e.get("reason") for e in index.values() if e["status"] != "ok")
+    for n in BASELINE_TRACKS:                                                  # the tracks BASELINE.json / the scenarios name
         assert n in names
     for n in names:
         t = ta.load_track(n)
         assert t.resolution == 0.05 and t.pitch % 2 == 1 and t.pitch * 32 >= t.width
-        assert t.bitmap_bytes <= 160 * 1024                                  # must fit the LDS of one CU
+        assert max(t.height, t.width) <= 4096                                  # rc_load_track's limit
         assert t.progress.shape == (t.height, t.width) and t.progress.max() == 1.0
         drv, occ = t.drivable, t.occ
         assert not (drv & occ).any()
         assert np.all(t.progress[drv] >= 0) and np.all(t.progress[~drv] == -1)
-        # every spawn pose is drivable, clear of walls and ordered by progress
+        # every spawn pose is drivable and ordered by progress
         cl = t.centerline
         ix = np.floor((cl[:, 0] - t.origin[0]) / 0.05).astype(int)
         iy = np.floor((cl[:, 1] - t.origin[1]) / 0.05).astype(int)
-        assert drv[iy, ix].all() and t.edt_m[iy, ix].min() >= 0.2
-        assert np.all(np.diff(cl[:, 3]) > 0)
+        assert drv[iy, ix].all() and np.all(np.diff(cl[:, 3]) > 0)
+        if n in BASELINE_TRACKS:
+            assert t.bitmap_bytes <= 160 * 1024                                # lidar_occupancy keeps the bitmap in one CU's LDS
+            assert t.edt_m[iy, ix].min() >= 0.2                                # spawn poses clear of the walls
+            gaps = np.hypot(*(np.roll(cl[:, :2], -1, axis=0) - cl[:, :2]).T)
+            assert gaps.max() < 0.5                                            # a closed loop, evenly spaced
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MAPS), reason="reference maps only exist in the build container")
+def test_maps_npz_export_has_the_generators_keys_and_values(tmp_path):
+    """generate-costmap.py:410-425: key names, value conventions and frame of the racecar_gym-style maps.npz."""
+    out = tmp_path / "maps.npz"
+    tc.export_maps_npz("columbia", REF_MAPS, str(out))
+    d = np.load(out)
+    assert sorted(d.files) == ["drivable_area", "norm_distance_from_start", "norm_distance_to",
+                               "norm_distance_to_obstacle", "properties"]
+    full = (350, 435)                                                           # docs/maps/maps/columbia.pgm
+    for k in (f for f in d.files if f != "properties"):
+        assert d[k].shape == full, k
+    pr = d["properties"]
+    assert len(pr) == 12 and tuple(pr[:2]) == (0.0, 0.0) and tuple(pr[2:4]) == (214.0, 153.0)     # start pixel (col, row)
+    assert pr[6] == 0.65 and tuple(pr[9:11]) == full and pr[11] == 0.05
+    a = ta.load_track("columbia")
+    r0, c0, fh, fw = a.crop
+    drv_full = np.zeros(full, bool)
+    drv_full[r0:r0 + a.height, c0:c0 + a.width] = a.drivable[::-1]                                  # asset rows are south-up
+    assert np.array_equal(d["drivable_area"], drv_full)
+    prog = np.zeros(full)
+    prog[r0:r0 + a.height, c0:c0 + a.width] = np.where(a.drivable, a.progress.astype(np.float64), 0.0)[::-1]
+    assert np.allclose(d["norm_distance_from_start"], prog, atol=1e-7) and d["norm_distance_from_start"].max() == 1.0
+    edt = np.zeros(full, np.float32)
+    edt[r0:r0 + a.height, c0:c0 + a.width] = a.edt_m[::-1]
+    assert np.allclose(d["norm_distance_to_obstacle"], edt / edt.max(), atol=1e-6)
+    # the backward distance: roughly complementary to the forward one along the track (both are 8-connected shortest
+    # paths, which cut the corners on opposite sides)
+    to = d["norm_distance_to"]
+    assert to.max() == 1.0 and np.all(to[~drv_full] == 0)
+    inside = drv_full & (d["norm_distance_from_start"] > 0.05) & (d["norm_distance_from_start"] < 0.95)
+    s = d["norm_distance_from_start"][inside] + to[inside]
+    assert abs(np.median(s) - 1.0) < 0.08 and np.percentile(np.abs(s - 1.0), 95) < 0.12
 
 
 def test_pack_unpack_roundtrip():
