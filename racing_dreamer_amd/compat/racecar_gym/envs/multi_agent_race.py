@@ -128,10 +128,11 @@ class MultiAgentRaceEnv:
         return self._fetch()[1]
 
     def render(self, mode: str = "follow", agent: str = None, **kwargs):
-        from .rendering import render_birds_eye
+        """HxWx3 uint8 frame of the view `mode` ('birds_eye' | 'follow') on agent `agent`, as the Render wrapper asks
+        for once per video after every step (dreamer/wrappers.py:178-183)."""
+        from .rendering import render_view
         _, _, state = self._fetch()
-        return render_birds_eye(self._scenario.world.track, state, focus=agent or self._ids[0],
-                                follow=(mode == "follow"))
+        return render_view(self._scenario.world.track, state, focus=agent or self._ids[0], mode=mode)
 
     def seed(self, seed=None):
         self._seed = 0 if seed is None else int(seed)

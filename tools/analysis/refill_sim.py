@@ -2,7 +2,7 @@
 (persistent-lane scheduling) versus the static 64-consecutive-beams mapping."""
 import sys
 import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/analysis')
 from skip_stats import emulate
 from oracle import racecar_oracle as ro, c_oracle
 from racing_dreamer_amd.track_assets import load_track

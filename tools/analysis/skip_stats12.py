@@ -1,29 +1,15 @@
-"""Analysis helper: direction-specialised rectangles for the FIRST trip only (the start cell is shared by a car's
-1080 rays and read once per car) against specialising every trip.  nfirst / nrest = planes per quadrant."""
+"""Analysis helper: first-trip rectangles specialised by LOG-SLOPE bins (bin = clamp(floor(m log2 |dy/dx|))), which the
+kernel can derive from the float bits of |dy * (1/dx)| in two instructions; later trips use the 4 quadrant planes."""
 import sys
 import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/analysis')
 from oracle import racecar_oracle as ro, c_oracle
 from racing_dreamer_amd.track_assets import load_track
 from skip_stats9 import best_rect
 from skip_stats10 import expd
 
-_cache = {}
 
-
-def tables(occ, nclass):
-    if nclass not in _cache:
-        tabs = []
-        for sy in (-1, 1):
-            for sx in (-1, 1):
-                for k in range(nclass):
-                    lo, hi = 90.0 / nclass * k, 90.0 / nclass * (k + 1)
-                    tabs.append(best_rect(occ, sx, sy, expd([lo + (hi - lo) * 0.25, lo + (hi - lo) * 0.75])))
-        _cache[nclass] = (np.stack([t[0] for t in tabs]), np.stack([t[1] for t in tabs]))
-    return _cache[nclass]
-
-
-def emulate(track, cars, nfirst, nrest):
+def emulate(track, cars, m, kmin, kmax, tabs4):
     occ = track.occ.copy(); occ[0,:]=occ[-1,:]=occ[:,0]=occ[:,-1]=True
     cb, sb = ro.beam_table()
     x, y, th = cars.T; ct, st = np.cos(th), np.sin(th)
@@ -33,17 +19,29 @@ def emulate(track, cars, nfirst, nrest):
     ix = np.floor(gx).astype(int); iy = np.floor(gy).astype(int)
     n = len(ix); it = np.zeros(n, int); act = ~occ[iy, ix]
     px, py = dx > 0, dy > 0
-    ang = np.degrees(np.arctan2(np.abs(dy), np.abs(dx)))
     q = py.astype(int)*2 + px.astype(int)
     idx, idy = 1/np.where(dx==0,1e-30,dx), 1/np.where(dy==0,1e-30,dy)
-    first = True
+    nb = kmax - kmin + 1
+    if m > 0:
+        k = np.clip(np.floor(m * np.log2(np.maximum(np.abs(dy), 1e-30) / np.maximum(np.abs(dx), 1e-30))).astype(int), kmin, kmax) - kmin
+        first = []
+        for sy in (-1, 1):
+            for sx in (-1, 1):
+                for b in range(nb):
+                    lo, hi = (b + kmin) / m, (b + kmin + 1) / m                     # log2 slope range of the bin
+                    a = [np.degrees(np.arctan(2.0 ** (lo + (hi - lo) * f))) for f in (0.25, 0.75)]
+                    first.append(best_rect(occ, sx, sy, expd(a)))
+        fw = np.stack([t[0] for t in first]); fh = np.stack([t[1] for t in first])
+        fcls = q * nb + k
+    sw, sh = tabs4
+    trip = 0
     while act.any():
-        nclass = nfirst if first else nrest
-        first = False
-        sw, sh = tables(occ, nclass)
-        cls = q * nclass + np.minimum((ang / (90.0 / nclass)).astype(int), nclass - 1)
         a_ = np.nonzero(act)[0]; it[a_] += 1
-        rx = sw[cls[a_], iy[a_], ix[a_]] - 1; ry = sh[cls[a_], iy[a_], ix[a_]] - 1
+        if trip == 0 and m > 0:
+            rx = fw[fcls[a_], iy[a_], ix[a_]] - 1; ry = fh[fcls[a_], iy[a_], ix[a_]] - 1
+        else:
+            rx = sw[q[a_], iy[a_], ix[a_]] - 1; ry = sh[q[a_], iy[a_], ix[a_]] - 1
+        trip += 1
         xe = np.where(px[a_], ix[a_] + 1 + rx, ix[a_] - rx); ye = np.where(py[a_], iy[a_] + 1 + ry, iy[a_] - ry)
         txe = (xe - gx[a_])*idx[a_]; tye = (ye - gy[a_])*idy[a_]
         xexit = txe < tye; tt = np.where(xexit, txe, tye)
@@ -62,7 +60,10 @@ if __name__ == '__main__':
     b.reset(mode=1, seed=0)
     for k in range(30): b.step(b.random_actions(1, k))
     cars = np.stack([b.arr['x'], b.arr['y'], b.arr['theta']], 1).astype(np.float64)
-    for nfirst, nrest in ((1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (2, 2), (8, 2)):
-        it = emulate(t, cars, nfirst, nrest)
+    occ = t.occ.copy(); occ[0,:]=occ[-1,:]=occ[:,0]=occ[:,-1]=True
+    t4 = [best_rect(occ, sx, sy, expd([22.5, 67.5])) for sy in (-1, 1) for sx in (-1, 1)]
+    tabs4 = (np.stack([a[0] for a in t4]), np.stack([a[1] for a in t4]))
+    for m, kmin, kmax in ((0, 0, 0), (1, -4, 3), (1, -8, 7), (2, -8, 7), (2, -16, 15), (4, -16, 15), (4, -32, 31)):
+        it = emulate(t, cars, m, kmin, kmax, tabs4)
         w = it.reshape(-1, 1080)[:, :1024].reshape(-1, 64)
-        print(f'first {4*nfirst:3d} planes, rest {4*nrest:2d}: trips/ray {it.mean():.2f}  per-wave max {w.max(1).mean():.2f}')
+        print(f'm {m} bins/quadrant {kmax-kmin+1 if m else 1:3d} (log2 slope {kmin/max(m,1):+.1f}..{(kmax+1)/max(m,1):+.1f}): trips/ray {it.mean():.2f}  per-wave max {w.max(1).mean():.2f}')

@@ -3,7 +3,7 @@
 Later trips use the 4 quadrant planes of fully free rectangles."""
 import sys
 import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/analysis')
 from oracle import racecar_oracle as ro, c_oracle
 from racing_dreamer_amd.track_assets import load_track
 from skip_stats9 import best_rect

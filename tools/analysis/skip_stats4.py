@@ -1,7 +1,7 @@
 """Analysis helper: composition (rectangle skips A vs single-cell steps B) of the slowest lane of each wave."""
 import sys
 import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/analysis')
 from skip_stats2 import trace
 from oracle import racecar_oracle as ro, c_oracle
 from racing_dreamer_amd.track_assets import load_track

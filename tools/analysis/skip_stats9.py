@@ -1,7 +1,7 @@
 """Analysis helper: per (cell, quadrant) anchored free RECTANGLE (w, h stored separately), chosen by a score."""
 import sys
 import numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tools')
+sys.path.insert(0, '.'); sys.path.insert(0, 'tools/analysis')
 from oracle import racecar_oracle as ro, c_oracle
 from racing_dreamer_amd.track_assets import load_track
 

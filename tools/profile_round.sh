@@ -5,7 +5,7 @@
 out=${1:-gpurun_out/prof}; R=$(pwd); mkdir -p $out; export TMPDIR=/tmp
 run_stats() {   # name, bench args...
   name=$1; shift
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$out/kt_$name -o kt -- python3 $R/bench.py --no-cpu-baseline --no-ftg "$@" > $R/$out/bench_prof_$name.json 2> $R/$out/err_$name.log)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $R/$out/kt_$name -o kt -- python3 $R/bench.py --no-cpu-baseline --no-ftg --no-configs "$@" > $R/$out/bench_prof_$name.json 2> $R/$out/err_$name.log)
   db=$(find $out/kt_$name -name "*.db" | head -1)
   python tools/rocpd_summary.py stats $db > $out/kernel_stats_$name.csv && python tools/rocpd_summary.py gaps $db > $out/gaps_$name.csv
   rm -rf $out/kt_$name
@@ -20,13 +20,13 @@ for group in "FETCH_SIZE" "WRITE_SIZE" \
              "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
              "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --pmc $group -d $R/$out/pass_a$i -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-ftg --steps 10 --warmup 2 > /dev/null 2> $R/$out/err_pass_a$i.log) || exit 1
+  (cd /tmp && rocprofv3 --pmc $group -d $R/$out/pass_a$i -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-ftg --no-configs --steps 10 --warmup 2 > /dev/null 2> $R/$out/err_pass_a$i.log) || exit 1
 done
 python tools/rocpd_summary.py pmc $(find $out -path "*pass_a*" -name "*.db" | sort) > $out/pmc_counters_65536_austria.csv
 # the same FETCH/WRITE passes for the lidar_occupancy config (patch kernel traffic)
 for group in "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
-  (cd /tmp && rocprofv3 --pmc $group -d $R/$out/pass_b$i -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-ftg --obs-type lidar_occupancy --steps 10 --warmup 2 > /dev/null 2> $R/$out/err_pass_b$i.log) || exit 1
+  (cd /tmp && rocprofv3 --pmc $group -d $R/$out/pass_b$i -o pmc -- python3 $R/bench.py --no-cpu-baseline --no-ftg --no-configs --obs-type lidar_occupancy --steps 10 --warmup 2 > /dev/null 2> $R/$out/err_pass_b$i.log) || exit 1
 done
 python tools/rocpd_summary.py pmc $(find $out -path "*pass_b*" -name "*.db" | sort) > $out/pmc_counters_65536_austria_lidar_occupancy.csv
 rm -rf $out/pass_a* $out/pass_b*
