@@ -26,6 +26,7 @@
 #define PATCH 64
 #define MAX_CARS 4
 #define N_FOOT 34
+#define FOOT_STEP 0.05f       /* pitch of the footprint lattice [m] */
 #define DT 0.01f
 #define INV_DT 100.0f
 #define MAX_RANGE 15.0f
@@ -209,14 +210,20 @@ void oc_reset(const oc_track *t, const oc_cfg *c, oc_state *s, const uint8_t *ma
     }
 }
 
+/* Wall contact (H5): the 34 border points of the 12 x 7 body lattice in 16.16 fixed-point cell coordinates - see
+ * racecar_oracle.py, _wall_hit. */
 static int wall_hit(const oc_track *t, const oc_state *s, int i) {
+    const float k = FOOT_STEP * t->inv_res;
+    const float gx = (s->x[i] - t->org_x) * t->inv_res, gy = (s->y[i] - t->org_y) * t->inv_res;
+    if (!(fabsf(gx) <= 8192.0f && fabsf(gy) <= 8192.0f)) return 1;
+    const int32_t ex = (int32_t)rintf((s->ct[i] * k) * 65536.0f), ey = (int32_t)rintf((s->st[i] * k) * 65536.0f);
+    const int32_t x0 = (int32_t)rintf(gx * 65536.0f), y0 = (int32_t)rintf(gy * 65536.0f);
     int hit = 0;
-    for (int k = 0; k < N_FOOT; ++k) {
-        const float fx = t->foot[2 * k], fy = t->foot[2 * k + 1];
-        const float wx = s->x[i] + (fx * s->ct[i] - fy * s->st[i]);
-        const float wy = s->y[i] + (fx * s->st[i] + fy * s->ct[i]);
-        int ix, iy;
-        cell_of(t, wx, wy, &ix, &iy);
+    for (int n = 0; n < N_FOOT; ++n) {
+        const int li = n < 24 ? n % 12 : (n < 29 ? 0 : 11);
+        const int lj = n < 12 ? 0 : (n < 24 ? 6 : (n < 29 ? n - 23 : n - 28));
+        const int32_t px = x0 + (li - 2) * ex - (lj - 3) * ey, py = y0 + (li - 2) * ey + (lj - 3) * ex;
+        const int ix = px >> 16, iy = py >> 16;                 /* arithmetic shifts (gcc): floor */
         hit |= inb(t, ix, iy) ? t->occ[(size_t)iy * t->w + ix] : 1;
     }
     return hit;

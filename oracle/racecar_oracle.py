@@ -64,6 +64,11 @@ X_REAR, X_FRONT, HALF_W = -0.10, 0.45, 0.15
 BOX_CX = f32(0.175)              # (X_FRONT + X_REAR) / 2
 BOX_HL = f32(0.275)              # (X_FRONT - X_REAR) / 2
 BOX_HW = f32(0.15)
+FOOT_STEP = f32(0.05)             # pitch of the footprint lattice [m]: X_REAR + 0.05 i, -HALF_W + 0.05 j
+Q16 = f32(65536.0)
+# border of the 12 x 7 lattice: the two long sides (j = 0, 6), then the short sides without their corners
+FOOT_LATTICE = ([(i, 0) for i in range(12)] + [(i, 6) for i in range(12)]
+                + [(0, j) for j in range(1, 6)] + [(11, j) for j in range(1, 6)])
 N_CHECKPOINTS = 20
 PROGRESS_REWARD = f32(100.0)
 PATCH = 64
@@ -358,14 +363,7 @@ class OracleRaceEnv:
         # --- collisions (H5)
         for a in range(A):
             c = envs * A + a
-            hit = np.zeros(envs.size, bool)
-            x, y, ct, st = self.x[c], self.y[c], self.ct[c], self.st[c]
-            for fx, fy in self.fp:
-                wx = x + (fx * ct - fy * st)
-                wy = y + (fx * st + fy * ct)
-                ix, iy = self._cell(wx, wy)
-                hit |= self._lookup(self.occ, ix, iy, True)
-            self.wall[c] = hit
+            self.wall[c] = self._wall_hit(c)
             self.opp[c] = 0
         for a in range(A):
             for b in range(a + 1, A):
@@ -410,6 +408,30 @@ class OracleRaceEnv:
                 done = np.zeros(envs.size, bool)
             self.reward[c] = self.reward[c] + r.astype(f32)
             self.done[c] = done
+
+    def _wall_hit(self, c):
+        """Wall contact of cars `c`: any of the 34 perimeter points of the 0.55 x 0.30 m body rectangle in an occupied
+        (or ring, or off-grid) cell.  The points are the border of a 12 x 7 lattice of 0.05 m pitch in the body frame
+        (`footprint_table`), evaluated in 16.16 FIXED-POINT cell coordinates so that the device walks them with integer
+        adds and every implementation lands in exactly the same cells: rear axle P0 = rne(65536 g), lattice vectors
+        e = rne(65536 k (cos, sin)), f = (-e.y, e.x) with k = 0.05 m / resolution, point (i, j) = P0 + (i - 2) e +
+        (j - 3) f, cell = point >> 16 (arithmetic shift).  A car whose position is not a finite number within 8192
+        cells of the grid origin counts as in contact."""
+        k = FOOT_STEP * self.inv_res
+        ex = np.rint((self.ct[c] * k) * Q16).astype(np.int64)
+        ey = np.rint((self.st[c] * k) * Q16).astype(np.int64)
+        gx = (self.x[c] - self.org_x) * self.inv_res
+        gy = (self.y[c] - self.org_y) * self.inv_res
+        with np.errstate(invalid="ignore"):
+            bad = ~((np.abs(gx) <= f32(8192.0)) & (np.abs(gy) <= f32(8192.0)))
+            x0 = np.rint(np.where(bad, f32(0.0), gx) * Q16).astype(np.int64)
+            y0 = np.rint(np.where(bad, f32(0.0), gy) * Q16).astype(np.int64)
+        hit = bad.copy()
+        for i, j in FOOT_LATTICE:
+            px = x0 + (i - 2) * ex - (j - 3) * ey
+            py = y0 + (i - 2) * ey + (j - 3) * ex
+            hit |= self._lookup(self.occ, (px >> 16).astype(i32), (py >> 16).astype(i32), True)
+        return hit
 
     def _obb_overlap(self, ca, cb_):
         cta, sta, ctb, stb = self.ct[ca], self.st[ca], self.ct[cb_], self.st[cb_]

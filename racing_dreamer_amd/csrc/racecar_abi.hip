@@ -710,7 +710,6 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     li.ray_threads = 1024;
     li.patch_threads = 1024;
     HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
-    HIP_TRY(rck_set_footprint(foot.data()));
     HIP_TRY(rck_build_quad_planes(t, (uint16_t *)t.quad_rect, env->stream));
     HIP_TRY(rck_build_first_table(t, (uint16_t *)t.first_rect, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));

@@ -93,7 +93,6 @@ void rck_set_launch_events(hipEvent_t start, hipEvent_t stop);   // attach start
 hipError_t rck_set_lds_limits(size_t lds_bytes);
 hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch, quad_plane_bytes
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch
-hipError_t rck_set_footprint(const float *foot_host);   // 34 x 2 body-frame perimeter points -> constant memory
 struct RcRandomActions { int32_t on; uint32_t seed_lo, seed_hi, step; };   // on != 0: draw the actions in the dynamics kernel
 hipError_t rck_launch_dynamics(const RcParams &p, float *actions, int repeat, const RcRandomActions &ra, hipStream_t s);
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);

@@ -56,28 +56,31 @@ struct Car {
     int wall, opp, wrong, done, trunc, fresh;
 };
 
-// Body-frame perimeter points of the car (spec constants; set once per device by rck_set_footprint): in constant
-// memory, so the unrolled test below reads them through the scalar unit.
-__constant__ float c_footprint[2 * RCS_N_FOOTPRINT];
-
-// Footprint perimeter vs occupancy (H5).  Outside the grid counts as wall: such a point reads cell (0, 0), which
-// belongs to the sentinel ring and is always set.  Branch-free and fully unrolled, so the 34 bitmap words are
-// requested back to back and waited for once (the rolled, branchy form took 34 dependent round trips: 3/4 of the
-// kernel's 17 us at 65 536 envs).
+// Footprint perimeter vs occupancy (H5): the 34 border points of the 12 x 7 body lattice (0.05 m pitch, rear axle at
+// lattice node (2, 3)) in 16.16 fixed-point cell coordinates - oracle/racecar_oracle.py, _wall_hit.  With the lattice
+// vectors e = rne(65536 k (cos, sin)) and f = (-e.y, e.x) a point is two integer multiply-adds of the rear-axle
+// position, its cell two shifts, and "outside the grid counts as wall" is one unsigned min per axis: a negative or
+// too large index clamps to the last row / column, which belongs to the sentinel ring and is always set.  About 10
+// vector instructions per point, all 34 words requested back to back and waited for once (the fp32 rotation +
+// floor + bounds select of the first version took 30 per point: 2/3 of the kernel, which runs one wave per SIMD and
+// is therefore bound by its own instruction stream).
 __device__ __forceinline__ int wall_hit(const RcTrackDev &t, const Car &c) {
-    uint32_t hit = 0;
+    const float k = RCS_FOOT_STEP * t.inv_res;
+    const float gx = (c.x - t.org_x) * t.inv_res, gy = (c.y - t.org_y) * t.inv_res;
+    const bool bad = !(fabsf(gx) <= 8192.0f && fabsf(gy) <= 8192.0f);      // not a position: counts as contact
+    const int ex = (int)__builtin_rintf((c.ct * k) * 65536.0f), ey = (int)__builtin_rintf((c.st * k) * 65536.0f);
+    const int x0 = (int)__builtin_rintf(gx * 65536.0f), y0 = (int)__builtin_rintf(gy * 65536.0f);
+    const uint32_t wm1 = (uint32_t)(t.w - 1), hm1 = (uint32_t)(t.h - 1);
+    uint32_t hit = bad ? 1u : 0u;
+    auto probe = [&](int li, int lj) {
+        const int px = x0 + (li - 2) * ex - (lj - 3) * ey, py = y0 + (li - 2) * ey + (lj - 3) * ex;
+        const uint32_t ix = min((uint32_t)(px >> 16), wm1), iy = min((uint32_t)(py >> 16), hm1);
+        hit |= t.ray_words[iy * (uint32_t)t.pitch + (ix >> 5)] >> (ix & 31u);
+    };
 #pragma unroll
-    for (int k = 0; k < RCS_N_FOOTPRINT; ++k) {
-        const float fx = c_footprint[2 * k], fy = c_footprint[2 * k + 1];
-        const float wx = c.x + (fx * c.ct - fy * c.st);
-        const float wy = c.y + (fx * c.st + fy * c.ct);
-        int ix, iy;
-        cell_of(t, wx, wy, ix, iy);
-        const bool inb = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
-        const int word = inb ? iy * t.pitch + (ix >> 5) : 0;
-        const int shift = inb ? (ix & 31) : 0;
-        hit |= t.ray_words[word] >> shift;
-    }
+    for (int i = 0; i < 12; ++i) { probe(i, 0); probe(i, 6); }
+#pragma unroll
+    for (int j = 1; j < 6; ++j) { probe(0, j); probe(11, j); }
     return (int)(hit & 1u);
 }
 
@@ -97,20 +100,26 @@ __device__ __forceinline__ int obb_overlap(const Car &a, const Car &b) {
     return sep ? 0 : 1;
 }
 
+// Reset of one env in two halves.  `prepare_reset` is everything that does not depend on how the current step ends -
+// the Philox draw keyed by (global env id, episode counter), the spawn-table gather, sin / cos of the spawn heading
+// and its progress lookup: three dependent memory round trips - so the dynamics kernel issues it next to the state
+// loads and the integrator instead of behind the step (that kernel runs one wave per SIMD: its duration is the
+// length of its dependent chain).  `apply_reset` installs the prepared poses when the env did finish.
+struct Spawn { float x, y, th, ct, st, pr; int cp; };
+
 template <int A>
-__device__ __forceinline__ void reset_env(const RcParams &p, int e, Car (&car)[A], int &steps, int &agent_steps) {
+__device__ __forceinline__ void prepare_reset(const RcParams &p, int e, Spawn (&sp)[A], uint32_t &ep) {
     const RcTrackDev &t = p.trk;
     const uint32_t g = p.first_env + (uint32_t)e;
-    const uint32_t ep = p.st.episode[e];
+    ep = p.st.episode[e];
     const rcd::u32x4 r = rcd::philox4x32(g, ep, 0u, 0u, p.seed_lo, p.seed_hi);
-    p.st.episode[e] = ep + 1u;
     const int n = t.n_centerline;
     const int idx0 = p.reset_mode == 0 ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r.x, (uint32_t)n);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         int idx = (idx0 - a * RCS_BALL_GAP_BINS) % n;
         if (idx < 0) idx += n;
-        Car &c = car[a];
+        Spawn &c = sp[a];
         c.x = t.centerline[4 * idx + 0];
         c.y = t.centerline[4 * idx + 1];
         c.th = t.centerline[4 * idx + 2];
@@ -120,13 +129,25 @@ __device__ __forceinline__ void reset_env(const RcParams &p, int e, Car (&car)[A
         c.pr = pr;
         const int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
         c.cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void apply_reset(const RcParams &p, int e, Car (&car)[A], const Spawn (&sp)[A], uint32_t ep,
+                                            int &steps, int &agent_steps) {
+    p.st.episode[e] = ep + 1u;
+#pragma unroll
+    for (int a = 0; a < A; ++a) {
+        Car &c = car[a];
+        c.x = sp[a].x; c.y = sp[a].y; c.th = sp[a].th; c.ct = sp[a].ct; c.st = sp[a].st;
+        c.pr = sp[a].pr; c.cp = sp[a].cp;
         c.v = c.dl = c.om = c.ac = 0.0f;
         c.wall = c.opp = c.wrong = c.done = c.trunc = 0;
         c.lap = 1;
         c.fresh = 1;
         if (p.car_task[a] == 2) {                 // n_step_progress: the window starts at the spawn progress
             float *h = p.st.nstep_hist + (size_t)(e * A + a) * RC_NSTEP_MAX;
-            for (int k = 0; k < RC_NSTEP_MAX; ++k) h[k] = pr;
+            for (int k = 0; k < RC_NSTEP_MAX; ++k) h[k] = sp[a].pr;
         }
     }
     steps = 0;
@@ -210,6 +231,9 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
     Car car[A];
     load_cars<A>(p, e, car);
     int steps = p.st.steps[e], agent_steps = p.st.agent_steps[e];
+    Spawn spawn[A];
+    uint32_t episode = 0;
+    if (p.auto_reset) prepare_reset<A>(p, e, spawn, episode);      // ahead of the step: see prepare_reset
     float motor[A], steer[A];
     bool any_done = false;
 #pragma unroll
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
         bool fin = false;
 #pragma unroll
         for (int a = 0; a < A; ++a) fin |= car[a].done != 0;
-        if (fin) reset_env<A>(p, e, car, steps, agent_steps);
+        if (fin) apply_reset<A>(p, e, car, spawn, episode, steps, agent_steps);
     }
     store_state_and_obs<A>(p, e, car, steps, agent_steps);
 }
@@ -352,7 +376,10 @@ __global__ __launch_bounds__(256) void rc_reset_kernel(RcParams p, const uint8_t
     int steps, agent_steps;
 #pragma unroll
     for (int a = 0; a < A; ++a) car[a].rew = 0.0f;
-    reset_env<A>(p, e, car, steps, agent_steps);
+    Spawn spawn[A];
+    uint32_t episode;
+    prepare_reset<A>(p, e, spawn, episode);
+    apply_reset<A>(p, e, car, spawn, episode, steps, agent_steps);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         const int i = e * A + a;
@@ -1599,9 +1626,6 @@ hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, 
     return hipGetLastError();
 }
 
-hipError_t rck_set_footprint(const float *foot_host) {
-    return hipMemcpyToSymbol(HIP_SYMBOL(c_footprint), foot_host, sizeof(float) * 2 * RCS_N_FOOTPRINT);
-}
 
 hipError_t rck_set_lds_limits(size_t lds_bytes) {
     hipError_t e;

@@ -24,5 +24,6 @@
 #define RCS_BALL_GAP_BINS 12      // 1.2 m between the cars of one env at reset
 #define RCS_GRID_LEAD_BINS 8      // grid mode: the last car starts 0.8 m after the start line
 #define RCS_N_FOOTPRINT 34
+#define RCS_FOOT_STEP 0.05f      // pitch of the footprint lattice [m] (12 x 7 nodes, rear axle at node (2, 3))
 #define RCS_PI 3.14159274101257324f
 #define RCS_TWO_PI 6.28318548202514648f

@@ -48,3 +48,15 @@ def test_tables_agree():
     cb, sb = ro.beam_table()
     assert np.array_equal(np.stack([cb, sb], 1), spec.beam_table())
     assert np.array_equal(ro.footprint_table(), spec.footprint_table())
+    # the fixed-point footprint walk visits the same 34 points: lattice node (i, j) = (X_REAR + 0.05 i, -HALF_W + 0.05 j)
+    pts = np.array([(spec.X_REAR + 0.05 * i, -spec.HALF_W + 0.05 * j) for i, j in ro.FOOT_LATTICE])
+    assert len(ro.FOOT_LATTICE) == 34 and np.allclose(pts, ro.footprint_table(), atol=1e-7)
+
+
+def test_patch_and_footprint_fixed_point_constants_agree():
+    dev = _defines(os.path.join(ROOT, "racing_dreamer_amd", "csrc", "racecar_spec.h"), "RCS_")
+    c = _defines(os.path.join(ROOT, "oracle", "racecar_oracle.c"))
+    f = np.float32
+    assert f(dev["FOOT_STEP"]) == ro.FOOT_STEP == f(c["FOOT_STEP"]) == f(0.05)
+    assert f(dev["PATCH_STEP_Q16"]) == ro.PATCH_STEP_Q16 == f(c["PATCH_STEP_Q16"]) == f(3.125 * 65536)
+    assert int(dev["PATCH_WINDOW_I"]) == ro.PATCH_WINDOW_I == int(c["PATCH_WINDOW_I"]) == spec.PATCH_CROP_HALF
