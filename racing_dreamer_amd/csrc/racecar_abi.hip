@@ -9,6 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -99,6 +102,31 @@ struct Rccl {
     const char *(*GetErrorString)(int) = nullptr;
 };
 
+// Device tables of one compiled track (bitmaps, progress grid, spawn table, the scan's rectangle planes and first-trip
+// table: 30 - 420 MB, built on the device in 20 - 100 ms).  They are read-only and depend on nothing but the track, so
+// handles of one process that load the same track on the same device share one copy: the second rc_load_track of a
+// track costs a hash of its inputs instead of an upload and a rebuild (tests and multi-handle clients create many).
+struct TrackTables {
+    int device = 0;
+    void *mem = nullptr;
+    RcTrackDev t{};
+    size_t lds_bytes = 0, lds_bytes_skip = 0, lds_bytes_packed = 0;
+    ~TrackTables() {
+        if (mem) {
+            (void)hipSetDevice(device);
+            (void)hipFree(mem);
+        }
+    }
+};
+std::mutex g_track_mutex;
+std::map<std::pair<int, uint64_t>, std::weak_ptr<TrackTables>> g_track_cache;
+
+uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
+    const unsigned char *b = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+    return h;
+}
+
 struct EventPair {
     hipEvent_t a, b;
     int kernel;
@@ -116,7 +144,7 @@ struct rc_env {
     bool own_arena = false;
     Layout layout{};
     void *state_mem = nullptr;
-    void *track_mem = nullptr;
+    std::shared_ptr<TrackTables> track;   // shared with the other handles that loaded the same track on this device
     uint8_t *mask_dev = nullptr;
     float *actions_in = nullptr;   // inside the arena the handle was created with (RC_F_ACTION_IN)
     void *out_arena = nullptr;     // where the output fields currently point (rc_set_arena)
@@ -552,7 +580,7 @@ void rc_destroy(rc_env *env) {
     for (EventPair &ep : env->free_events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (env->own_arena && env->arena) (void)hipFree(env->arena);
     if (env->state_mem) (void)hipFree(env->state_mem);
-    if (env->track_mem) (void)hipFree(env->track_mem);
+    env->track.reset();
     if (env->mask_dev) (void)hipFree(env->mask_dev);
     if (env->own_stream && env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
@@ -572,6 +600,50 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     if (h > 4096 || w > 4096) return fail(RC_ERR_INVALID, "grids larger than 4096 cells per side are not supported (h=%d w=%d)", h, w);
     HIP_TRY(hipSetDevice(env->cfg.device));
     const size_t nwords = (size_t)h * pitch;
+    // the same track already on this device (another handle of the process loaded it)?
+    uint64_t key = 0xcbf29ce484222325ull;
+    {
+        const int32_t dims[4] = {h, w, pitch, n_centerline};
+        const float geo[3] = {resolution, origin_x, origin_y};
+        key = fnv1a(key, dims, sizeof(dims));
+        key = fnv1a(key, geo, sizeof(geo));
+        key = fnv1a(key, occ_words, nwords * 4);
+        key = fnv1a(key, drivable_words, nwords * 4);
+        key = fnv1a(key, progress, (size_t)h * w * 4);
+        key = fnv1a(key, centerline, (size_t)n_centerline * 16);
+    }
+    std::lock_guard<std::mutex> track_lock(g_track_mutex);
+    auto finish_load = [&](const std::shared_ptr<TrackTables> &tt) {
+        env->track = tt;
+        env->params.trk = tt->t;
+        set_band(env);
+        RcLaunchInfo &li = env->launch;
+        li.lds_bytes = tt->lds_bytes;
+        li.lds_bytes_skip = tt->lds_bytes_skip;
+        li.lds_bytes_packed = tt->lds_bytes_packed;
+        li.raycast_variant = 7;         // per-cell, per-quadrant free rectangles, one wave per car
+        li.car_threads = 64;
+        li.car_split = 1;
+        li.ray_threads = 1024;
+        li.patch_threads = 1024;
+        env->has_track = true;
+        set_launch_geometry(env);
+        env->was_reset = false;
+    };
+    const bool fits_lds_early = align_up(nwords * 4 + 4, 64) <= 160 * 1024;
+    if (!fits_lds_early && env->params.render_patch)
+        return fail(RC_ERR_INVALID, "track bitmap %zu B does not fit the 160 KiB LDS (needed for obs_type lidar_occupancy)", align_up(nwords * 4 + 4, 64));
+    {
+        auto it = g_track_cache.find({env->cfg.device, key});
+        if (it != g_track_cache.end()) {
+            if (std::shared_ptr<TrackTables> tt = it->second.lock()) {
+                HIP_TRY(hipStreamSynchronize(env->stream));       // nothing of this handle still reads its old track
+                finish_load(tt);
+                return RC_OK;
+            }
+            g_track_cache.erase(it);
+        }
+    }
     const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_kernel)
     // The lidar_occupancy render and the scan's early forms (variants 0-3) keep the whole bitmap in the 160 KiB LDS;
     // the default scan does not, so a larger map is fine as long as the patch is not asked for.
@@ -670,10 +742,12 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
     const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes + 4 * quad_plane_bytes + first_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
-    if (env->track_mem) { HIP_TRY(hipFree(env->track_mem)); env->track_mem = nullptr; }
-    HIP_TRY(hipMalloc(&env->track_mem, total));
-    char *m = (char *)env->track_mem;
-    RcTrackDev &t = env->params.trk;
+    env->track.reset();                                    // (frees the old tables if no other handle shares them)
+    std::shared_ptr<TrackTables> tt = std::make_shared<TrackTables>();
+    tt->device = env->cfg.device;
+    HIP_TRY(hipMalloc(&tt->mem, total));
+    char *m = (char *)tt->mem;
+    RcTrackDev &t = tt->t;
     HIP_TRY(hipMemcpy(m, ray.data(), bm_bytes, hipMemcpyHostToDevice)); t.ray_words = (const uint32_t *)m; m += bm_bytes;
     HIP_TRY(hipMemcpy(m, drv.data(), bm_bytes, hipMemcpyHostToDevice)); t.drv_words = (const uint32_t *)m; m += bm_bytes;
     HIP_TRY(hipMemcpy(m, progress, (size_t)h * w * 4, hipMemcpyHostToDevice)); t.progress = (const float *)m; m += prog_bytes;
@@ -694,28 +768,26 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
     t.tmax = RCS_MAX_RANGE * t.inv_res;
-    set_band(env);
+    t.band = t.band_p1 = t.band2 = 0.0f;                   // per handle: set_band
     // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
-    RcLaunchInfo &li = env->launch;
-    li.lds_bytes = fits_lds ? bm_bytes : 0;
-    li.lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
-    li.lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
-    // default: per-cell, per-quadrant free rectangles read through L1/L2, one wave per car (variant 7).  Measured
-    // at 65 536 cars on austria: 0.285 ms against 0.37 ms for the same traversal on persistent 1024-ray chunks
-    // (variant 6), 0.79 ms for symmetric per-cell squares (variant 5), 0.97 ms for the packed 4x4 table in LDS
-    // (variant 3); columbia 0.33 (v6 0.44), barcelona 0.34 (0.39), gbr 0.35 (0.43).
-    li.raycast_variant = 7;
-    li.car_threads = 64;
-    li.car_split = 1;
-    li.ray_threads = 1024;
-    li.patch_threads = 1024;
-    HIP_TRY(rck_set_lds_limits(std::max(std::max(li.lds_bytes, li.lds_bytes_skip), li.lds_bytes_packed)));
+    tt->lds_bytes = fits_lds ? bm_bytes : 0;
+    tt->lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;
+    tt->lds_bytes_packed = (blk_shift == 2 && packed_bytes <= 160 * 1024) ? packed_bytes : 0;
+    {   // the dynamic-LDS ceiling is a property of the kernel functions, not of a handle: only ever raise it, or a
+        // small track loaded after a large one would make the large one's launches fail
+        static std::map<int, size_t> lds_limit;
+        size_t &lim = lds_limit[env->cfg.device];
+        const size_t need = std::max(std::max(tt->lds_bytes, tt->lds_bytes_skip), tt->lds_bytes_packed);
+        if (need > lim || lim == 0) {
+            HIP_TRY(rck_set_lds_limits(std::max(need, lim)));
+            lim = std::max(need, lim);
+        }
+    }
     HIP_TRY(rck_build_quad_planes(t, (uint16_t *)t.quad_rect, env->stream));
     HIP_TRY(rck_build_first_table(t, (uint16_t *)t.first_rect, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
-    env->has_track = true;
-    set_launch_geometry(env);
-    env->was_reset = false;
+    g_track_cache[{env->cfg.device, key}] = tt;
+    finish_load(tt);
     return RC_OK;
 }
 
