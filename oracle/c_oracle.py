@@ -95,7 +95,7 @@ class COracleEnv:
         self.H, self.W = occ.shape
         self._keep = dict(
             occ=np.ascontiguousarray(occ, np.uint8), ring=np.ascontiguousarray(ring, np.uint8),
-            drv=np.ascontiguousarray(np.asarray(drivable, bool), np.uint8),
+            drv=np.ascontiguousarray(np.asarray(drivable, bool) & ~ring, np.uint8),   # spec: the ring is not drivable
             progress=np.ascontiguousarray(progress, np.float32),
             centerline=np.ascontiguousarray(centerline, np.float32),
             beams=np.ascontiguousarray(np.stack(ro.beam_table(), axis=1), np.float32),

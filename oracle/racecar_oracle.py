@@ -249,7 +249,7 @@ class OracleRaceEnv:
         self.ring = np.zeros_like(self.occ)
         self.ring[0, :] = self.ring[-1, :] = self.ring[:, 0] = self.ring[:, -1] = True
         self.occ |= self.ring
-        self.drv = np.asarray(drivable, bool)
+        self.drv = np.asarray(drivable, bool) & ~self.ring      # spec: the outermost ring of cells is not drivable
         self.progress_grid = np.asarray(progress, f32)
         self.centerline = np.asarray(centerline, f32)
         self.H, self.W = self.occ.shape

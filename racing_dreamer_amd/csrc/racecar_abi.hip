@@ -655,8 +655,11 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     std::memcpy(ray.data(), occ_words, nwords * 4);
     std::memcpy(drv.data(), drivable_words, nwords * 4);
     auto setbit = [&](int ix, int iy) { ray[(size_t)iy * pitch + (ix >> 5)] |= 1u << (ix & 31); };
-    for (int ix = 0; ix < w; ++ix) { setbit(ix, 0); setbit(ix, h - 1); }
-    for (int iy = 0; iy < h; ++iy) { setbit(0, iy); setbit(w - 1, iy); }
+    // ... and the drivable bitmap's outermost ring cleared: the lidar_occupancy render clamps out-of-grid taps onto it
+    // (env spec: "the outermost ring of cells is not drivable"; every compiled track keeps a 16-cell margin anyway)
+    auto clrbit = [&](int ix, int iy) { drv[(size_t)iy * pitch + (ix >> 5)] &= ~(1u << (ix & 31)); };
+    for (int ix = 0; ix < w; ++ix) { setbit(ix, 0); setbit(ix, h - 1); clrbit(ix, 0); clrbit(ix, h - 1); }
+    for (int iy = 0; iy < h; ++iy) { setbit(0, iy); setbit(w - 1, iy); clrbit(0, iy); clrbit(w - 1, iy); }
     std::vector<float> beams(((RC_N_BEAMS + 63) / 64) * 64 * 2, 0.0f), foot(RCS_N_FOOTPRINT * 2);   // beams padded to whole waves
     make_tables(beams.data(), foot.data());
     // the one-wave-per-car scan relies on no beam being exactly axis-parallel in the sensor frame (racecar_kernels.hip)

@@ -1347,6 +1347,31 @@ __device__ __forceinline__ uint32_t select_mask(unsigned long long m, uint32_t a
     return r;
 }
 
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_min_u32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+
+// One 16-pixel run: taps (X, Y) += (a, b).  CLAMP: coordinates are forced into the grid first - a tap left of / below
+// the grid has a negative coordinate, i.e. a huge unsigned one, and clamps like one beyond the far edge to the last
+// column / row, which is never drivable (rc_load_track clears the bitmap's outermost ring; so does the oracle).
+template <bool CLAMP>
+__device__ __forceinline__ void patch_run(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
+                                          uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t (&words)[4]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, xmax) : (uint32_t)X;
+        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, ymax) : (uint32_t)Y;
+        const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19);                  // iy * pitch + ix / 8
+        const uint32_t byte = lds[addr];
+        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, 16, 3), 1);              // bit ix % 8
+        words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
+        X += a;
+        Y += b;
+    }
+}
+
 __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
@@ -1355,8 +1380,8 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     const uint32_t zero_addr = (uint32_t)nwords * 4u;        // where rejected taps read
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     v4u_t *out128 = reinterpret_cast<v4u_t *>(p.out.patch);
-    const int wm1 = t.w - 1, hm1 = t.h - 1;
     const uint32_t pitch_b = (uint32_t)t.pitch * 4u;         // bytes per bitmap row (<= 512)
+    const uint32_t xmax = ((uint32_t)(t.w - 1) << 16) | 0xffffu, ymax = ((uint32_t)(t.h - 1) << 16) | 0xffffu;
     // The bitmap is the kernel's only LDS object, so it starts at LDS address 0 (checked on the host: rck_set_lds_limits
     // refuses a build in which the kernel has static LDS) and a tap's byte offset IS its LDS address: indexing a
     // null-based LDS pointer saves the add of the (zero) base the compiler otherwise emits per tap.
@@ -1365,59 +1390,69 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
         const unsigned q = base + threadIdx.x;
         if (q >= (unsigned)total_items) break;
-        // 64 rows * 4 quarter rows per car: a wave's 64 items belong to ONE car, so its state comes through the scalar
+        // 256 runs of 16 pixels per car: a wave's 64 runs belong to ONE car, so its state comes through the scalar
         // unit (its own counter) - as vector loads they shared the in-order counter with the previous item's store and
-        // every item waited for that store's acknowledgement
+        // every item waited for that store's acknowledgement.
+        // Which runs a wave gets decides how often it needs the tested loop: the pixels the 220-cell window cuts
+        // off lie in the four corners of the patch, at most 15.8 pixels from its edges whatever the heading, so wave 0
+        // of a car takes the four 16 x 16 corner blocks and is the only one that can need it; waves 1 - 3 take the
+        // top / bottom bands between the corners and the 32 middle rows.
         const unsigned car = __builtin_amdgcn_readfirstlane(q >> 8);
-        const int row = (int)((q >> 2) & 63u);
-        const int c0 = (int)(q & 3u) * 16;
+        const unsigned wv = __builtin_amdgcn_readfirstlane((q >> 6) & 3u);
+        const unsigned j = q & 63u;
+        int row, c0;
+        if (wv == 0) {
+            row = (int)(j & 15u) + ((j & 32u) ? 48 : 0);
+            c0 = (j & 16u) ? 48 : 0;
+        } else if (wv == 1) {
+            row = (int)(j & 15u) + ((j & 32u) ? 48 : 0);
+            c0 = (j & 16u) ? 32 : 16;
+        } else {
+            row = 16 + (int)(((wv - 2u) << 4) | (j >> 2));
+            c0 = (int)(j & 3u) * 16;
+        }
         uint32_t words[4] = {0u, 0u, 0u, 0u};
-        if (!p.st.fresh[car]) {                  // reset observation is all zeros, dreamer/wrappers.py:413
+        int icx, icy;
+        cell_of(t, p.st.x[car], p.st.y[car], icx, icy);
+        icx = __builtin_amdgcn_readfirstlane(icx);
+        icy = __builtin_amdgcn_readfirstlane(icy) + 1;
+        // a car tens of thousands of cells away from the grid (a diverged state) sees nothing; it also keeps X, Y in range
+        const bool sane = (unsigned)(icx + 16384) < 32768u && (unsigned)(icy + 16384) < 32768u;
+        if (!p.st.fresh[car] && sane) {          // reset observation is all zeros, dreamer/wrappers.py:413
             const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.ct[car] * RCS_PATCH_STEP_Q16));
             const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.st[car] * RCS_PATCH_STEP_Q16));
-            int icx, icy;
-            cell_of(t, p.st.x[car], p.st.y[car], icx, icy);
-            icx = __builtin_amdgcn_readfirstlane(icx);
-            icy = __builtin_amdgcn_readfirstlane(icy) + 1;
             // tap of this run's first pixel, in cells << 16, the start cell folded in: (X >> 16, Y >> 16) = (ix, iy)
             const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;
-            int X = x00 + c0 * a + row * b, Y = y00 + c0 * b - row * a;
-            // valid cells: the reference's [-110, 110) crop window around the start cell, clipped to the grid
-            const int lx = max(icx - RCS_PATCH_WINDOW_I, 0), hx = min(icx + RCS_PATCH_WINDOW_I - 1, wm1);
-            const int ly = max(icy - RCS_PATCH_WINDOW_I, 0), hy = min(icy + RCS_PATCH_WINDOW_I - 1, hm1);
-            const bool none = hx < lx || hy < ly;                          // (a car far outside the map)
-            const uint32_t sx = (uint32_t)(hx - lx), sy = (uint32_t)(hy - ly);
+            const int X = x00 + c0 * a + row * b, Y = y00 + c0 * b - row * a;
+            // the reference's [-110, 110) crop window around the start cell
+            const int lx = icx - RCS_PATCH_WINDOW_I, ly = icy - RCS_PATCH_WINDOW_I;
+            const uint32_t span = 2 * RCS_PATCH_WINDOW_I - 1;
             const int Xe = X + 15 * a, Ye = Y + 15 * b;
-            const bool ends_ok = (uint32_t)((X >> 16) - lx) <= sx && (uint32_t)((Y >> 16) - ly) <= sy &&
-                                 (uint32_t)((Xe >> 16) - lx) <= sx && (uint32_t)((Ye >> 16) - ly) <= sy;
-            if (none) {
-                // nothing to sample
-            } else if (__builtin_amdgcn_ballot_w64(!ends_ok) == 0) {
-                // every tap of every run of the wave is inside window and grid: (ix, iy) are valid, non-negative
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const uint32_t addr = mad_hi16((uint32_t)Y, pitch_b, (uint32_t)X >> 19);     // iy * pitch + ix / 8
-                    const uint32_t byte = lds_bytes[addr];
-                    const uint32_t bit = bfe_u32(byte, bfe_u32((uint32_t)X, 16, 3), 1);          // bit ix % 8
-                    words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
-                    X += a;
-                    Y += b;
-                }
+            const bool ends_ok = (uint32_t)((X >> 16) - lx) <= span && (uint32_t)((Y >> 16) - ly) <= span &&
+                                 (uint32_t)((Xe >> 16) - lx) <= span && (uint32_t)((Ye >> 16) - ly) <= span;
+            // window inside the grid (wave-uniform: a property of the car)?  then no tap can leave the grid
+            const bool inside = lx >= 0 && ly >= 0 && lx + (int)span <= t.w - 1 && ly + (int)span <= t.h - 1;
+            if (__builtin_amdgcn_ballot_w64(!ends_ok) == 0) {
+                // the two end taps of every run of the wave are inside the window, which is convex: so is every tap
+                if (inside) patch_run<false>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
+                else patch_run<true>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
             } else {
+                int Xk = X, Yk = Y;
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
-                    const int ix = X >> 16, iy = Y >> 16;
-                    const unsigned long long ok = cmp_le_u32((uint32_t)(ix - lx), sx) & cmp_le_u32((uint32_t)(iy - ly), sy);
-                    const uint32_t addr = (uint32_t)mad_i24(iy, (int)pitch_b, ix >> 3);
+                    const unsigned long long ok = cmp_le_u32((uint32_t)((Xk >> 16) - lx), span) & cmp_le_u32((uint32_t)((Yk >> 16) - ly), span);
+                    const uint32_t xc = min_u32((uint32_t)Xk, xmax), yc = min_u32((uint32_t)Yk, ymax);
+                    const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19);
                     const uint32_t byte = lds_bytes[select_mask(ok, addr, zero_addr)];
-                    const uint32_t bit = bfe_u32(byte, bfe_u32((uint32_t)X, 16, 3), 1);
+                    const uint32_t bit = bfe_u32(byte, bfe_u32(xc, 16, 3), 1);
                     words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
-                    X += a;
-                    Y += b;
+                    Xk += a;
+                    Yk += b;
                 }
             }
         }
-        __builtin_nontemporal_store(v4u_t{words[0], words[1], words[2], words[3]}, out128 + q);
+        __builtin_nontemporal_store(v4u_t{words[0], words[1], words[2], words[3]},
+                                    out128 + ((size_t)car * 256u + (unsigned)row * 4u + ((unsigned)c0 >> 4)));
     }
 }
 
