@@ -238,6 +238,7 @@ void set_launch_geometry(rc_env *env) {
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
     li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
+    li.patch_variant = env->dbg[RC_DBG_PATCH_VARIANT];
     // tuning knobs for experiments (rc_debug_set; all zero in production): workgroup size / workgroups per CU of the LDS-free scan
     if (li.raycast_variant == 7) {
         const int threads = env->dbg[RC_DBG_RAY_THREADS];

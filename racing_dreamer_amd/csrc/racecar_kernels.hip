@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void patch_run(const __attribute__((address_space(3))
     }
 }
 
-__global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items) {
+__global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items, int variant) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
     const int nwords = t.h * t.pitch;
@@ -1401,7 +1401,10 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
         const unsigned wv = __builtin_amdgcn_readfirstlane((q >> 6) & 3u);
         const unsigned j = q & 63u;
         int row, c0;
-        if (wv == 0) {
+        if (variant & 1) {                       // experiment: plain row-major runs (wave w = rows 16 w .. 16 w + 15)
+            row = (int)((wv << 4) | (j >> 2));
+            c0 = (int)(j & 3u) * 16;
+        } else if (wv == 0) {
             row = (int)(j & 15u) + ((j & 32u) ? 48 : 0);
             c0 = (j & 16u) ? 48 : 0;
         } else if (wv == 1) {
@@ -1451,8 +1454,9 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
                 }
             }
         }
-        __builtin_nontemporal_store(v4u_t{words[0], words[1], words[2], words[3]},
-                                    out128 + ((size_t)car * 256u + (unsigned)row * 4u + ((unsigned)c0 >> 4)));
+        v4u_t *dst = out128 + ((size_t)car * 256u + (unsigned)row * 4u + ((unsigned)c0 >> 4));
+        if (variant & 2) *dst = v4u_t{words[0], words[1], words[2], words[3]};          // experiment: plain stores
+        else __builtin_nontemporal_store(v4u_t{words[0], words[1], words[2], words[3]}, dst);
     }
 }
 
@@ -1750,7 +1754,7 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_PATCH * (RC_PATCH / 16);
-    launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total);
+    launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total, li.patch_variant);
     return hipGetLastError();
 }
 
