@@ -744,7 +744,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);
     const size_t cl_bytes = align_up((size_t)n_centerline * 16, 64);
     const size_t beam_bytes = align_up(beams.size() * 4, 64), foot_bytes = align_up(foot.size() * 4, 64);
-    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes + 4 * quad_plane_bytes + first_bytes;
+    const size_t spawn_bytes = align_up((size_t)n_centerline * 32, 64);
+    const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + spawn_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes + 4 * quad_plane_bytes + first_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
     env->track.reset();                                    // (frees the old tables if no other handle shares them)
     std::shared_ptr<TrackTables> tt = std::make_shared<TrackTables>();
@@ -756,6 +757,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(hipMemcpy(m, drv.data(), bm_bytes, hipMemcpyHostToDevice)); t.drv_words = (const uint32_t *)m; m += bm_bytes;
     HIP_TRY(hipMemcpy(m, progress, (size_t)h * w * 4, hipMemcpyHostToDevice)); t.progress = (const float *)m; m += prog_bytes;
     HIP_TRY(hipMemcpy(m, centerline, (size_t)n_centerline * 16, hipMemcpyHostToDevice)); t.centerline = (const float *)m; m += cl_bytes;
+    t.spawn = (const float4 *)m; m += spawn_bytes;            // filled below, on the device
     HIP_TRY(hipMemcpy(m, beams.data(), beams.size() * 4, hipMemcpyHostToDevice)); t.beams = (const float *)m; m += beam_bytes;
     HIP_TRY(hipMemcpy(m, foot.data(), foot.size() * 4, hipMemcpyHostToDevice)); t.footprint = (const float *)m; m += foot_bytes;
     HIP_TRY(hipMemcpy(m, blocks.data(), blk_bytes, hipMemcpyHostToDevice)); t.free_blocks = (const uint8_t *)m; m += blk_bytes;
@@ -789,6 +791,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     }
     HIP_TRY(rck_build_quad_planes(t, (uint16_t *)t.quad_rect, env->stream));
     HIP_TRY(rck_build_first_table(t, (uint16_t *)t.first_rect, env->stream));
+    HIP_TRY(rck_build_spawn_table(t, (float4 *)t.spawn, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
     g_track_cache[{env->cfg.device, key}] = tt;
     finish_load(tt);

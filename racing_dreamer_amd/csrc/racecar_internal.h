@@ -15,6 +15,8 @@ struct RcTrackDev {
     const uint32_t *drv_words;   // drivable area, [h][pitch]
     const float *progress;       // [h][w], < 0 outside the drivable area
     const float *centerline;     // [n_centerline][4] = x, y, heading, progress
+    const float4 *spawn;         // [n_centerline][2] = (x, y, heading, cos), (sin, progress at that cell, checkpoint as int bits, 0):
+                                 // everything a reset needs from a spawn index in one 32-byte gather (built on the device)
     const float *beams;          // [1080][2] = cos, sin of the beam angle in the sensor frame
     const float *footprint;      // [34][2] body-frame perimeter points
     const uint8_t *free_blocks;  // [blk_h][blk_w]: per (1<<blk_shift)^2-cell block, min over its cells of the
@@ -94,6 +96,7 @@ void rck_set_launch_events(hipEvent_t start, hipEvent_t stop);   // attach start
 hipError_t rck_set_lds_limits(size_t lds_bytes);
 hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch, quad_plane_bytes
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch
+hipError_t rck_build_spawn_table(const RcTrackDev &t, float4 *spawn_dev, hipStream_t s);   // needs centerline, progress, geometry
 struct RcRandomActions { int32_t on; uint32_t seed_lo, seed_hi, step; };   // on != 0: draw the actions in the dynamics kernel
 hipError_t rck_launch_dynamics(const RcParams &p, float *actions, int repeat, const RcRandomActions &ra, hipStream_t s);
 hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStream_t s);

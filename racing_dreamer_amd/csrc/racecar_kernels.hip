@@ -101,17 +101,33 @@ __device__ __forceinline__ int obb_overlap(const Car &a, const Car &b) {
 }
 
 // Reset of one env in two halves.  `prepare_reset` is everything that does not depend on how the current step ends -
-// the Philox draw keyed by (global env id, episode counter), the spawn-table gather, sin / cos of the spawn heading
-// and its progress lookup: three dependent memory round trips - so the dynamics kernel issues it next to the state
-// loads and the integrator instead of behind the step (that kernel runs one wave per SIMD: its duration is the
-// length of its dependent chain).  `apply_reset` installs the prepared poses when the env did finish.
+// the Philox draw keyed by (global env id, episode counter) and the gather of the spawn poses - so the dynamics kernel
+// issues it next to the state loads, ahead of the integrator, instead of behind the step (that kernel runs one wave
+// per SIMD: its duration is the length of its dependent chain, and a reset used to add three round trips to it in
+// nearly every wave of a random-action rollout).  `apply_reset` installs the prepared poses when the env did finish.
 struct Spawn { float x, y, th, ct, st, pr; int cp; };
 
+// The spawn table (RcTrackDev::spawn): per centerline index the pose, sin / cos of its heading (the spec's sincos32),
+// the progress value of its cell and its checkpoint - computed once per track ON THE DEVICE with the very functions a
+// reset would call, so a reset is one 32-byte gather with no arithmetic behind it.
+__global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float4 *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= t.n_centerline) return;
+    const float x = t.centerline[4 * i], y = t.centerline[4 * i + 1], th = t.centerline[4 * i + 2];
+    float sn, cs;
+    sincos32(th, sn, cs);
+    float pr = progress_at(t, x, y);
+    pr = pr < 0.0f ? 0.0f : pr;
+    int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
+    cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
+    out[2 * i] = make_float4(x, y, th, cs);
+    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp), 0.0f);
+}
+
 template <int A>
-__device__ __forceinline__ void prepare_reset(const RcParams &p, int e, Spawn (&sp)[A], uint32_t &ep) {
+__device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t ep, Spawn (&sp)[A]) {
     const RcTrackDev &t = p.trk;
     const uint32_t g = p.first_env + (uint32_t)e;
-    ep = p.st.episode[e];
     const rcd::u32x4 r = rcd::philox4x32(g, ep, 0u, 0u, p.seed_lo, p.seed_hi);
     const int n = t.n_centerline;
     const int idx0 = p.reset_mode == 0 ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r.x, (uint32_t)n);
@@ -119,16 +135,10 @@ __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, Spawn (&
     for (int a = 0; a < A; ++a) {
         int idx = (idx0 - a * RCS_BALL_GAP_BINS) % n;
         if (idx < 0) idx += n;
+        const float4 s0 = t.spawn[2 * idx], s1 = t.spawn[2 * idx + 1];
         Spawn &c = sp[a];
-        c.x = t.centerline[4 * idx + 0];
-        c.y = t.centerline[4 * idx + 1];
-        c.th = t.centerline[4 * idx + 2];
-        sincos32(c.th, c.st, c.ct);
-        float pr = progress_at(t, c.x, c.y);
-        pr = pr < 0.0f ? 0.0f : pr;
-        c.pr = pr;
-        const int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
-        c.cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
+        c.x = s0.x; c.y = s0.y; c.th = s0.z; c.ct = s0.w;
+        c.st = s1.x; c.pr = s1.y; c.cp = __float_as_int(s1.z);
     }
 }
 
@@ -228,12 +238,13 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= p.num_envs) return;
     const RcTrackDev &t = p.trk;
+    // the episode counter first: it is the oldest load in flight, so the reset's Philox draw can wait for it alone
+    const uint32_t episode = p.auto_reset ? p.st.episode[e] : 0u;
     Car car[A];
     load_cars<A>(p, e, car);
     int steps = p.st.steps[e], agent_steps = p.st.agent_steps[e];
     Spawn spawn[A];
-    uint32_t episode = 0;
-    if (p.auto_reset) prepare_reset<A>(p, e, spawn, episode);      // ahead of the step: see prepare_reset
+    if (p.auto_reset) prepare_reset<A>(p, e, episode, spawn);      // ahead of the step: see prepare_reset
     float motor[A], steer[A];
     bool any_done = false;
 #pragma unroll
@@ -377,8 +388,8 @@ __global__ __launch_bounds__(256) void rc_reset_kernel(RcParams p, const uint8_t
 #pragma unroll
     for (int a = 0; a < A; ++a) car[a].rew = 0.0f;
     Spawn spawn[A];
-    uint32_t episode;
-    prepare_reset<A>(p, e, spawn, episode);
+    const uint32_t episode = p.st.episode[e];
+    prepare_reset<A>(p, e, episode, spawn);
     apply_reset<A>(p, e, car, spawn, episode, steps, agent_steps);
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -1635,6 +1646,11 @@ hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, h
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(runs);
     return e;
+}
+
+hipError_t rck_build_spawn_table(const RcTrackDev &t, float4 *spawn_dev, hipStream_t s) {
+    hipLaunchKernelGGL(rc_build_spawn_kernel, dim3((t.n_centerline + 255) / 256), dim3(256), 0, s, t, spawn_dev);
+    return hipGetLastError();
 }
 
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s) {
