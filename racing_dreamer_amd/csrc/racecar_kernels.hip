@@ -1409,7 +1409,11 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
         // of a car takes the four 16 x 16 corner blocks and is the only one that can need it; waves 1 - 3 take the
         // top / bottom bands between the corners and the 32 middle rows.
         const unsigned car = __builtin_amdgcn_readfirstlane(q >> 8);
-        const unsigned wv = __builtin_amdgcn_readfirstlane((q >> 6) & 3u);
+        // which quarter of the car's patch this wave renders: rotated by the car index, so that the four corner waves of
+        // a workgroup's four cars sit on four different SIMDs (a workgroup's waves go to the SIMDs cyclically: with a
+        // fixed assignment all corner waves - the ones that may need the longer loop - shared ONE SIMD, and the
+        // persistent loop ran at that SIMD's pace)
+        const unsigned wv = __builtin_amdgcn_readfirstlane(((q >> 6) + car) & 3u);
         const unsigned j = q & 63u;
         int row, c0;
         if (variant & 1) {                       // experiment: plain row-major runs (wave w = rows 16 w .. 16 w + 15)

@@ -754,3 +754,27 @@ def test_mixed_track_shards_like_config_4():
             ov = ora.step(ro.random_actions(1, k, sh.num_envs, first_car=sh.first_env), repeat=4)
         compare_outputs(dv, ov, sh.num_envs, 1, f"rank {rank} on {name}")
         env.close()
+
+
+def test_every_compiled_map_steps_like_the_oracle():
+    """all 29 compiled maps of docs/maps/maps run on the device (any grid up to 4096 cells per side:
+    columbia_simple is 1083 x 1489, f1_mco 937 x 1072) - reset, three agent steps and the scan against the C oracle."""
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import available_tracks, load_track
+    from racing_dreamer_amd import spec
+    names = available_tracks()
+    assert len(names) >= 29
+    n = 48
+    for name in names:
+        track = load_track(name)
+        env = BatchedRaceEnv(track, n, 1, auto_reset=True)
+        ora = c_oracle.COracleEnv(track.occ, track.drivable, track.progress, track.centerline, track.origin,
+                                  track.resolution, ro.OracleConfig(num_envs=n, auto_reset=True), threads=8)
+        compare_outputs(env.reset(mode="random", seed=3), ora.reset(mode=spec.RESET_RANDOM, seed=3), n, 1, f"{name} reset")
+        for k in range(3):
+            act = ro.random_actions(5, k, n)
+            act[:, 0] = np.abs(act[:, 0])
+            compare_outputs(env.step(torch.from_numpy(act).cuda(), repeat=4), ora.step(act, repeat=4), n, 1, f"{name} step {k}")
+        env.close()
