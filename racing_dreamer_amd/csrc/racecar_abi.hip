@@ -237,7 +237,7 @@ void set_launch_geometry(rc_env *env) {
     const long long rays = (long long)env->n_cars * RC_N_BEAMS;
     const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
     li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
-    li.patch_blocks = blocks_for(li.lds_bytes, quads, li.patch_threads);
+    li.patch_blocks = blocks_for(li.lds_bytes ? li.lds_bytes + RC_PATCH_STAGE_BYTES : 0, quads, li.patch_threads);
     li.patch_variant = env->dbg[RC_DBG_PATCH_VARIANT];
     // tuning knobs for experiments (rc_debug_set; all zero in production): workgroup size / workgroups per CU of the LDS-free scan
     if (li.raycast_variant == 7) {
@@ -631,9 +631,10 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         set_launch_geometry(env);
         env->was_reset = false;
     };
-    const bool fits_lds_early = align_up(nwords * 4 + 4, 64) <= 160 * 1024;
-    if (!fits_lds_early && env->params.render_patch)
-        return fail(RC_ERR_INVALID, "track bitmap %zu B does not fit the 160 KiB LDS (needed for obs_type lidar_occupancy)", align_up(nwords * 4 + 4, 64));
+    const bool fits_patch = align_up(nwords * 4 + 4, 64) + RC_PATCH_STAGE_BYTES <= 160 * 1024;
+    if (!fits_patch && env->params.render_patch)
+        return fail(RC_ERR_INVALID, "track bitmap %zu B (+ %d B of staging) does not fit the 160 KiB LDS (needed for obs_type lidar_occupancy)",
+                    align_up(nwords * 4 + 4, 64), RC_PATCH_STAGE_BYTES);
     {
         auto it = g_track_cache.find({env->cfg.device, key});
         if (it != g_track_cache.end()) {
@@ -783,7 +784,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         // small track loaded after a large one would make the large one's launches fail
         static std::map<int, size_t> lds_limit;
         size_t &lim = lds_limit[env->cfg.device];
-        const size_t need = std::max(std::max(tt->lds_bytes, tt->lds_bytes_skip), tt->lds_bytes_packed);
+        const size_t need = std::min<size_t>(160 * 1024, std::max(std::max(tt->lds_bytes + RC_PATCH_STAGE_BYTES, tt->lds_bytes_skip), tt->lds_bytes_packed));
         if (need > lim || lim == 0) {
             HIP_TRY(rck_set_lds_limits(std::max(need, lim)));
             lim = std::max(need, lim);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define RC_PATCH_STAGE_BYTES 16384              // rc_patch_kernel: 1 024 lanes x 16 bytes of rendered pixels, transposed through LDS
 #define RC_NSTEP_MAX 16                        // longest n_step_progress window (sub-steps)
 #define RC_FIRST_BINS 32                       // bins of |dy / dx|: four per octave over 2^-4 .. 2^4 (outer bins open-ended)
 #define RC_FIRST_SHIFT 21                      // slope bits >> 21 = (exponent << 2) | two mantissa bits
@@ -81,7 +82,8 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one wave per workgroup
     int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
     int32_t patch_blocks, patch_threads;
-    int32_t patch_variant;       // experiment bits of the lidar_occupancy render (rc_debug_set): 1 row-major runs, 2 plain stores
+    int32_t patch_variant;       // experiment bits of the lidar_occupancy render (rc_debug_set): 1 row-major runs, 2 plain
+                                 // stores, 4 every lane stores its own 16 bytes (no transposition through LDS)
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
     size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8

@@ -1398,15 +1398,22 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     // null-based LDS pointer saves the add of the (zero) base the compiler otherwise emits per tap.
     typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
     const lds_u8_ptr lds_bytes = (lds_u8_ptr)(uint32_t)0;
+    // 16 bytes per lane, transposed through LDS before they are stored: a wave's runs are 16-byte pieces of many rows
+    // (the corner blocks), and pieces of one 64-byte line written by different waves cost HBM a partial write each
+    // (measured: 1.39 x the algorithmic bytes) - so the workgroup's 1 024 results go to LDS in image order and leave
+    // as 16 KB of consecutive bytes
+    const uint32_t stage_base = ((uint32_t)(nwords + 1) * 4u + 15u) & ~15u;
+    typedef __attribute__((address_space(3))) v4u_t *lds_v4_ptr;
+    const lds_v4_ptr stage = (lds_v4_ptr)stage_base;
     for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
         const unsigned q = base + threadIdx.x;
-        if (q >= (unsigned)total_items) break;
+        const bool live = q < (unsigned)total_items;        // (no early exit: every lane meets the barriers below)
         // 256 runs of 16 pixels per car: a wave's 64 runs belong to ONE car, so its state comes through the scalar
         // unit (its own counter) - as vector loads they shared the in-order counter with the previous item's store and
         // every item waited for that store's acknowledgement.
         // Which runs a wave gets decides how often it needs the tested loop: the pixels the 220-cell window cuts
-        // off lie in the four corners of the patch, at most 15.8 pixels from its edges whatever the heading, so wave 0
-        // of a car takes the four 16 x 16 corner blocks and is the only one that can need it; waves 1 - 3 take the
+        // off lie in the four corners of the patch, at most 15.8 pixels from its edges whatever the heading, so ONE wave
+        // of a car takes the four 16 x 16 corner blocks and is the only one that can need it; the others take the
         // top / bottom bands between the corners and the 32 middle rows.
         const unsigned car = __builtin_amdgcn_readfirstlane(q >> 8);
         // which quarter of the car's patch this wave renders: rotated by the car index, so that the four corner waves of
@@ -1430,15 +1437,16 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
             c0 = (int)(j & 3u) * 16;
         }
         uint32_t words[4] = {0u, 0u, 0u, 0u};
+        const unsigned scar = live ? car : 0u;                // (a wave is all live or all past the end)
         int icx, icy;
-        cell_of(t, p.st.x[car], p.st.y[car], icx, icy);
+        cell_of(t, p.st.x[scar], p.st.y[scar], icx, icy);
         icx = __builtin_amdgcn_readfirstlane(icx);
         icy = __builtin_amdgcn_readfirstlane(icy) + 1;
         // a car tens of thousands of cells away from the grid (a diverged state) sees nothing; it also keeps X, Y in range
         const bool sane = (unsigned)(icx + 16384) < 32768u && (unsigned)(icy + 16384) < 32768u;
-        if (!p.st.fresh[car] && sane) {          // reset observation is all zeros, dreamer/wrappers.py:413
-            const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.ct[car] * RCS_PATCH_STEP_Q16));
-            const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.st[car] * RCS_PATCH_STEP_Q16));
+        if (live && !p.st.fresh[scar] && sane) { // reset observation is all zeros, dreamer/wrappers.py:413
+            const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.ct[scar] * RCS_PATCH_STEP_Q16));
+            const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.st[scar] * RCS_PATCH_STEP_Q16));
             // tap of this run's first pixel, in cells << 16, the start cell folded in: (X >> 16, Y >> 16) = (ix, iy)
             const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;
             const int X = x00 + c0 * a + row * b, Y = y00 + c0 * b - row * a;
@@ -1469,9 +1477,24 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
                 }
             }
         }
-        v4u_t *dst = out128 + ((size_t)car * 256u + (unsigned)row * 4u + ((unsigned)c0 >> 4));
-        if (variant & 2) *dst = v4u_t{words[0], words[1], words[2], words[3]};          // experiment: plain stores
-        else __builtin_nontemporal_store(v4u_t{words[0], words[1], words[2], words[3]}, dst);
+        const v4u_t px = {words[0], words[1], words[2], words[3]};
+        const unsigned in_car = (unsigned)row * 4u + ((unsigned)c0 >> 4);              // 16-byte piece of the car's 4 KB patch
+        if (variant & 4) {                        // experiment: every lane stores its own piece
+            if (live) {
+                v4u_t *dst = out128 + ((size_t)car * 256u + in_car);
+                if (variant & 2) *dst = px;
+                else __builtin_nontemporal_store(px, dst);
+            }
+        } else {
+            stage[(threadIdx.x & ~255u) + in_car] = px;
+            __syncthreads();
+            if (live) {
+                const v4u_t lin = stage[threadIdx.x];
+                if (variant & 2) out128[q] = lin;                                      // experiment: plain stores
+                else __builtin_nontemporal_store(lin, out128 + q);
+            }
+            __syncthreads();                      // the next iteration's pieces overwrite the staging area
+        }
     }
 }
 
@@ -1774,7 +1797,7 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_PATCH * (RC_PATCH / 16);
-    launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes, s, p, total, li.patch_variant);
+    launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes + RC_PATCH_STAGE_BYTES, s, p, total, li.patch_variant);
     return hipGetLastError();
 }
 
