@@ -427,6 +427,8 @@ def main():
             out["configs"] = [time_config(*c) for c in cfgs]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
+            from oracle import cpu_baseline as cb
+            out["cpu_baseline"]["single_env"] = cb.run_single_env()      # BASELINE.json configs[0]: the B = 1 CPU step()
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -106,7 +106,34 @@ int main(int argc, char **argv) {
     for (int e = 0; e < num_envs; ++e) pmax = fmaxf(pmax, ptot[e]);
     printf("%d agent steps: mean reward per env %.3f, finished episodes %ld, lidar range [%.3f, %.3f] m, "
            "best lap+progress %.3f\n", steps, total_reward / num_envs, episodes, lo, hi, pmax);
-    const int ok = lo >= 0.0f && hi <= 15.0f && total_reward > 0.0;
+    int ok = lo >= 0.0f && hi <= 15.0f && total_reward > 0.0;
+
+    /* The multi-GPU leg from plain C: this process is rank 0 of a communicator of one (a job of N processes hands the
+     * 128-byte id of rank 0 to the others by file, socket or MPI).  The scan stores the LiDAR row a second time as
+     * uint16 into a caller-owned slab; the all-gather sends that half-size record. */
+    char id[128];
+    void *slab = NULL, *gathered = NULL;
+    const size_t cbytes = rc_compact_bytes(&cfg);
+    CHECK(rc_comm_unique_id(id, sizeof id));
+    CHECK(rc_comm_init(env, id, sizeof id, 0, 1));
+    CHECK(rc_device_alloc(env, cbytes, &slab));
+    CHECK(rc_device_alloc(env, cbytes, &gathered));
+    CHECK(rc_set_compact_slab(env, slab, cbytes));
+    CHECK(rc_follow_the_gap(env, 0.6f, 0.3f));
+    CHECK(rc_step(env, NULL, 4));
+    CHECK(rc_gather_trajectory(env, RC_GATHER_FULL_U16, gathered, cbytes));
+    CHECK(rc_gather_wait(env, 1));
+    uint16_t q[1080];
+    CHECK(rc_copy_from_device(env, gathered, q, sizeof q));                   /* rank 0's record, car 0, uint16 LiDAR */
+    CHECK(rc_copy_out(env, RC_F_LIDAR, lidar, sizeof(float) * (size_t)num_envs * 1080));
+    int q_ok = 1;
+    for (int i = 0; i < 1080; ++i) q_ok &= q[i] == (uint16_t)lrintf(lidar[i] * 4369.0f);   /* rne(v * 65535 / 15) */
+    printf("gathered %zu bytes per rank (fp32 record: %zu); uint16 scan of car 0 %s the fp32 one\n", rc_gather_bytes(env, RC_GATHER_FULL_U16),
+           rc_gather_bytes(env, RC_GATHER_FULL), q_ok ? "matches" : "DIFFERS FROM");
+    ok = ok && q_ok;
+    CHECK(rc_set_compact_slab(env, NULL, 0));
+    CHECK(rc_device_free(env, slab));
+    CHECK(rc_device_free(env, gathered));
     rc_destroy(env);
     free(occ); free(drv); free(progress); free(cl); free(lidar); free(reward); free(ptot); free(done);
     printf(ok ? "OK\n" : "FAILED\n");

@@ -191,6 +191,13 @@ int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes);
  * plus OCCUPANCY when enabled): the source buffer of the multi-GPU all-gather. */
 int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes);
 
+/* Device memory for clients that do not link the HIP runtime themselves (a plain-C learner process): allocation on the
+ * handle's device, release, and a stream-ordered copy of caller-chosen device bytes to the host.  What they hand out
+ * is ordinary device memory: usable as compact slab, gather destination or arena. */
+int rc_device_alloc(rc_env *env, size_t bytes, void **dev_ptr);
+int rc_device_free(rc_env *env, void *dev_ptr);
+int rc_copy_from_device(rc_env *env, const void *dev_src, void *host_dst, size_t bytes);
+
 /* ---- Half-size record and multi-GPU gather -------------------------------------------------------
  * The record of a step is 4 396 B per car, 4 320 of them the fp32 LiDAR row.  rc_set_compact_slab makes the scan
  * store a second copy of the row as uint16 - q = rne((v + off) * scale) with (off, scale) = (0, 65535/15) for

@@ -32,3 +32,25 @@ def run(track, cars=1, occupancy=False, repeat=1, n_envs=0, target_s=12.0):
                       f"(oracle/racecar_oracle.c, gcc -O2) on {cores} threads; the upstream PyBullet env is not "
                       f"installable here and cannot be timed",
             "os_cpu_count": os.cpu_count()}
+
+
+def run_single_env(track_name="columbia", steps=3000):
+    """BASELINE.json configs[0] - 1 env, columbia, obs_type=lidar, CPU step() - as a timing: the oracle stepped one env
+    at a time (B = 1, one core), the scalar C port and the vectorised NumPy port, random actions with auto-reset."""
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track(track_name)
+    out = {"workload": f"configs[0]: 1 env, {track_name}, obs_type=lidar, CPU step() (B = 1, one core)"}
+    cfg = ro.OracleConfig(num_envs=1, auto_reset=True)
+    for name, make, n in (("c_port_steps_per_s", lambda: c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin,
+                                                                              t.resolution, cfg, threads=1), steps),
+                          ("numpy_port_steps_per_s", lambda: ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin,
+                                                                              t.resolution, cfg), max(steps // 10, 50))):
+        env = make()
+        env.reset(mode=ro.RESET_RANDOM, seed=0)
+        acts = [ro.random_actions(1, k, 1) for k in range(n)]
+        env.step(acts[0])
+        t0 = time.perf_counter()
+        for a in acts:
+            env.step(a)
+        out[name] = n / (time.perf_counter() - t0)
+    return out

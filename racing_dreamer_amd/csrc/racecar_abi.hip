@@ -962,6 +962,31 @@ int rc_set_arena(rc_env *env, void *arena, size_t bytes) {
     return RC_OK;
 }
 
+int rc_device_alloc(rc_env *env, size_t bytes, void **dev_ptr) {
+    if (!env || !dev_ptr || bytes == 0) return fail(RC_ERR_INVALID, "NULL argument or zero size");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(hipMalloc(dev_ptr, bytes));
+    return RC_OK;
+}
+
+int rc_device_free(rc_env *env, void *dev_ptr) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!dev_ptr) return RC_OK;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    if (env->comm_stream) HIP_TRY(hipStreamSynchronize(env->comm_stream));
+    HIP_TRY(hipFree(dev_ptr));
+    return RC_OK;
+}
+
+int rc_copy_from_device(rc_env *env, const void *dev_src, void *host_dst, size_t bytes) {
+    if (!env || !dev_src || !host_dst) return fail(RC_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    return RC_OK;
+}
+
 size_t rc_compact_bytes(const rc_config *cfg) {
     if (!cfg || cfg->num_envs < 1 || cfg->cars_per_env < 1) return 0;
     const int n = cfg->num_envs * cfg->cars_per_env;

@@ -132,6 +132,8 @@ def test_plain_c_client_builds_and_runs(tmp_path):
                     f"-Wl,-rpath,{libdir}", "-lm"], check=True)
     out = subprocess.run([str(exe), "512", "120"], check=True, capture_output=True, text=True, timeout=120).stdout
     assert 'step before reset: "Must reset environment."' in out
+    # the multi-GPU leg from plain C: rc_comm_init + rc_set_compact_slab + rc_gather_trajectory (RCCL, one rank)
+    assert "uint16 scan of car 0 matches the fp32 one" in out and "gathered 1144832 bytes per rank" in out, out
     assert out.strip().endswith("OK"), out
 
 
