@@ -257,7 +257,8 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant);
  * max(w, h) * 2^value cells instead of 2^-21 - tests/test_gpu_parity.py narrows it to show that its corner-aimed rays
  * detect a band below the rounding bound.  Takes effect immediately (also after rc_load_track). */
 enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, RC_DBG_BAND_LOG2 = 3,
-       RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiments: bit 0 row-major runs, bit 1 plain stores */
+       RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiments: bit 0 row-major runs, bit 1 plain stores,
+                                       bit 2 results transposed through LDS */
        RC_DBG_COUNT = 5 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
 

@@ -83,7 +83,7 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
     int32_t patch_blocks, patch_threads;
     int32_t patch_variant;       // experiment bits of the lidar_occupancy render (rc_debug_set): 1 row-major runs, 2 plain
-                                 // stores, 4 every lane stores its own 16 bytes (no transposition through LDS)
+                                 // stores, 4 results transposed through LDS and stored as consecutive bytes
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
     size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8

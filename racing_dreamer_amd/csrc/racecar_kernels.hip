@@ -1398,10 +1398,12 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     // null-based LDS pointer saves the add of the (zero) base the compiler otherwise emits per tap.
     typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
     const lds_u8_ptr lds_bytes = (lds_u8_ptr)(uint32_t)0;
-    // 16 bytes per lane, transposed through LDS before they are stored: a wave's runs are 16-byte pieces of many rows
-    // (the corner blocks), and pieces of one 64-byte line written by different waves cost HBM a partial write each
-    // (measured: 1.39 x the algorithmic bytes) - so the workgroup's 1 024 results go to LDS in image order and leave
-    // as 16 KB of consecutive bytes
+    // Experiment (patch_variant bit 2): the 16 bytes per lane transposed through LDS before they are stored.  A wave's
+    // runs are 16-byte pieces of many rows (the corner blocks), and pieces of one 64-byte line written by different
+    // waves cost HBM a partial write each (measured: 1.39 x the algorithmic bytes against 1.07 x with row-major runs);
+    // sending the workgroup's 1 024 results through LDS in image order makes them 16 KB of consecutive bytes - and the
+    // two workgroup barriers per iteration that needs, between waves of unequal length, cost more than the partial
+    // writes: 0.1255 ms against 0.1088 (profiles/r02_b_patch_variants.txt).  Default: every lane stores its own piece.
     const uint32_t stage_base = ((uint32_t)(nwords + 1) * 4u + 15u) & ~15u;
     typedef __attribute__((address_space(3))) v4u_t *lds_v4_ptr;
     const lds_v4_ptr stage = (lds_v4_ptr)stage_base;
@@ -1479,14 +1481,14 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
         }
         const v4u_t px = {words[0], words[1], words[2], words[3]};
         const unsigned in_car = (unsigned)row * 4u + ((unsigned)c0 >> 4);              // 16-byte piece of the car's 4 KB patch
-        if (variant & 4) {                        // experiment: every lane stores its own piece
+        if (!(variant & 4)) {                     // default: every lane stores its own piece
             if (live) {
                 v4u_t *dst = out128 + ((size_t)car * 256u + in_car);
                 if (variant & 2) *dst = px;
                 else __builtin_nontemporal_store(px, dst);
             }
         } else {
-            stage[(threadIdx.x & ~255u) + in_car] = px;
+            stage[(threadIdx.x & ~255u) + in_car] = px;       // experiment: transposed through LDS (see above)
             __syncthreads();
             if (live) {
                 const v4u_t lin = stage[threadIdx.x];
