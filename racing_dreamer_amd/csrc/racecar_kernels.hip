@@ -1403,7 +1403,7 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     // waves cost HBM a partial write each (measured: 1.39 x the algorithmic bytes against 1.07 x with row-major runs);
     // sending the workgroup's 1 024 results through LDS in image order makes them 16 KB of consecutive bytes - and the
     // two workgroup barriers per iteration that needs, between waves of unequal length, cost more than the partial
-    // writes: 0.1255 ms against 0.1088 (profiles/r02_b_patch_variants.txt).  Default: every lane stores its own piece.
+    // writes: 0.1255 ms against 0.1088 (profiles/r02_b_patch_lds_transposition_experiment.txt).  Default: every lane stores its own piece.
     const uint32_t stage_base = ((uint32_t)(nwords + 1) * 4u + 15u) & ~15u;
     typedef __attribute__((address_space(3))) v4u_t *lds_v4_ptr;
     const lds_v4_ptr stage = (lds_v4_ptr)stage_base;
