@@ -239,7 +239,6 @@ void set_launch_geometry(rc_env *env) {
     li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
     li.patch_blocks = blocks_for(li.lds_bytes ? li.lds_bytes + RC_PATCH_STAGE_BYTES : 0, quads, li.patch_threads);
     li.patch_variant = env->dbg[RC_DBG_PATCH_VARIANT];
-    env->params.scan_flags = env->dbg[RC_DBG_SCAN_FLAGS];
     // tuning knobs for experiments (rc_debug_set; all zero in production): workgroup size / workgroups per CU of the LDS-free scan
     if (li.raycast_variant == 7) {
         const int threads = env->dbg[RC_DBG_RAY_THREADS];

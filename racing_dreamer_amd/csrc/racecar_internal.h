@@ -72,7 +72,6 @@ struct RcParams {
     float act_lo0, act_lo1, act_hi0, act_hi1;
     int32_t reset_mode;
     uint32_t seed_lo, seed_hi;
-    int32_t scan_flags;          // experiment bits of the scan (rc_debug_set): 1 = no sign-uniform path
     int32_t car_task[4];         // task per car slot (resolved: never -1)
     int32_t n_steps;             // window of RC_TASK_N_STEP_PROGRESS [sub-steps]
 };

@@ -857,11 +857,6 @@ __device__ __forceinline__ unsigned long long cmp_lt_f32(float a, float b) {    
     asm("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
     return m;
 }
-__device__ __forceinline__ unsigned long long cmp_lt_f32_s0(float a) {                   // lane mask of a < 0
-    unsigned long long m;
-    asm("v_cmp_gt_f32_e64 %0, 0, %1" : "=s"(m) : "v"(a));
-    return m;
-}
 __device__ __forceinline__ uint32_t select_mask_u(unsigned long long m, uint32_t a, uint32_t b) {   // m ? a : b
     uint32_t r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
@@ -1088,59 +1083,6 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
     return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
 }
 
-// The same traversal for a wave whose rays all head into ONE direction quadrant - 14 of a car's 17 rounds of 64 beams,
-// the others straddle an axis.  The sign masks are then wave-uniform values (`snx`, `sny`, -1 or 0, in scalar
-// registers): the shifted start cell, the plane offset and the band-shifted origin (`hx`, `hy`, chosen by the caller
-// from four per-car constants) come from the scalar unit instead of 9 vector instructions per round, and the first-trip
-// entry's quadrant offset too (first_trip_entry_uni).  The loop is ray_traverse's.
-__device__ __forceinline__ float ray_traverse_uni(const uint16_t *qr, const RcTrackDev &t, float gx, float gy, float dx,
-                                                  float dy, float idx, float idy, int snx, int sny, float hx, float hy,
-                                                  int ix, int iy, unsigned v) {
-    const int pitch2 = t.cell_pitch * 2;
-    const char *qb = reinterpret_cast<const char *>(qr);
-    int jx = ix - snx, jy = iy - sny;                                     // shifted cell index (a broadcast)
-    const int P = t.quad_plane_bytes;
-    const unsigned qoffp = ((unsigned)sny & (unsigned)(2 * P - pitch2)) + ((unsigned)snx & (unsigned)(P - 2));   // scalar
-    const bool started = (v & 255u) != 0;
-    const float band2 = t.band2;
-    float tt = 0.0f;
-    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) {
-        const int xe = add_sbyte<0>(v, jx);
-        const int ye = add_sbyte<1>(v, jy);
-        const v2f te = (v2f{(float)xe, (float)ye} - v2f{gx, gy}) * v2f{idx, idy};
-        const float txe = te.x, tye = te.y;
-        const unsigned long long xm = cmp_lt_f32(txe, tye);
-        tt = select_mask(xm, txe, tye);
-        const v2f zz = v2f{dx, dy} * tt + v2f{hx, hy};
-        const float z = select_mask(xm, zz.y, zz.x);
-        int on = floor_to_int(z);
-        if (cmp_lt_f32_s(__builtin_amdgcn_fractf(z), band2)) {
-            const int mx = (int)select_mask_u(xm, 0xffffffffu, 0u);
-            const int na = bfi(mx, sny, snx);
-            on = exact_other_cell(on + na, bfi(mx, jy, jx) + na, na + 1, bfi(mx, gy, gx), bfi(mx, idy, idx), tt, mx) - na;
-        }
-        jx = (int)select_mask_u(xm, (uint32_t)xe, (uint32_t)on);
-        jy = (int)select_mask_u(xm, (uint32_t)on, (uint32_t)ye);
-        unsigned a2;
-        asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(a2) : "v"(jx), "s"(qoffp));
-        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, a2));
-    }
-    if (!started) return 0.0f;
-    return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
-}
-
-// first_trip_entry with the quadrant given as wave-uniform sign masks: the quadrant's byte offset is a scalar operand
-__device__ __forceinline__ unsigned first_trip_entry_uni(const char *first_line, float dy, float idx, int snx, int sny) {
-    if (first_line == nullptr) return 0u;
-    float slope;
-    asm("v_mul_f32_e64 %0, |%1|, |%2|" : "=v"(slope) : "v"(dy), "v"(idx));
-    const unsigned bin = med3_u32(__float_as_uint(slope) >> RC_FIRST_SHIFT, RC_FIRST_BIAS, RC_FIRST_BIAS + RC_FIRST_BINS - 1);
-    const unsigned off = ((unsigned)sny & (4u * RC_FIRST_BINS)) | ((unsigned)snx & (2u * RC_FIRST_BINS));      // scalar
-    unsigned addr;
-    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(bin), "s"(off));
-    return *reinterpret_cast<const uint16_t *>(first_line + addr);
-}
-
 // One ray of the per-ray kernel (variant 6): direction made safe, start entry read from its quadrant plane.
 __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrackDev &t, float gx, float gy,
                                                 float dx, float dy, int ix, int iy) {
@@ -1273,12 +1215,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // and first-trip entry are already computed / in flight (and round r + 2's beam pair is being fetched), so no
     // round starts by waiting for its start entry.  Two register sets take turns (the loop body holds two rounds), so
     // nothing is copied between them.
-    struct Ray { float dx, dy, idx, idy; int nx, ny; unsigned v; bool uni; int snx, sny; };
-    // band-shifted origins of the two directions per axis, as scalars (ray_traverse_uni picks one per round)
-    auto uniform = [](float a) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(a))); };
-    const float hxp = uniform(gx + t.band), hxn = uniform(gx + t.band_p1);
-    const float hyp = uniform(gy + t.band), hyn = uniform(gy + t.band_p1);
-    const bool try_uni = p.scan_flags == 0;                               // (experiment knob: 1 = always the general path)
+    struct Ray { float dx, dy, idx, idy; int nx, ny; unsigned v; };
     // (dx, dy) = (ct cb - st sb, ct sb + st cb): two packed products and ONE packed add that negates only its low
     // lane's second operand (the compiler emits two packed adds for the scalar form); one rounding per operator
     auto prepare = [&](float2 b, Ray &r) {
@@ -1287,17 +1224,8 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
         r.dx = d.x; r.dy = d.y;
         ray_reciprocals(r.dx, r.dy, r.idx, r.idy);
-        // do all rays of the round head into one quadrant?  (dx < 0 is the spec's own test of the stepping direction)
-        const unsigned long long all = __builtin_amdgcn_ballot_w64(true);
-        const unsigned long long mx = cmp_lt_f32_s0(r.dx), my = cmp_lt_f32_s0(r.dy);
-        r.uni = try_uni && (mx == 0 || mx == all) && (my == 0 || my == all);
-        if (r.uni) {
-            r.snx = mx ? -1 : 0; r.sny = my ? -1 : 0;
-            r.v = first_trip_entry_uni(first_line, r.dy, r.idx, r.snx, r.sny);
-        } else {
-            r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
-            r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
-        }
+        r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
+        r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
     };
     // one round: prepare `nxt` for round + split, traverse `cur`, store.  false: this lane has no beam in the round
     auto stage = [&](int round, const Ray &cur, Ray &nxt) -> bool {
@@ -1311,12 +1239,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
             boff += bstep;
             if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
         }
-        float rng;
-        if (cur.uni)
-            rng = ray_traverse_uni(t.quad_rect, t, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.snx, cur.sny,
-                                   cur.snx ? hxn : hxp, cur.sny ? hyn : hyp, ix, iy, cur.v);
-        else
-            rng = ray_traverse(t.quad_rect, t, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ix, iy, cur.v);
+        float rng = ray_traverse(t.quad_rect, t, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ix, iy, cur.v);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll
