@@ -108,9 +108,10 @@ int main(int argc, char **argv) {
            "best lap+progress %.3f\n", steps, total_reward / num_envs, episodes, lo, hi, pmax);
     int ok = lo >= 0.0f && hi <= 15.0f && total_reward > 0.0;
 
-    /* The multi-GPU leg from plain C: this process is rank 0 of a communicator of one (a job of N processes hands the
-     * 128-byte id of rank 0 to the others by file, socket or MPI).  The scan stores the LiDAR row a second time as
-     * uint16 into a caller-owned slab; the all-gather sends that half-size record. */
+    /* The multi-GPU leg from plain C (third argument "gather"): this process is rank 0 of a communicator of one (a job
+     * of N processes hands the 128-byte id of rank 0 to the others by file, socket or MPI).  The scan stores the LiDAR
+     * row a second time as uint16 into a caller-owned slab; the all-gather sends that half-size record. */
+    if (argc > 3 && strcmp(argv[3], "gather") == 0) {
     char id[128];
     void *slab = NULL, *gathered = NULL;
     const size_t cbytes = rc_compact_bytes(&cfg);
@@ -134,6 +135,7 @@ int main(int argc, char **argv) {
     CHECK(rc_set_compact_slab(env, NULL, 0));
     CHECK(rc_device_free(env, slab));
     CHECK(rc_device_free(env, gathered));
+    }
     rc_destroy(env);
     free(occ); free(drv); free(progress); free(cl); free(lidar); free(reward); free(ptot); free(done);
     printf(ok ? "OK\n" : "FAILED\n");
