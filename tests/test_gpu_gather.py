@@ -179,3 +179,37 @@ def test_two_hip_shards_gather_the_unsharded_oracle_run():
                 if mode == "full-u16":
                     q16 = torch.cat([v["lidar_u16"] for v in views]).numpy()
                     assert np.array_equal(q16, ro.quantise_lidar_u16(o["lidar"])), (rank, k)
+
+
+def test_device_memory_helpers_of_the_c_abi():
+    """rc_device_alloc / rc_device_free / rc_copy_from_device: what a client without the HIP runtime uses for the compact
+    slab and the gather destination (examples/c_rollout.c does); here through ctypes, against the torch-owned slab."""
+    import ctypes as C
+    import torch
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv("columbia", 128, 1, auto_reset=True)
+    lib, h = env._lib, env._h
+    nbytes = lib.rc_compact_bytes(C.byref(env._cfg))
+    slab = C.c_void_p()
+    L.check(lib.rc_device_alloc(h, nbytes, C.byref(slab)))
+    assert slab.value and slab.value % 64 == 0
+    L.check(lib.rc_set_compact_slab(h, slab, nbytes))
+    env.reset(mode="random", seed=8)
+    env.step_random(seed=1, step=0, repeat=2)
+    host = np.empty(nbytes, np.uint8)
+    L.check(lib.rc_copy_from_device(h, slab, host.ctypes.data, nbytes))
+    env.enable_compact(buffers=1)                         # the same record into a torch-owned slab
+    env.step_random(seed=1, step=1, repeat=2)
+    a, b, c = env.compact_layout
+    assert a == 128 * 1080 * 2 and b + c <= nbytes
+    # the first slab still holds step 0's record: its summary section differs from step 1's, its layout is the same
+    q0 = host[:a].view(np.uint16).reshape(128, 1080)
+    assert q0.max() > 20000 and not np.array_equal(host, env.compact.cpu().numpy())
+    assert rc_ok(lib.rc_device_free(h, slab)) and rc_ok(lib.rc_device_free(h, None))
+    assert lib.rc_device_alloc(h, 0, C.byref(slab)) == -1 and b"zero size" in lib.rc_last_error()
+    env.close()
+
+
+def rc_ok(rc):
+    return rc == 0
