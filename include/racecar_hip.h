@@ -259,8 +259,7 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant);
 enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, RC_DBG_BAND_LOG2 = 3,
        RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiments: bit 0 row-major runs, bit 1 plain stores,
                                        bit 2 results transposed through LDS */
-       RC_DBG_SCAN_FLAGS = 5,       /* scan experiments: bit 0 no two-rays-per-lane form for small batches */
-       RC_DBG_COUNT = 6 };
+       RC_DBG_COUNT = 5 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
 
 /* Host-only: the beam (cos, sin) and footprint tables the kernels use (float32 [1080][2], [34][2]). */

@@ -25,9 +25,9 @@ GATHER_FULL, GATHER_FULL_U16, GATHER_SUMMARY = range(3)
 GATHER_MODES = {"full": GATHER_FULL, "full-u16": GATHER_FULL_U16, "summary": GATHER_SUMMARY}
 
 # rc_debug_set knobs (experiments / validation only; all 0 in production)
-DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2, DBG_PATCH_VARIANT, DBG_SCAN_FLAGS = range(6)
+DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2, DBG_PATCH_VARIANT = range(5)
 DEBUG_KNOBS = {"ray_threads": DBG_RAY_THREADS, "ray_split": DBG_RAY_SPLIT, "ray_wg_per_cu": DBG_RAY_WG_PER_CU,
-               "band_log2": DBG_BAND_LOG2, "patch_variant": DBG_PATCH_VARIANT, "scan_flags": DBG_SCAN_FLAGS}
+               "band_log2": DBG_BAND_LOG2, "patch_variant": DBG_PATCH_VARIANT}
 
 K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_FTG, K_COUNT = range(7)
 KERNEL_NAMES = {K_DYNAMICS: "rc_dynamics_kernel", K_RAYCAST: "rc_raycast_kernel", K_PATCH: "rc_patch_kernel",

@@ -255,7 +255,6 @@ void set_launch_geometry(rc_env *env) {
             split = (int)std::min<long long>(17, std::max<long long>(1, (want + n - 1) / n));
         }
         li.car_split = split;
-        li.car_pairs = env->dbg[RC_DBG_SCAN_FLAGS] & 1 ? 0 : 1;      // (experiment knob: bit 0 = never two rays per lane)
     } else if (li.raycast_variant >= 4) {
         const int threads = env->dbg[RC_DBG_RAY_THREADS];
         if (threads >= 64 && threads <= 1024 && threads % 64 == 0) li.ray_threads = threads;

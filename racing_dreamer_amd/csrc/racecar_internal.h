@@ -81,7 +81,6 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t ray_blocks, ray_threads;
     int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one wave per workgroup
     int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
-    int32_t car_pairs;           // with car_split > 1: the two-rays-per-lane form of the scan (rc_raycast_car_pairs_kernel)
     int32_t patch_blocks, patch_threads;
     int32_t patch_variant;       // experiment bits of the lidar_occupancy render (rc_debug_set): 1 row-major runs, 2 plain
                                  // stores, 4 results transposed through LDS and stored as consecutive bytes

@@ -1177,46 +1177,6 @@ __device__ __forceinline__ uint32_t quantise_pair(float a, float b, float off, f
 
 constexpr unsigned kCarLdsBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges
 
-// Flush a wave's ranges from its LDS row to the car's output row (and, when asked for, the uint16 copy).
-__device__ __forceinline__ void flush_ranges(const RcParams &p, const unsigned car, const unsigned part, const int split,
-                                             const unsigned lane, const char *lds_row) {
-    float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
-    // Flush the wave's ranges from LDS to the output row.  A store per round costs more than its 256 bytes: loads and
-    // stores share one in-order counter on gfx9, so the first table load of the NEXT round also waited for the
-    // store's acknowledgement from L2 (the scan ran 11 % faster with the stores removed).  Staged in LDS (its own
-    // counter), the 17 rows go out back to back at the end and nothing waits for them.
-    char *out_bytes = reinterpret_cast<char *>(out);
-    // Optional second copy of the row as uint16 (rc_set_compact_slab: the half-size record of the multi-GPU gather):
-    // q = rne((value + q_off) * q_scale), 0 .. 65535 over the row's value range - taken from the same LDS row, so it
-    // costs the scan 2 160 more bytes of stores per car and ~30 instructions.
-    char *out16 = reinterpret_cast<char *>(p.out.lidar_u16);            // wave-uniform, null when not asked for
-    if (out16 != nullptr) out16 += (size_t)car * (2 * RC_N_BEAMS);
-    const float q_off = p.lidar_transform == 1 ? 0.5f : 0.0f;
-    const float q_scale = p.lidar_transform == 0 ? 65535.0f / RCS_MAX_RANGE : 65535.0f;
-    if (split == 1) {                   // the whole row is this wave's: 270 16-byte vectors, 5 stores of 1 KB
-#pragma unroll
-        for (int k = 0; k < (RC_N_BEAMS / 4 + 63) / 64; ++k) {
-            const unsigned o = (lane + 64u * (unsigned)k) * 16u;
-            if (o < 4u * RC_N_BEAMS) {
-                const v4u val = *reinterpret_cast<const v4u *>(lds_row + o);
-                __builtin_nontemporal_store(val, reinterpret_cast<v4u *>(out_bytes + o));    // streamed: leaves the tables in L2 (1 % faster)
-                if (out16 != nullptr) {
-                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
-                    const v2u q = {quantise_pair(__uint_as_float(val.x), __uint_as_float(val.y), q_off, q_scale),
-                                   quantise_pair(__uint_as_float(val.z), __uint_as_float(val.w), q_off, q_scale)};
-                    __builtin_nontemporal_store(q, reinterpret_cast<v2u *>(out16 + (o >> 1)));
-                }
-            }
-        }
-    } else {
-        for (unsigned o = lane * 4u + 256u * part; o < 4u * RC_N_BEAMS; o += 256u * (unsigned)split) {
-            const float v = *reinterpret_cast<const float *>(lds_row + o);
-            *reinterpret_cast<float *>(out_bytes + o) = v;
-            if (out16 != nullptr) *reinterpret_cast<uint16_t *>(out16 + (o >> 1)) = (uint16_t)quantise_pair(v, v, q_off, q_scale);
-        }
-    }
-}
-
 template <int A>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
                                          const unsigned lane, char *lds_row) {
@@ -1306,127 +1266,40 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         if (round + split >= kRounds) break;
         if (!stage(round + split, rb, ra)) break;
     }
-    flush_ranges(p, car, part, split, lane, lds_row);
-}
-
-// ---- Small batches: TWO rays per lane -------------------------------------------------------------------------------
-// With fewer cars than wave slots (4 096 cars = 12 288 waves of five or six rounds on 8 192 slots) the scan is not bound
-// by instruction issue but by each wave's own dependent chain: a trip is 19 dependent instructions behind a table load.
-// This form keeps two rays of a lane in flight - rounds r and r + split of the wave's share - and advances whichever
-// of the two is still under way in every pass of ONE loop, so that the table load of one overlaps the arithmetic of
-// the other.  Per-ray arithmetic is ray_traverse's to the letter (the results are bit-identical; the parity tests
-// run this path for every batch below the threshold); there is no software pipeline across pairs (the pair's two
-// first-trip entries are requested together instead).  Launched instead of scan_car when a car's rounds are split
-// over several waves (RcLaunchInfo::car_split > 1).
-struct RayState { float dx, dy, idx, idy, hx, hy, tt; int jx, jy, nx, ny; unsigned v, qoffp; };
-
-__device__ __forceinline__ void ray_setup(RayState &r, const RcTrackDev &t, float gx, float gy, float ct, float st, float2 b,
-                                          const char *first_line, int ix, int iy) {
-    const v2f pa = v2f{b.x, b.y} * ct, pb = v2f{b.y, b.x} * st;
-    v2f d;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
-    r.dx = d.x; r.dy = d.y;
-    ray_reciprocals(r.dx, r.dy, r.idx, r.idy);
-    r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
-    r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
-    r.jx = ix - r.nx; r.jy = iy - r.ny;
-    r.hx = bfi(r.nx, gx + t.band_p1, gx + t.band); r.hy = bfi(r.ny, gy + t.band_p1, gy + t.band);
-    const int pitch2 = t.cell_pitch * 2, P = t.quad_plane_bytes;
-    r.qoffp = ((unsigned)r.ny & (unsigned)(2 * P - pitch2)) + ((unsigned)r.nx & (unsigned)(P - 2));
-    r.tt = 0.0f;
-}
-
-__device__ __forceinline__ void ray_trip(RayState &r, const RcTrackDev &t, const char *qb, float gx, float gy, int pitch2,
-                                         float band2) {
-    const int xe = add_sbyte<0>(r.v, r.jx);
-    const int ye = add_sbyte<1>(r.v, r.jy);
-    const v2f te = (v2f{(float)xe, (float)ye} - v2f{gx, gy}) * v2f{r.idx, r.idy};
-    const float txe = te.x, tye = te.y;
-    const unsigned long long xm = cmp_lt_f32(txe, tye);
-    r.tt = select_mask(xm, txe, tye);
-    const v2f zz = v2f{r.dx, r.dy} * r.tt + v2f{r.hx, r.hy};
-    const float z = select_mask(xm, zz.y, zz.x);
-    int on = floor_to_int(z);
-    if (cmp_lt_f32_s(__builtin_amdgcn_fractf(z), band2)) {
-        const int mx = (int)select_mask_u(xm, 0xffffffffu, 0u);
-        const int na = bfi(mx, r.ny, r.nx);
-        on = exact_other_cell(on + na, bfi(mx, r.jy, r.jx) + na, na + 1, bfi(mx, gy, gx), bfi(mx, r.idy, r.idx), r.tt, mx) - na;
-    }
-    r.jx = (int)select_mask_u(xm, (uint32_t)xe, (uint32_t)on);
-    r.jy = (int)select_mask_u(xm, (uint32_t)on, (uint32_t)ye);
-    r.v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(r.jy, pitch2, ((unsigned)r.jx << 1) + r.qoffp));
-}
-
-template <int A>
-__device__ __forceinline__ void scan_car_pairs(const RcParams &p, const unsigned car, const unsigned part, const int split,
-                                               const unsigned lane, char *lds_row) {
-    const RcTrackDev &t = p.trk;
-    const char *beams = reinterpret_cast<const char *>(t.beams);
-    const float4 sp = p.st.scan_pose[car];
-    float ct = sp.z, st = sp.w;
-    const bool legal = (fabsf(ct) <= 2.0f) & (fabsf(st) <= 2.0f) & ((fabsf(ct) >= 0.5f) | (fabsf(st) >= 0.5f));
-    if (!legal) { ct = 1.0f; st = 0.0f; }                               // (see scan_car)
-    const float lx = sp.x + RCS_LIDAR_X * ct, ly = sp.y + RCS_LIDAR_X * st;
-    const float gx = (lx - t.org_x) * t.inv_res, gy = (ly - t.org_y) * t.inv_res;
-    const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
-    const char *first_line = nullptr;
-    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
-        first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * RC_FIRST_BIAS;
-    constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
-    const char *qb = reinterpret_cast<const char *>(t.quad_rect);
-    const int pitch2 = t.cell_pitch * 2;
-    const float band2 = t.band2;
-    auto finish = [&](const RayState &r, bool started) -> float {
-        float rng = started ? select_mask(cmp_nlt_f32_s(r.tt, t.tmax) | cmp_ne_u32(r.v, 0u), RCS_MAX_RANGE, r.tt * t.res) : 0.0f;
-        if (A > 1) {
-            const unsigned env = car / A;
+    // Flush the wave's ranges from LDS to the output row.  A store per round costs more than its 256 bytes: loads and
+    // stores share one in-order counter on gfx9, so the first table load of the NEXT round also waited for the
+    // store's acknowledgement from L2 (the scan ran 11 % faster with the stores removed).  Staged in LDS (its own
+    // counter), the 17 rows go out back to back at the end and nothing waits for them.
+    char *out_bytes = reinterpret_cast<char *>(out);
+    // Optional second copy of the row as uint16 (rc_set_compact_slab: the half-size record of the multi-GPU gather):
+    // q = rne((value + q_off) * q_scale), 0 .. 65535 over the row's value range - taken from the same LDS row, so it
+    // costs the scan 2 160 more bytes of stores per car and ~30 instructions.
+    char *out16 = reinterpret_cast<char *>(p.out.lidar_u16);            // wave-uniform, null when not asked for
+    if (out16 != nullptr) out16 += (size_t)car * (2 * RC_N_BEAMS);
+    const float q_off = p.lidar_transform == 1 ? 0.5f : 0.0f;
+    const float q_scale = p.lidar_transform == 0 ? 65535.0f / RCS_MAX_RANGE : 65535.0f;
+    if (split == 1) {                   // the whole row is this wave's: 270 16-byte vectors, 5 stores of 1 KB
 #pragma unroll
-            for (unsigned o = 0; o < (unsigned)A; ++o) {
-                const unsigned oc = env * A + o;
-                if (oc != car) {
-                    const float tc = ray_vs_car(lx, ly, r.dx, r.dy, p.st.x[oc], p.st.y[oc], p.st.ct[oc], p.st.st[oc]);
-                    rng = tc < rng ? tc : rng;
+        for (int k = 0; k < (RC_N_BEAMS / 4 + 63) / 64; ++k) {
+            const unsigned o = (lane + 64u * (unsigned)k) * 16u;
+            if (o < 4u * RC_N_BEAMS) {
+                const v4u val = *reinterpret_cast<const v4u *>(lds_row + o);
+                __builtin_nontemporal_store(val, reinterpret_cast<v4u *>(out_bytes + o));    // streamed: leaves the tables in L2 (1 % faster)
+                if (out16 != nullptr) {
+                    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+                    const v2u q = {quantise_pair(__uint_as_float(val.x), __uint_as_float(val.y), q_off, q_scale),
+                                   quantise_pair(__uint_as_float(val.z), __uint_as_float(val.w), q_off, q_scale)};
+                    __builtin_nontemporal_store(q, reinterpret_cast<v2u *>(out16 + (o >> 1)));
                 }
             }
         }
-        if (p.lidar_transform == 1) rng = rng / RCS_MAX_RANGE - 0.5f;                 // dreamer/tools.py:274
-        else if (p.lidar_transform == 2) rng = rng * (1.0f / RCS_MAX_RANGE);          // single_agent.py:92-99
-        return rng;
-    };
-    for (int round = (int)part; round < kRounds; round += 2 * split) {
-        const int round_b = round + split;
-        const bool has_b = round_b < kRounds;                            // wave-uniform
-        const unsigned beam_a = lane + 64u * (unsigned)round, beam_b = lane + 64u * (unsigned)(has_b ? round_b : round);
-        const float2 ba = *reinterpret_cast<const float2 *>(beams + 8u * beam_a);   // (table padded to 17 x 64 entries)
-        const float2 bb = *reinterpret_cast<const float2 *>(beams + 8u * beam_b);
-        RayState a, b;
-        ray_setup(a, t, gx, gy, ct, st, ba, first_line, ix, iy);
-        ray_setup(b, t, gx, gy, ct, st, bb, first_line, ix, iy);
-        const bool live_a = beam_a < RC_N_BEAMS, live_b = has_b && beam_b < RC_N_BEAMS;
-        const bool started_a = (a.v & 255u) != 0, started_b = (b.v & 255u) != 0;
-        // every trip moves a ray at least one cell towards its quadrant and the grid is ringed by stop cells: the
-        // counter only bounds a logic error
-        for (int guard = 8192; guard != 0; --guard) {
-            const bool go_a = live_a && (a.v & 255u) != 0, go_b = live_b && (b.v & 255u) != 0;
-            if (__builtin_amdgcn_ballot_w64(go_a || go_b) == 0) break;
-            if (go_a) ray_trip(a, t, qb, gx, gy, pitch2, band2);
-            if (go_b) ray_trip(b, t, qb, gx, gy, pitch2, band2);
+    } else {
+        for (unsigned o = lane * 4u + 256u * part; o < 4u * RC_N_BEAMS; o += 256u * (unsigned)split) {
+            const float v = *reinterpret_cast<const float *>(lds_row + o);
+            *reinterpret_cast<float *>(out_bytes + o) = v;
+            if (out16 != nullptr) *reinterpret_cast<uint16_t *>(out16 + (o >> 1)) = (uint16_t)quantise_pair(v, v, q_off, q_scale);
         }
-        if (live_a) *reinterpret_cast<float *>(lds_row + 4u * beam_a) = finish(a, started_a);
-        if (live_b) *reinterpret_cast<float *>(lds_row + 4u * beam_b) = finish(b, started_b);
     }
-    flush_ranges(p, car, part, split, lane, lds_row);
-}
-
-template <int A>
-__global__ __launch_bounds__(256) void rc_raycast_car_pairs_kernel(RcParams p, int split) {
-    extern __shared__ uint32_t lds_words[];
-    char *lds_row = reinterpret_cast<char *>(lds_words) + (threadIdx.x >> 6) * (kCarLdsBytes);
-    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
-    if (car >= (unsigned)p.n_cars) return;
-    scan_car_pairs<A>(p, car, part, split, lane, lds_row);
 }
 
 template <int A>
@@ -1905,11 +1778,7 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
     if (li.raycast_variant == 7) {
         const int threads = li.car_threads, per = threads / 64;                     // waves per workgroup
         const long long waves = (long long)p.n_cars * li.car_split;
-        if (li.car_split > 1 && li.car_pairs) {      // small batch: two rays per lane (scan_car_pairs)
-            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_pairs_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
-        } else {
-            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
-        }
+        DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
     } else if (li.raycast_variant == 6) {
         DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 6>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
     } else if (li.raycast_variant == 5) {
