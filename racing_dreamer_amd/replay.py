@@ -155,3 +155,40 @@ class TrajectoryRing:
                 out["progress_total"][first, 0] = -1.0
         out["env"], out["car"], out["t0"], out["terminal"] = e, c, t0, terminal
         return out
+
+
+class ShardedReplay:
+    """The multi-GPU form of the replay store that needs no per-step collective: every rank keeps the
+    records of ITS envs in its own `TrajectoryRing`, and what crosses the links is the training batch - each rank draws
+    `batch / world` windows from its shard and an all-gather over `torch.distributed` (backend "nccl" = RCCL; "gloo" in
+    the CPU tests) hands every rank the same global batch: 50 x 50 windows of the 2 236-byte record are 5.6 MB per
+    train step, where gathering every step's records of 65 536 envs is 147 MB per GPU per 0.23 ms.  This is the
+    concat of `Collect` -> `save_episodes` -> `load_episodes` (dreamer/wrappers.py:213-219, dreamer/tools.py:235-264)
+    at the granularity its consumer reads it."""
+
+    def __init__(self, ring: TrajectoryRing, group=None):
+        import torch.distributed as dist
+        self.ring, self.group, self._dist = ring, group, dist
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def sample(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
+               generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        """`batch` windows in total (a multiple of the world size), rank r's `batch / world` at rows
+        [r * batch / world, (r + 1) * batch / world); `env` holds this rank's LOCAL env indices, `rank` the owner."""
+        if batch % self.world:
+            raise ValueError(f"batch {batch} is not a multiple of the world size {self.world}")
+        local = self.ring.sample(batch // self.world, length, fields=fields, generator=generator)
+        out = {}
+        host_bounce = self._dist.get_backend(self.group) == "gloo"
+        for name, t in local.items():
+            src = t.contiguous()
+            if host_bounce and src.is_cuda:                  # gloo has no device collectives (functional tests only)
+                src = src.cpu()
+            # (collectives know neither uint16 nor bool on every backend: send their bits)
+            wide = src.view(torch.int16) if src.dtype == torch.uint16 else (src.to(torch.uint8) if src.dtype == torch.bool else src)
+            dst = torch.empty((batch,) + tuple(wide.shape[1:]), dtype=wide.dtype, device=wide.device)
+            self._dist.all_gather_into_tensor(dst, wide, group=self.group)          # rank r's rows at r * batch / world
+            dst = dst.view(torch.uint16) if src.dtype == torch.uint16 else (dst.to(torch.bool) if src.dtype == torch.bool else dst)
+            out[name] = dst.to(t.device)
+        out["rank"] = torch.arange(self.world, device=out["env"].device).repeat_interleave(batch // self.world)
+        return out

@@ -164,3 +164,48 @@ def test_compact_and_summary_views_parse_the_documented_layout():
     assert m["inbound_bytes_per_gpu_per_step"] == 7 * 65536 * 4396 and 3.5 < m["link_bound_ms_per_step"] < 4.0
     assert gather_link_model(65536 * 4396, 1)["link_bound_ms_per_step"] == 0.0
     assert gather_link_model(65536 * 76, 2)["link_bound_ms_per_step"] == pytest.approx(65536 * 76 / 76.8e9 * 1e3)
+
+
+def _replay_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_replay import FakeEnv
+    from racing_dreamer_amd.replay import ShardedReplay, TrajectoryRing
+    env = FakeEnv(num_envs=4, cars=1)
+    ring = TrajectoryRing(env, capacity=8)
+    ring.reset()
+    for _ in range(9):
+        ring.step()
+        ring.fields["lidar"][ring.head] += 100.0 * rank          # mark this rank's records
+    g = torch.Generator().manual_seed(10 + rank)
+    batch = ShardedReplay(ring).sample(batch=12, length=3, generator=g)
+    q.put((rank, {k: v.numpy() for k, v in batch.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_replay_gathers_the_training_batch_not_the_records():
+    """each rank samples batch / world windows from its own ring; every rank ends up with the same global
+    batch, rank r's windows in rows [r * batch / world, ...)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replay_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = results[0], results[1]
+    assert sorted(a) == sorted(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k                      # the same global batch on both ranks
+    assert a["lidar"].shape == (12, 3, 8) and a["rank"].tolist() == [0] * 6 + [1] * 6
+    owner = (a["lidar"][:, 0, 0] >= 100.0).astype(int)              # rank 1 marked its records with + 100
+    assert owner.tolist() == a["rank"].tolist()
+    r = a["reward"]
+    assert np.all(r[:, 1:] - r[:, :-1] == 1.0)                      # windows are consecutive steps
