@@ -213,3 +213,63 @@ def test_device_memory_helpers_of_the_c_abi():
 
 def rc_ok(rc):
     return rc == 0
+
+
+def _replay_rank(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from racing_dreamer_amd.batched_env import BatchedRaceEnv
+        from racing_dreamer_amd.distributed import shard_envs
+        from racing_dreamer_amd.replay import ShardedReplay, TrajectoryRing
+        sh = shard_envs(64, rank, world)
+        env = BatchedRaceEnv("columbia", sh.num_envs, 1, auto_reset=True, first_env=sh.first_env)
+        ring = TrajectoryRing(env, capacity=8)
+        ring.reset(mode="random", seed=2)
+        for k in range(10):
+            env.fill_random_actions(seed=3, step=k)
+            ring.step(None, repeat=2)
+        g = torch.Generator(device="cuda").manual_seed(5 + rank)
+        batch = ShardedReplay(ring).sample(batch=8, length=3, generator=g, fields=("lidar", "reward", "time", "fresh", "done"))
+        # this rank's rows, re-read from its own ring
+        oldest = (ring.head + 1) % ring.capacity
+        mine = slice(4 * rank, 4 * rank + 4)
+        ok = True
+        for j in range(4):
+            t0, e = int(batch["t0"][mine][j]), int(batch["env"][mine][j])
+            slots = [(oldest + t0 + i) % ring.capacity for i in range(3)]
+            want = torch.stack([ring.fields["time"][s, e, 0] for s in slots])
+            ok &= bool(torch.equal(batch["time"][mine][j].cpu(), want.cpu()))
+        q.put((rank, ok, {k: v.cpu().numpy() for k, v in batch.items()}))
+        env.close()
+    except Exception as e:          # noqa: BLE001
+        q.put((rank, False, repr(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_replay_on_two_hip_rings():
+    """Each rank keeps its shard's records in its own device-resident ring; the sampled training batch is what the
+    collective carries: both ranks end up with the same 8 windows, 4 from each ring."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_replay_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, ok0, a), (r1, ok1, b) = sorted(results, key=lambda t: t[0])
+    assert ok0 and ok1, (a if not ok0 else b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["lidar"].shape == (8, 3, 1080) and a["rank"].tolist() == [0, 0, 0, 0, 1, 1, 1, 1]
+    dt = a["time"][:, 1:] - a["time"][:, :-1]
+    inner = dt[a["fresh"][:, 1:] == 0]
+    assert np.allclose(inner, 0.02, atol=1e-6)                      # consecutive agent steps of 2 sub-steps
