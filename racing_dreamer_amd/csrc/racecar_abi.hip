@@ -322,8 +322,10 @@ int observe(rc_env *env) {
 
 Rccl g_rccl;
 std::string g_rccl_path;
+std::mutex g_rccl_mutex;
 
 int load_rccl() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);       // handles may be set up from different threads
     if (g_rccl.handle) return RC_OK;
     void *h = nullptr;
     if (!g_rccl_path.empty()) {

@@ -1196,7 +1196,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // has to terminate.  With a legal pair and the beam table's entries all non-zero (checked at rc_load_track) at
     // least one of the two products in dx = ct cb - st sb and in dy = st cb + ct sb is non-zero, so neither
     // component can be -0.0, which the spec would step as +.
-    const bool legal = (fabsf(ct) <= 2.0f) & (fabsf(st) <= 2.0f) & ((fabsf(ct) >= 0.5f) | (fabsf(st) >= 0.5f));
+    const bool legal = ((int)(fabsf(ct) <= 2.0f) & (int)(fabsf(st) <= 2.0f) & ((int)(fabsf(ct) >= 0.5f) | (int)(fabsf(st) >= 0.5f))) != 0;
     if (!legal) { ct = 1.0f; st = 0.0f; }
     const float lx = car_x + RCS_LIDAR_X * ct;
     const float ly = car_y + RCS_LIDAR_X * st;
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     // writes: 0.1255 ms against 0.1088 (profiles/r02_b_patch_lds_transposition_experiment.txt).  Default: every lane stores its own piece.
     const uint32_t stage_base = ((uint32_t)(nwords + 1) * 4u + 15u) & ~15u;
     typedef __attribute__((address_space(3))) v4u_t *lds_v4_ptr;
-    const lds_v4_ptr stage = (lds_v4_ptr)stage_base;
+    const lds_v4_ptr stage = (lds_v4_ptr)(uintptr_t)stage_base;
     for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
         const unsigned q = base + threadIdx.x;
         const bool live = q < (unsigned)total_items;        // (no early exit: every lane meets the barriers below)
