@@ -1383,44 +1383,6 @@ __device__ __forceinline__ void patch_run(const __attribute__((address_space(3))
     }
 }
 
-// The same run with two-operand instructions where the form above has three-operand ones (the 4.3-cycle class): the
-// tap's aligned DWORD is read instead of its byte, so the bit index is the low five bits of X >> 16 as the shift
-// instruction takes them (no field extract), and the bit goes into byte k of the result through an SDWA `and` that
-// preserves the other bytes (no shift-or): add, add, shift, mad, and, shift, LDS read, shift, and = 8 instructions of
-// which one is of the expensive class, against 7 with four.
-template <int B>
-__device__ __forceinline__ void put_bit(uint32_t &acc, uint32_t shifted, uint32_t one) {          // byte B of acc = shifted & 1
-    if (B == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(shifted), "v"(one));
-    if (B == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(shifted), "v"(one));
-    if (B == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(shifted), "v"(one));
-    if (B == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(shifted), "v"(one));
-}
-
-template <bool CLAMP, int K>
-__device__ __forceinline__ void patch_tap_dw(const __attribute__((address_space(3))) uint8_t *lds, int &X, int &Y, int a, int b,
-                                             uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t (&words)[4], uint32_t one) {
-    const uint32_t xc = CLAMP ? min_u32((uint32_t)X, xmax) : (uint32_t)X;
-    const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, ymax) : (uint32_t)Y;
-    const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19) & ~3u;                    // the tap's dword
-    const uint32_t word = *reinterpret_cast<const __attribute__((address_space(3))) uint32_t *>(lds + addr);
-    uint32_t shifted;
-    asm("v_lshrrev_b32 %0, %1, %2" : "=v"(shifted) : "v"(xc >> 16), "v"(word));    // >> (ix % 32): the low 5 bits of the count
-    put_bit<K & 3>(words[K >> 2], shifted, one);
-    X += a;
-    Y += b;
-}
-
-template <bool CLAMP>
-__device__ __forceinline__ void patch_run_dw(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
-                                             uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t (&words)[4]) {
-    uint32_t one = 1u;
-    asm("" : "+v"(one));                                                            // (a register: SDWA takes no literal)
-#define RC_TAP(K) patch_tap_dw<CLAMP, K>(lds, X, Y, a, b, pitch_b, xmax, ymax, words, one)
-    RC_TAP(0); RC_TAP(1); RC_TAP(2); RC_TAP(3); RC_TAP(4); RC_TAP(5); RC_TAP(6); RC_TAP(7);
-    RC_TAP(8); RC_TAP(9); RC_TAP(10); RC_TAP(11); RC_TAP(12); RC_TAP(13); RC_TAP(14); RC_TAP(15);
-#undef RC_TAP
-}
-
 __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items, int variant) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
@@ -1500,13 +1462,8 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
             const bool inside = lx >= 0 && ly >= 0 && lx + (int)span <= t.w - 1 && ly + (int)span <= t.h - 1;
             if (__builtin_amdgcn_ballot_w64(!ends_ok) == 0) {
                 // the two end taps of every run of the wave are inside the window, which is convex: so is every tap
-                if (variant & 8) {                // experiment: the three-operand byte form
-                    if (inside) patch_run<false>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
-                    else patch_run<true>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
-                } else {
-                    if (inside) patch_run_dw<false>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
-                    else patch_run_dw<true>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
-                }
+                if (inside) patch_run<false>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
+                else patch_run<true>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
             } else {
                 int Xk = X, Yk = Y;
 #pragma unroll
