@@ -14,7 +14,10 @@ SOURCES = ["racecar_kernels.hip", "racecar_abi.hip"]
 HEADERS = ["racecar_device.h", "racecar_internal.h", "racecar_spec.h", os.path.join("..", "..", "include", "racecar_hip.h")]
 # -ffp-contract=off: the env spec is "one IEEE fp32 operation per written operator" (DESIGN.md §2);
 # a fused multiply-add would break bit-exact parity with the CPU oracle.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wall",
+# -fno-slp-vectorize: packed fp32 (v_pk_*_f32) issues at half rate on gfx950, i.e. buys nothing over two scalar
+# operations, and costs register-pair copies, explicit |x| / -x operands and wait states (tools/ubench/valu_issue4.hip);
+# the places where a packed form does help are written as explicit vector types.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-std=c++17", "-Wall",
          "-Wno-unused-function"]
 
 

@@ -274,7 +274,7 @@ void set_band(rc_env *env) {
     RcTrackDev &t = env->params.trk;
     const int l2 = env->dbg[RC_DBG_BAND_LOG2];
     t.band = std::ldexp((float)(std::max(t.w, t.h) + 2), (l2 <= -10 && l2 >= -40) ? l2 : -21);
-    t.band_p1 = 1.0f + t.band;
+    t.band_mh = t.band - 0.5f;
     t.band2 = 2.0f * t.band;
 }
 
@@ -777,7 +777,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     t.org_x = origin_x; t.org_y = origin_y; t.res = resolution;
     t.inv_res = 1.0f / resolution;
     t.tmax = RCS_MAX_RANGE * t.inv_res;
-    t.band = t.band_p1 = t.band2 = 0.0f;                   // per handle: set_band
+    t.band = t.band_mh = t.band2 = 0.0f;                   // per handle: set_band
     // launch geometry: persistent workgroups, the whole bitmap resident in each workgroup's LDS
     tt->lds_bytes = fits_lds ? bm_bytes : 0;
     tt->lds_bytes_skip = bm_bytes + blk_bytes <= 160 * 1024 ? bm_bytes + blk_bytes : 0;

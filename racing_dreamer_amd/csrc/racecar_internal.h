@@ -26,7 +26,9 @@ struct RcTrackDev {
     int32_t cell_pitch;
     const uint16_t *quad_rect;   // [4][h][cell_pitch]: per direction quadrant q = (dy < 0) * 2 + (dx < 0) and cell, a free
                                  // rectangle with that cell at its corner, extending towards the quadrant:
-                                 // width | height << 8 in cells (1..255 each), 0 = stop cell
+                                 // width | height << 8 in cells (1..255 each), 0 = wall, 0x0100 = sentinel ring.
+                                 // Plane q is stored MIRRORED: columns reversed when q & 1, rows when q & 2, so that
+                                 // every ray walks its plane towards increasing addresses (racecar_kernels.hip)
     int32_t quad_plane_bytes;    // bytes per quadrant plane
     const uint16_t *first_rect;  // [h][cell_pitch][RC_FIRST_PLANES]: first-trip rectangles by quadrant and slope bin (variant 7)
     const uint32_t *packed_blocks; // [blk_h][blk_w] for 4x4 blocks: bits 0-15 occupancy of the block's cells
@@ -34,8 +36,8 @@ struct RcTrackDev {
     int32_t blk_w, blk_h, blk_shift, blk_bytes, packed_bytes, packed_w;   // packed_w: uint32 per packed row
     int32_t h, w, pitch, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
-    float band, band_p1, band2;  // scan variants 6/7: half-width of the zone around a cell boundary in which the other-axis cell
-                                 // is counted exactly = (max(w, h) + 2) * 2^-21 cells; 1 + band; 2 * band
+    float band, band_mh, band2;  // scan variants 6/7: half-width of the zone around a cell boundary in which the other-axis cell
+                                 // is counted exactly = (max(w, h) + 2) * 2^-21 cells; band - 0.5; 2 * band
 };
 
 struct RcStateDev {              // persistent per-car / per-env simulator state (SoA)

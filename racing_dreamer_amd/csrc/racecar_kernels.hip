@@ -900,12 +900,25 @@ __device__ __forceinline__ float min_with(float a, float hi) {
     return r;
 }
 
-// Table entry (uint16 per quadrant plane and cell): byte 0 = signed x offset from the SHIFTED cell index to the
-// boundary that leaves the rectangle (+width for a ray heading +x, -width for -x), byte 1 the same for y; a wall
-// is 0x0000 and a cell of the sentinel ring 0x0100, so "stop" <=> byte 0 == 0 and "no return" <=> entry != 0
-// at the stop.  Shifted index: j = i for a positive direction, i + 1 for a negative one - then the boundary is
-// j + offset for both signs and the shifted index of the cell behind that boundary is the boundary itself, so a
-// trip needs no sign arithmetic at all.
+// Table entry (uint16 per quadrant plane and cell): byte 0 = width, byte 1 = height (1..255 cells) of a free rectangle
+// with the cell at its corner, extending towards the quadrant; a wall is 0x0000 and a cell of the sentinel ring 0x0100,
+// so "stop" <=> byte 0 == 0 and "no return" <=> entry != 0 at the stop.
+//
+// THE MIRRORED FRAME.  The traversal negates every axis on which the ray heads towards -: position g~ = -g, direction
+// |d|, reciprocal |1/d|, cell index i~ = floor(-p) = ~i, boundary b~ = -b.  Negation is exact and IEEE arithmetic is
+// symmetric under it, so every boundary time fl(fl(b~ - g~) * |1/d|) is bit-identical to the spec's fl(fl(b - g) * (1/d))
+// and the comparisons (including "ties go to y") are the same - but in that frame EVERY ray heads towards + on both
+// axes: the boundary that leaves a rectangle is i~ + width, the cell behind it has that very index, and a trip holds
+// no sign arithmetic.  The quadrant planes are stored mirrored to match (plane q: columns reversed when q & 1, rows
+// when q & 2), so a cell's entry sits at plane(q) + 2 (i~x + (q & 1 ? w : 0)) + pitch2 (i~y + (q & 2 ? h : 0)).
+//
+// Cell indices as float bits.  T = bits(1.5 * 2^23 + i~) = 0x4b400000 + i~ (|i~| < 2^22): adding an integer to T is
+// adding it to the float, bits(z + 1.5 * 2^23) is 0x4b400000 + rne(z), and as_float(T) - 1.5 * 2^23 is the index as a
+// float, exactly.  The conversions of a trip (int -> float for the two boundaries, float -> int for the new cell)
+// become one full-rate add / subtract each; on gfx950 v_cvt_*, v_floor, v_fract, SDWA forms, v_bfi, v_cndmask, compares,
+// min / max, every three-operand integer op AND any op that reads an SGPR issue at half the rate of
+// v_add / v_sub / v_mul / v_fma_f32, v_add / v_sub_u32, v_and / v_or / v_xor and the right shifts
+// (tools/ubench/valu_issue4.hip), and this kernel is bound by exactly that issue rate.
 // ---- First-trip table (RcTrackDev::first_rect) --------------------------------------------------------------
 // All 1080 rays of a car start in the same cell, so the FIRST rectangle of every ray can come from a much richer
 // table than the four quadrant planes without any cache cost: a car reads one 256-byte line per step.  Per cell
@@ -943,7 +956,7 @@ __global__ __launch_bounds__(256) void rc_build_first_kernel(RcTrackDev t, uint1
     const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane group q = (dy < 0) * 2 + (dx < 0)
     const bool swap = bin >= RC_FIRST_BINS / 2;
     const RcFirstBin b = c_first_bins[bin];
-    const int cap = 127;
+    const int cap = 255;
     int hmax = cap, bw = 1, bh = 1;
     float best = -1.0f;
     for (int c = 0; c < cap; ++c) {
@@ -959,22 +972,22 @@ __global__ __launch_bounds__(256) void rc_build_first_kernel(RcTrackDev t, uint1
         const float sc = fminf((float)pw * b.ka0, (float)ph * b.kb0) + fminf((float)pw * b.ka1, (float)ph * b.kb1);
         if (sc > best) { best = sc; bw = pw; bh = ph; }
     }
-    e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
+    e = (uint16_t)(bw | (bh << 8));
 }
 
 // ---- Quadrant planes (RcTrackDev::quad_rect), built on the device --------------------------------------------------
-// Free run length from every cell towards -x and towards +x (capped at 127; 0 on a stop cell): one thread per row.
+// Free run length from every cell towards -x and towards +x (capped at 255; 0 on a stop cell): one thread per row.
 __global__ __launch_bounds__(256) void rc_build_runs_kernel(RcTrackDev t, uint8_t *__restrict__ run_neg, uint8_t *__restrict__ run_pos) {
     const int iy = blockIdx.x * blockDim.x + threadIdx.x;
     if (iy >= t.h) return;
     int r = 0;
     for (int ix = 0; ix < t.w; ++ix) {                          // towards -x: cells ix, ix - 1, ... are free
-        r = bit_at(t.ray_words, t.pitch, ix, iy) ? 0 : min(r + 1, 127);
+        r = bit_at(t.ray_words, t.pitch, ix, iy) ? 0 : min(r + 1, 255);
         run_neg[(size_t)iy * t.w + ix] = (uint8_t)r;
     }
     r = 0;
     for (int ix = t.w - 1; ix >= 0; --ix) {
-        r = bit_at(t.ray_words, t.pitch, ix, iy) ? 0 : min(r + 1, 127);
+        r = bit_at(t.ray_words, t.pitch, ix, iy) ? 0 : min(r + 1, 255);
         run_pos[(size_t)iy * t.w + ix] = (uint8_t)r;
     }
 }
@@ -989,18 +1002,20 @@ __global__ __launch_bounds__(256) void rc_build_quad_kernel(RcTrackDev t, const 
     const int q = (int)(gid & 3u);
     const unsigned cell = gid >> 2;
     const int ix = (int)(cell % (unsigned)t.w), iy = (int)(cell / (unsigned)t.w);
-    uint16_t &e = out[(size_t)q * (t.quad_plane_bytes / 2) + (size_t)iy * t.cell_pitch + ix];
+    const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane q = (dy < 0) * 2 + (dx < 0)
+    // mirrored storage: a ray heading -x reads its plane with the columns reversed (likewise -y and the rows)
+    const int rx = sx > 0 ? ix : t.w - 1 - ix, ry = sy > 0 ? iy : t.h - 1 - iy;
+    uint16_t &e = out[(size_t)q * (t.quad_plane_bytes / 2) + (size_t)ry * t.cell_pitch + rx];
     if (ix == 0 || iy == 0 || ix == t.w - 1 || iy == t.h - 1) { e = 0x0100; return; }       // sentinel ring: "no return"
     if (bit_at(t.ray_words, t.pitch, ix, iy)) { e = 0; return; }                              // wall
-    const int sx = (q & 1) ? -1 : 1, sy = (q & 2) ? -1 : 1;       // plane q = (dy < 0) * 2 + (dx < 0)
     const uint8_t *run = sx > 0 ? run_pos : run_neg;
     // 1 / cos and 1 / sin of the four sample directions
     const float ka[4] = {1.0195911f, 1.2026898f, 1.7999525f, 5.1258309f};
     const float kb[4] = {5.1258309f, 1.7999525f, 1.2026898f, 1.0195911f};
     const float log_ka_sum = __logf(ka[0]) + __logf(ka[1]) + __logf(ka[2]) + __logf(ka[3]);
-    int cur = 127, bw = 1, bh = 1;
+    int cur = 255, bw = 1, bh = 1;
     float best = -1.0e30f;
-    for (int n = 1; n <= 127; ++n) {
+    for (int n = 1; n <= 255; ++n) {
         const int y = iy + (n - 1) * sy;
         if (y < 0 || y >= t.h) break;
         cur = min(cur, (int)run[(size_t)y * t.w + ix]);
@@ -1011,7 +1026,7 @@ __global__ __launch_bounds__(256) void rc_build_quad_kernel(RcTrackDev t, const 
         for (int k = 0; k < 4; ++k) sc += __logf(fminf((float)cur * ka[k], (float)n * kb[k]));
         if (sc > best) { best = sc; bw = cur; bh = n; }
     }
-    e = (uint16_t)(((sx * bw) & 0xff) | (((sy * bh) & 0xff) << 8));
+    e = (uint16_t)(bw | (bh << 8));
 }
 
 // The start cell's entry for a ray of direction (dx, dy): quadrant from the signs, slope bin from the float bits of
@@ -1029,58 +1044,109 @@ __device__ __forceinline__ unsigned first_trip_entry(const char *first_line, flo
     return *reinterpret_cast<const uint16_t *>(first_line + addr);
 }
 
-// Other-axis cell after an exit: z = (origin + band) + tt * d, cell = floor(z), trusted unless fract(z) < 2 band,
-// i.e. unless the position lies within `band` of a cell boundary; then the spec's own comparisons decide
-// (exact_other_cell).  How wide the band must be: with M = the largest coordinate on the grid (cells), the spec
-// crosses boundary b iff fl(fl(b - g) * fl(1/d)) < tt, which differs from the real-number test "b before the
-// position at time tt" by at most 3 roundings = 1.8e-7 M cells, and z carries 3 roundings of its own (origin + band,
-// the product, the sum), another 1.8e-7 M.  band = M * 2^-21 = 4.8e-7 M covers their sum with 30 % to spare: 2.6e-4
-// cell on austria (548 cells wide), 1e-3 on a 2048-cell map.  (The band used to be a fixed 1e-3: a wave took the
-// exact path whenever one of its lanes was inside, 8.6 % of all trips on austria; now 2.3 %.)
-// The traversal proper: from start cell (ix, iy) with start entry v, direction (dx, dy) (finite, never -0.0), its
-// reciprocals and sign masks nx, ny (-1 for a negative component, 0 otherwise).
-__device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, float gx, float gy, float dx,
-                                              float dy, float idx, float idy, int nx, int ny, int ix, int iy, unsigned v) {
+// ---- The traversal (variants 6 and 7), in the mirrored frame with cell indices as float bits (see above) ----------
+constexpr float kCellMagic = 12582912.0f;               // 1.5 * 2^23
+constexpr uint32_t kCellMagicBits = 0x4b400000u;        // its bit pattern: T = kCellMagicBits + i~
+
+// What a trip needs besides the ray.  The per-car kernel holds these in VECTOR registers (pin_vgpr): a full-rate
+// vector instruction that reads a scalar register issues at half rate.
+struct TravConst {
+    float band_mh, res;        // band - 0.5 (see below); metres per cell
+    uint32_t kx, ky, c00;      // plane address = 2 Tx + pitch2 (Ty mod 2^24) + c00 + (dx < 0 ? kx : 0) + (dy < 0 ? ky : 0), mod 2^32
+};
+__device__ __forceinline__ TravConst trav_const(const RcTrackDev &t) {
+    const uint32_t pitch2 = 2u * (uint32_t)t.cell_pitch, P = (uint32_t)t.quad_plane_bytes;
+    // plane q = 2 (dy < 0) + (dx < 0) starts at q P; a mirrored axis adds the grid's extent to its index (i~ = ~i >= -w);
+    // c00 takes the magic out of 2 Tx and pitch2 (Ty mod 2^24) again
+    return {t.band_mh, t.res, P + 2u * (uint32_t)t.w, 2u * P + pitch2 * (uint32_t)t.h, 0u - 2u * kCellMagicBits - pitch2 * 0x400000u};
+}
+__device__ __forceinline__ float pin_vgpr(float x) { float r; asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+__device__ __forceinline__ uint32_t pin_vgpr(uint32_t x) { uint32_t r; asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+__device__ __forceinline__ int pin_vgpr(int x) { int r; asm("v_mov_b32 %0, %1" : "=v"(r) : "s"(x)); return r; }
+
+// The exact other-axis cell after the exit crossing at time tt (all in the mirrored frame: the ray heads towards +).
+// est_T / cur_T: the estimated new cell (off by at most one) and the current one as float bits, og / oid the origin and
+// |1 / d| on that axis.  The spec's traversal crosses boundary b before the exit iff t_b < tt, or t_b == tt when the
+// exit is an x crossing (tie != 0: "ties go to y"); boundary times can be -0.0, so these are IEEE comparisons.
+__device__ __forceinline__ uint32_t exact_other_cell_m(uint32_t est_T, uint32_t cur_T, float og, float oid, float tt, uint32_t tie) {
+    const int m0 = max((int)(est_T - cur_T) - 1, 0);
+    const uint32_t b0T = cur_T + 1u + (uint32_t)m0;                       // first boundary that is in doubt
+    const float b0 = __uint_as_float(b0T) - kCellMagic;
+    const float tb0 = (b0 - og) * oid, tb1 = ((b0 + 1.0f) - og) * oid;
+    const uint32_t c0 = (tb0 < tt || (tie != 0 && tb0 == tt)) ? 1u : 0u;
+    const uint32_t c1 = (tb1 < tt || (tie != 0 && tb1 == tt)) ? 1u : 0u;
+    return b0T - 1u + c0 + c1;
+}
+
+// New cell after an exit: z = (g~ + band - 0.5) + tt |d| on BOTH axes, T = bits(z + 1.5 * 2^23), i.e. the cell is
+// rne(z) = floor(position + band) - except at an exact tie, which the band test below catches.  On the exit axis the
+// position is the boundary xe itself up to the rounding of g~ + fl(fl(xe - g~) |1/d|) |d| (six roundings on values
+// <= M = the largest coordinate on the grid: 3.6e-7 M cells), so floor(xe + band +- 3.6e-7 M) = xe: no select between
+// "the boundary" and "floor of the position" is needed.  On the other axis floor(position + band) is trusted unless
+// fract(z + 0.5) < 2 band, i.e. unless the position lies within `band` of a cell boundary; then the spec's own
+// comparisons decide (exact_other_cell_m).  How wide the band must be: the spec crosses boundary b iff
+// fl(fl(b - g) * fl(1/d)) < tt, which differs from the real-number test "b before the position at time tt" by at
+// most 3 roundings = 1.8e-7 M cells, z carries 3 roundings of its own, another 1.8e-7 M, and the sum z + 0.5 of the
+// test one more (0.6e-7 M): a position is in doubt only if z + 0.5 lands in [k, k + band + 4.2e-7 M) for an integer k.
+// band = M * 2^-21 = 4.8e-7 M covers both requirements (band > 3.6e-7 M, 2 band > band + 4.2e-7 M): 2.6e-4 cell on
+// austria (548 cells wide), 1e-3 on a 2048-cell map.  tools/band_validation.sh: the parity tests fail for bands
+// <= M 2^-26 and pass from M 2^-24 on.
+// The traversal proper: from start cell (ix, iy) with start entry v (FROM_PLANE: read from the ray's plane instead, 0
+// when !in_grid), direction (dx, dy) (finite, never -0.0), its reciprocals and sign masks nx, ny (-1 for a negative
+// component, 0 otherwise).  21 full-rate and 9 half-rate vector instructions per trip.
+template <bool FROM_PLANE>
+__device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, const TravConst &k, float gx, float gy,
+                                              float dx, float dy, float idx, float idy, int nx, int ny, int ix, int iy,
+                                              unsigned v, bool in_grid) {
     const int pitch2 = t.cell_pitch * 2;
     const char *qb = reinterpret_cast<const char *>(qr);
-    int jx = ix - nx, jy = iy - ny;                                       // shifted cell index
-    // other-axis origin in shifted coordinates, moved up by the band (one rounding each)
-    const float hx = bfi(nx, gx + t.band_p1, gx + t.band), hy = bfi(ny, gy + t.band_p1, gy + t.band);
-    // byte offset of shifted cell (0, 0) in this ray's plane q = 2 (dy < 0) + (dx < 0); true cell = shifted + n:
-    // q P + ny pitch2 + nx 2 = ny (pitch2 - 2 P) + nx (2 - P), and n K = n & -K for n in {0, -1}
-    const int P = t.quad_plane_bytes;
-    unsigned qoffp = ((unsigned)ny & (unsigned)(2 * P - pitch2)) + ((unsigned)nx & (unsigned)(P - 2));
-    asm("" : "+v"(qoffp));                                                // one value: keep it out of the loop's address math
+    // mirrored origin, the origin of the position estimate, the start cell (i~ = ~i on a mirrored axis) and the part of
+    // the table address that depends on the quadrant only
+    const float gmx = __uint_as_float(__float_as_uint(gx) ^ ((uint32_t)nx & 0x80000000u));
+    const float gmy = __uint_as_float(__float_as_uint(gy) ^ ((uint32_t)ny & 0x80000000u));
+    const float hx = gmx + k.band_mh, hy = gmy + k.band_mh;
+    uint32_t Tx = (uint32_t)(ix ^ nx) + kCellMagicBits, Ty = (uint32_t)(iy ^ ny) + kCellMagicBits;
+    uint32_t qoff = (((uint32_t)nx & k.kx) + ((uint32_t)ny & k.ky)) + k.c00;
+    asm("" : "+v"(qoff));                                                 // one value: keep it out of the loop's address math
+    if (FROM_PLANE) {
+        v = 0;
+        if (in_grid) v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(Ty, pitch2, (Tx << 1) + qoff));
+    }
     const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     const float band2 = t.band2;
     float tt = 0.0f;
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
     // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
     for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) {
-        const int xe = add_sbyte<0>(v, jx);                               // boundaries that leave the rectangle
-        const int ye = add_sbyte<1>(v, jy);
-        const v2f te = (v2f{(float)xe, (float)ye} - v2f{gx, gy}) * v2f{idx, idy};    // packed: one subtract, one multiply
-        const float txe = te.x, tye = te.y;
-        // leaves through the x side iff txe < tye (ties: y).  The lane mask goes to an SGPR pair and every choice
-        // below is an e64 select on it; both candidate positions come from one packed multiply and one packed add
-        // (19 instructions per trip against 21 with a sign mask, min and four bit-field inserts)
+        const uint32_t xe = Tx + (v & 255u), ye = Ty + (v >> 8);         // boundaries that leave the rectangle, as float bits
+        const float ax = (__uint_as_float(xe) - kCellMagic) - gmx, ay = (__uint_as_float(ye) - kCellMagic) - gmy;
+        const float txe = ax * fabsf(idx), tye = ay * fabsf(idy);
+        // leaves through the x side iff txe < tye (ties: y)
         const unsigned long long xm = cmp_lt_f32(txe, tye);
         tt = select_mask(xm, txe, tye);
-        const v2f zz = v2f{dx, dy} * tt + v2f{hx, hy};
-        const float z = select_mask(xm, zz.y, zz.x);
-        int on = floor_to_int(z);                                         // shifted cell on the other axis
-        if (cmp_lt_f32_s(__builtin_amdgcn_fractf(z), band2)) {            // within `band` of a boundary: exact count
-            const int mx = (int)select_mask_u(xm, 0xffffffffu, 0u);
-            const int na = bfi(mx, ny, nx);                               // true cell = shifted cell + na
-            on = exact_other_cell(on + na, bfi(mx, jy, jx) + na, na + 1, bfi(mx, gy, gx), bfi(mx, idy, idx), tt, mx) - na;
+        const float zx = hx + tt * fabsf(dx), zy = hy + tt * fabsf(dy);
+        Tx = __float_as_uint(zx + kCellMagic);
+        Ty = __float_as_uint(zy + kCellMagic);
+        const float zo = select_mask(xm, zy, zx);                         // the other axis
+        if (cmp_lt_f32_s(__builtin_amdgcn_fractf(zo + 0.5f), band2)) {    // within `band` of a boundary: exact count
+            const uint32_t tie = select_mask_u(xm, 1u, 0u);
+            // the current cell on that axis = boundary - extent (the old Tx, Ty are not kept: no register copies per trip)
+            const uint32_t cur = select_mask_u(xm, ye, xe) - select_mask_u(xm, v >> 8, v & 255u);
+            const uint32_t nT = exact_other_cell_m(select_mask_u(xm, Ty, Tx), cur, select_mask(xm, gmy, gmx),
+                                                   select_mask(xm, fabsf(idy), fabsf(idx)), tt, tie);
+            Tx = select_mask_u(xm, Tx, nT);
+            Ty = select_mask_u(xm, nT, Ty);
         }
-        jx = (int)select_mask_u(xm, (uint32_t)xe, (uint32_t)on);
-        jy = (int)select_mask_u(xm, (uint32_t)on, (uint32_t)ye);
-        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(jy, pitch2, ((unsigned)jx << 1) + qoffp));
+        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(Ty, pitch2, (Tx << 1) + qoff));
     }
     if (!started) return 0.0f;
+    // The one place where the mirrored frame is not bit-identical: a zero boundary time.  The spec's fl(b - g) is +0 and
+    // its product with 1/d < 0 is -0.0, which the range then carries; here it is +0.  A ray that stops at time 0 never
+    // left its origin; it crossed x at all only if it started on the far face of its column, and when it crossed both
+    // axes (a corner) the spec stepped y first - so its last crossing was the x one iff it left the start column.
+    if (tt == 0.0f) tt = __uint_as_float((uint32_t)(Tx != (uint32_t)(ix ^ nx) + kCellMagicBits ? nx : ny) & 0x80000000u);
     // stopped at a wall within range: the range; beyond 15 m, at the ring (entry 0x0100) or never stopped: no return
-    return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * t.res);
+    return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * k.res);
 }
 
 // One ray of the per-ray kernel (variant 6): direction made safe, start entry read from its quadrant plane.
@@ -1096,13 +1162,8 @@ __device__ __forceinline__ float cast_ray_rects(const uint16_t *qr, const RcTrac
     const int nx = sign_mask(dx), ny = sign_mask(dy);
     float idx, idy;
     ray_reciprocals(dx, dy, idx, idy);
-    unsigned v = 0;
-    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h) {
-        const int pitch2 = t.cell_pitch * 2, P = t.quad_plane_bytes;
-        const unsigned q = ((unsigned)ny & (unsigned)(2 * P)) + ((unsigned)nx & (unsigned)P);
-        v = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const char *>(qr) + (size_t)iy * pitch2 + ix * 2 + q);
-    }
-    return ray_traverse(qr, t, gx, gy, dx, dy, idx, idy, nx, ny, ix, iy, v);
+    const bool in_grid = (unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h;
+    return ray_traverse<true>(qr, t, trav_const(t), gx, gy, dx, dy, idx, idy, nx, ny, ix, iy, 0u, in_grid);
 }
 
 template <int A, int VARIANT>
@@ -1208,6 +1269,10 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     const char *first_line = nullptr;
     if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
         first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * RC_FIRST_BIAS;
+    // wave-uniform operands of the trip, in vector registers
+    const TravConst kc = trav_const(t);
+    const TravConst k = {pin_vgpr(kc.band_mh), pin_vgpr(kc.res), pin_vgpr(kc.kx), pin_vgpr(kc.ky), pin_vgpr(kc.c00)};
+    const int ixv = pin_vgpr(ix), iyv = pin_vgpr(iy);
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
     const unsigned bstep = 512u * (unsigned)split;
     unsigned obyte = lane * 4u + 256u * part;                            // ... and of its range in the car's output row
@@ -1216,13 +1281,11 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // round starts by waiting for its start entry.  Two register sets take turns (the loop body holds two rounds), so
     // nothing is copied between them.
     struct Ray { float dx, dy, idx, idy; int nx, ny; unsigned v; };
-    // (dx, dy) = (ct cb - st sb, ct sb + st cb): two packed products and ONE packed add that negates only its low
-    // lane's second operand (the compiler emits two packed adds for the scalar form); one rounding per operator
+    // (dx, dy) = (ct cb - st sb, ct sb + st cb), one rounding per operator: four products, a subtract and an add - plain
+    // full-rate instructions (the packed forms issue at half rate and need their operands swizzled into pairs)
     auto prepare = [&](float2 b, Ray &r) {
-        const v2f pa = v2f{b.x, b.y} * ct, pb = v2f{b.y, b.x} * st;
-        v2f d;
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,0]" : "=v"(d) : "v"(pa), "v"(pb));
-        r.dx = d.x; r.dy = d.y;
+        r.dx = ct * b.x - st * b.y;
+        r.dy = ct * b.y + st * b.x;
         ray_reciprocals(r.dx, r.dy, r.idx, r.idy);
         r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
         r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
@@ -1239,7 +1302,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
             boff += bstep;
             if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
         }
-        float rng = ray_traverse(t.quad_rect, t, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ix, iy, cur.v);
+        float rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll
