@@ -816,8 +816,10 @@ __device__ __forceinline__ int byte_xor(unsigned word, int m) {              // 
 // and only exactly zero or >= 1e-32 in practice, so that path runs when a beam is exactly axis-parallel.
 // 6 + 4 instructions instead of 2 x 11 for the division expansion.
 __device__ __forceinline__ void ray_reciprocals(float dx, float dy, float &idx, float &idy) {
-    // callers pass components already forced into [-2, 2], so only the lower bound needs a test
-    if (fabsf(dx) >= 0x1p-100f && fabsf(dy) >= 0x1p-100f) {
+    // callers pass components already forced into [-2, 2], so only the lower bound needs a test - and one test of the
+    // product serves both: |dx dy| >= 2^-99 with both factors <= 2 puts each at 2^-100 or more (a product below the
+    // bound merely takes the slower path, which is correct for every input)
+    if (fabsf(dx * dy) >= 0x1p-99f) {
         const float rx = __builtin_amdgcn_rcpf(dx), ry = __builtin_amdgcn_rcpf(dy);
         idx = __builtin_fmaf(__builtin_fmaf(-dx, rx, 1.0f), rx, rx);
         idy = __builtin_fmaf(__builtin_fmaf(-dy, ry, 1.0f), ry, ry);
@@ -878,6 +880,15 @@ __device__ __forceinline__ unsigned long long cmp_ne_u32(uint32_t a, uint32_t b)
 __device__ __forceinline__ float select_mask(unsigned long long m, float a, float b) {  // m ? a : b
     float r;
     asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+template <int BYTE>
+__device__ __forceinline__ uint32_t add_ubyte(unsigned word, uint32_t a) {   // a + (uint8)(word >> 8 BYTE), one instruction
+    uint32_t r;
+    if (BYTE == 0)
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(word), "v"(a));
+    else
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(word), "v"(a));
     return r;
 }
 template <int BYTE>
@@ -1112,39 +1123,51 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
         v = 0;
         if (in_grid) v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(Ty, pitch2, (Tx << 1) + qoff));
     }
-    const bool started = (v & 255u) != 0;                                 // false: the sensor sits in a stop cell
     const float band2 = t.band2;
     float tt = 0.0f;
-    // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
-    // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
-    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) {
-        const uint32_t xe = Tx + (v & 255u), ye = Ty + (v >> 8);         // boundaries that leave the rectangle, as float bits
+    auto trip = [&]() {
+        const uint32_t xe = add_ubyte<0>(v, Tx), ye = add_ubyte<1>(v, Ty);  // boundaries that leave the rectangle, as float bits
         const float ax = (__uint_as_float(xe) - kCellMagic) - gmx, ay = (__uint_as_float(ye) - kCellMagic) - gmy;
         const float txe = ax * fabsf(idx), tye = ay * fabsf(idy);
         // leaves through the x side iff txe < tye (ties: y)
         const unsigned long long xm = cmp_lt_f32(txe, tye);
         tt = select_mask(xm, txe, tye);
-        const float zx = hx + tt * fabsf(dx), zy = hy + tt * fabsf(dy);
+        // (an estimate, not a spec value - the exact path below covers its error: a fused multiply-add is welcome)
+        const float zx = __builtin_fmaf(tt, fabsf(dx), hx), zy = __builtin_fmaf(tt, fabsf(dy), hy);
         Tx = __float_as_uint(zx + kCellMagic);
         Ty = __float_as_uint(zy + kCellMagic);
         const float zo = select_mask(xm, zy, zx);                         // the other axis
         if (cmp_lt_f32_s(__builtin_amdgcn_fractf(zo + 0.5f), band2)) {    // within `band` of a boundary: exact count
             const uint32_t tie = select_mask_u(xm, 1u, 0u);
             // the current cell on that axis = boundary - extent (the old Tx, Ty are not kept: no register copies per trip)
-            const uint32_t cur = select_mask_u(xm, ye, xe) - select_mask_u(xm, v >> 8, v & 255u);
+            // (the entry through an opaque copy: shared with the loop condition, `v & 255` would stay a separate
+            // instruction in every trip instead of folding into the compare's byte select)
+            unsigned vv = v;
+            asm("" : "+v"(vv));
+            const uint32_t cur = select_mask_u(xm, ye, xe) - select_mask_u(xm, vv >> 8, vv & 255u);
             const uint32_t nT = exact_other_cell_m(select_mask_u(xm, Ty, Tx), cur, select_mask(xm, gmy, gmx),
                                                    select_mask(xm, fabsf(idy), fabsf(idx)), tt, tie);
             Tx = select_mask_u(xm, Tx, nT);
             Ty = select_mask_u(xm, nT, Ty);
         }
         v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(Ty, pitch2, (Tx << 1) + qoff));
-    }
-    if (!started) return 0.0f;
+    };
+    // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
+    // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
+    if ((v & 255u) == 0) return 0.0f;                                     // the sensor sits in a stop cell
+    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) trip();
     // The one place where the mirrored frame is not bit-identical: a zero boundary time.  The spec's fl(b - g) is +0 and
     // its product with 1/d < 0 is -0.0, which the range then carries; here it is +0.  A ray that stops at time 0 never
     // left its origin; it crossed x at all only if it started on the far face of its column, and when it crossed both
     // axes (a corner) the spec stepped y first - so its last crossing was the x one iff it left the start column.
-    if (tt == 0.0f) tt = __uint_as_float((uint32_t)(Tx != (uint32_t)(ix ^ nx) + kCellMagicBits ? nx : ny) & 0x80000000u);
+    // (a wave-uniform branch that is almost never taken: one compare per round; the start cell is recomputed inside it
+    // rather than kept in a register across the loop)
+    if (__builtin_amdgcn_ballot_w64(tt == 0.0f) != 0) {
+        int mx = nx;
+        asm volatile("" : "+v"(mx));
+        const uint32_t sgn = (uint32_t)(Tx != (uint32_t)(ix ^ mx) + kCellMagicBits ? mx : ny) & 0x80000000u;
+        tt = __uint_as_float(__float_as_uint(tt) | (tt == 0.0f ? sgn : 0u));
+    }
     // stopped at a wall within range: the range; beyond 15 m, at the ring (entry 0x0100) or never stopped: no return
     return select_mask(cmp_nlt_f32_s(tt, t.tmax) | cmp_ne_u32(v, 0u), RCS_MAX_RANGE, tt * k.res);
 }
@@ -1240,7 +1263,7 @@ constexpr unsigned kCarLdsBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS pe
 
 template <int A>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
-                                         const unsigned lane, char *lds_row) {
+                                         const unsigned lane, const uint32_t lds_row) {
     const RcTrackDev &t = p.trk;
     // the wave's first beam pair does not depend on the car: requested before the car's state, so the two round trips
     // overlap (a wave's start-up - state, start cell, first-trip line - is serial latency that nothing else hides)
@@ -1274,8 +1297,14 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     const TravConst k = {pin_vgpr(kc.band_mh), pin_vgpr(kc.res), pin_vgpr(kc.kx), pin_vgpr(kc.ky), pin_vgpr(kc.c00)};
     const int ixv = pin_vgpr(ix), iyv = pin_vgpr(iy);
     constexpr int kRounds = (RC_N_BEAMS + 63) / 64;
-    const unsigned bstep = 512u * (unsigned)split;
-    unsigned obyte = lane * 4u + 256u * part;                            // ... and of its range in the car's output row
+    // (per-round steps live in vector registers: a full-rate add that reads a scalar register issues at half rate)
+    const unsigned bstep = pin_vgpr(512u * (unsigned)split), ostep = pin_vgpr(256u * (unsigned)split);
+    // LDS address of this lane's slot in the wave's staged output row (lds_row = LDS address of the row: the kernel's
+    // dynamic LDS is its only LDS object and starts at 0, checked by rck_set_lds_limits) and the row's end
+    typedef __attribute__((address_space(3))) float *lds_f32_ptr;
+    typedef const __attribute__((address_space(3))) v4u *lds_v4u_ptr;
+    uint32_t oslot = lds_row + lane * 4u + 256u * part;
+    const uint32_t oend = lds_row + 4u * RC_N_BEAMS;
     // Software pipeline over the rounds: while round r is traversed, round r + 1's direction, reciprocals, sign masks
     // and first-trip entry are already computed / in flight (and round r + 2's beam pair is being fetched), so no
     // round starts by waiting for its start entry.  Two register sets take turns (the loop body holds two rounds), so
@@ -1292,7 +1321,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     };
     // one round: prepare `nxt` for round + split, traverse `cur`, store.  false: this lane has no beam in the round
     auto stage = [&](int round, const Ray &cur, Ray &nxt) -> bool {
-        if (obyte >= 4u * RC_N_BEAMS) return false;                       // last round: 56 of 64 lanes
+        if (oslot >= oend) return false;                                  // last round: 56 of 64 lanes
         // `cur` was requested a whole round ago and has arrived: say so BEFORE the next round's loads go out, or the
         // compiler, unable to count the conditional loads in flight, waits for all of them at the first use of cur.v
         // (vmcnt(0), other counters untouched)
@@ -1316,8 +1345,8 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         }
         if (p.lidar_transform == 1) rng = rng / RCS_MAX_RANGE - 0.5f;                 // dreamer/tools.py:274
         else if (p.lidar_transform == 2) rng = rng * (1.0f / RCS_MAX_RANGE);          // single_agent.py:92-99
-        *reinterpret_cast<float *>(lds_row + obyte) = rng;               // staged: see the flush below
-        obyte += 256u * (unsigned)split;
+        *(lds_f32_ptr)(uintptr_t)oslot = rng;                             // staged: see the flush below
+        oslot += ostep;
         return true;
     };
     Ray ra, rb;
@@ -1346,7 +1375,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         for (int k = 0; k < (RC_N_BEAMS / 4 + 63) / 64; ++k) {
             const unsigned o = (lane + 64u * (unsigned)k) * 16u;
             if (o < 4u * RC_N_BEAMS) {
-                const v4u val = *reinterpret_cast<const v4u *>(lds_row + o);
+                const v4u val = *(lds_v4u_ptr)(uintptr_t)(lds_row + o);
                 __builtin_nontemporal_store(val, reinterpret_cast<v4u *>(out_bytes + o));    // streamed: leaves the tables in L2 (1 % faster)
                 if (out16 != nullptr) {
                     typedef unsigned v2u __attribute__((ext_vector_type(2)));
@@ -1358,7 +1387,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         }
     } else {
         for (unsigned o = lane * 4u + 256u * part; o < 4u * RC_N_BEAMS; o += 256u * (unsigned)split) {
-            const float v = *reinterpret_cast<const float *>(lds_row + o);
+            const float v = *(lds_f32_ptr)(uintptr_t)(lds_row + o);
             *reinterpret_cast<float *>(out_bytes + o) = v;
             if (out16 != nullptr) *reinterpret_cast<uint16_t *>(out16 + (o >> 1)) = (uint16_t)quantise_pair(v, v, q_off, q_scale);
         }
@@ -1371,7 +1400,9 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     // (2 per wave + 6 %, 8 per wave + 20 %) - the hardware dispatcher balances 65 536 short waves better than any
     // static share, and a finished wave's flush is not waited for by anybody.
     extern __shared__ uint32_t lds_words[];                              // 17 x 64 floats per wave of the workgroup
-    char *lds_row = reinterpret_cast<char *>(lds_words) + (threadIdx.x >> 6) * (kCarLdsBytes);
+    // LDS address of this wave's row
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_words;
+    const uint32_t lds_row = __builtin_amdgcn_readfirstlane(lds_base + (threadIdx.x >> 6) * kCarLdsBytes);
     const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
     const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
@@ -1808,11 +1839,16 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<4, 6>))
     SET(rc_patch_kernel)
 #undef SET
-    // rc_patch_kernel addresses its dynamic LDS from LDS address 0: true only while it has no static LDS
+    // rc_patch_kernel and rc_raycast_car_kernel address their dynamic LDS from LDS address 0: true only while they have
+    // no static LDS
     hipFuncAttributes fa;
-    e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(rc_patch_kernel));
-    if (e != hipSuccess) return e;
-    if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
+    for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_raycast_car_kernel<1>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<2>), reinterpret_cast<const void *>(rc_raycast_car_kernel<3>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<4>)}) {
+        e = hipFuncGetAttributes(&fa, k);
+        if (e != hipSuccess) return e;
+        if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
+    }
     return hipSuccess;
 }
 
