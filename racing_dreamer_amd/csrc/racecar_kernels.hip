@@ -1089,19 +1089,21 @@ __device__ __forceinline__ uint32_t exact_other_cell_m(uint32_t est_T, uint32_t 
     return b0T - 1u + c0 + c1;
 }
 
-// New cell after an exit: z = (g~ + band - 0.5) + tt |d| on BOTH axes, T = bits(z + 1.5 * 2^23), i.e. the cell is
-// rne(z) = floor(position + band) - except at an exact tie, which the band test below catches.  On the exit axis the
-// position is the boundary xe itself up to the rounding of g~ + fl(fl(xe - g~) |1/d|) |d| (six roundings on values
-// <= M = the largest coordinate on the grid: 3.6e-7 M cells), so floor(xe + band +- 3.6e-7 M) = xe: no select between
-// "the boundary" and "floor of the position" is needed.  On the other axis floor(position + band) is trusted unless
-// fract(z + 0.5) < 2 band, i.e. unless the position lies within `band` of a cell boundary; then the spec's own
-// comparisons decide (exact_other_cell_m).  How wide the band must be: the spec crosses boundary b iff
-// fl(fl(b - g) * fl(1/d)) < tt, which differs from the real-number test "b before the position at time tt" by at
-// most 3 roundings = 1.8e-7 M cells, z carries 3 roundings of its own, another 1.8e-7 M, and the sum z + 0.5 of the
-// test one more (0.6e-7 M): a position is in doubt only if z + 0.5 lands in [k, k + band + 4.2e-7 M) for an integer k.
-// band = M * 2^-21 = 4.8e-7 M covers both requirements (band > 3.6e-7 M, 2 band > band + 4.2e-7 M): 2.6e-4 cell on
-// austria (548 cells wide), 1e-3 on a 2048-cell map.  tools/band_validation.sh: the parity tests fail for bands
-// <= M 2^-26 and pass from M 2^-24 on.
+// New cell after an exit: z = fma(tt, |d|, fl(g~ + band - 0.5)) on BOTH axes, T = bits(z + 1.5 * 2^23), i.e. the cell
+// is rne(z) = floor(position + band) - except at an exact tie, which the band test below catches.  With u = 2^-24 and
+// M = the largest coordinate on the grid (cells):
+// * exit axis: the position is the boundary xe itself, and z - (xe + band - 0.5) is at most
+//   (xe - g~)(e0 + e1 + e2) + (g~ + band - 0.5) e4 + z e3 with |e| <= u - the subtraction, the reciprocal, the product,
+//   the rounded origin and the FMA: 5 u M = 3.0e-7 M cells.  band > 5 u M makes floor(xe + band +- 5 u M) = xe, so no
+//   select between "the boundary" and "floor of the position" is needed.
+// * other axis: floor(position + band) is trusted unless fract(z + 0.5) < 2 band, i.e. unless the position lies within
+//   `band` of a cell boundary; then the spec's own comparisons decide (exact_other_cell_m).  The spec crosses boundary b
+//   iff fl(fl(b - g) * fl(1/d)) < tt, which differs from the real-number test "b before the position at time tt" by at
+//   most 3 u M; z carries 2 u M of its own (origin, FMA) and the sum z + 0.5 of the test 1 u M: a position is in doubt
+//   only if z + 0.5 lands in [k, k + band + 6 u M) for an integer k, so 2 band >= band + 6 u M is needed.
+// band = (M + 2) 2^-21 = 8 u M covers both (8 > 5, 8 > 6): 2.6e-4 cell on austria (548 cells wide), 1e-3 on a 2048-cell
+// map.  tools/band_validation.sh (profiles/r02_d_band_validation.txt): the parity tests fail for bands <= M 2^-24 - the
+// exit axis then lands in the wrong cell and rays run off - and pass from M 2^-22 on.
 // The traversal proper: from start cell (ix, iy) with start entry v (FROM_PLANE: read from the ray's plane instead, 0
 // when !in_grid), direction (dx, dy) (finite, never -0.0), its reciprocals and sign masks nx, ny (-1 for a negative
 // component, 0 otherwise).  21 full-rate and 9 half-rate vector instructions per trip.
