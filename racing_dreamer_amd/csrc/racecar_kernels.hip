@@ -1042,17 +1042,17 @@ __global__ __launch_bounds__(256) void rc_build_quad_kernel(RcTrackDev t, const 
 
 // The start cell's entry for a ray of direction (dx, dy): quadrant from the signs, slope bin from the float bits of
 // |dy| * |1/dx| (relative error 1.2e-7 against the bin edges the builder widened by 1e-6; 1/0 is stood in for by
-// 3e38, which lands in the steepest bin like every slope above 2^4).  first_line points RC_FIRST_BIAS entries
-// before the cell's line, or is null when the sensor is off the grid (entry 0: the ray reads 0).
-__device__ __forceinline__ unsigned first_trip_entry(const char *first_line, float dy, float idx, int nx, int ny) {
-    if (first_line == nullptr) return 0u;
+// 3e38, which lands in the steepest bin like every slope above 2^4).  lds_line = LDS address RC_FIRST_BIAS entries
+// before the wave's copy of the cell's line (all zeros when the sensor is off the grid: the ray reads 0).
+__device__ __forceinline__ unsigned first_trip_entry(uint32_t lds_line, float dy, float idx, int nx, int ny) {
     float slope;
     asm("v_mul_f32_e64 %0, |%1|, |%2|" : "=v"(slope) : "v"(dy), "v"(idx));
     const unsigned bin = med3_u32(__float_as_uint(slope) >> RC_FIRST_SHIFT, RC_FIRST_BIAS, RC_FIRST_BIAS + RC_FIRST_BINS - 1);
     unsigned off, addr;
     asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(off) : "v"(ny), "v"(4u * RC_FIRST_BINS), "v"((unsigned)nx & (2u * RC_FIRST_BINS)));
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(addr) : "v"(bin), "v"(off));
-    return *reinterpret_cast<const uint16_t *>(first_line + addr);
+    typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
+    return *(lds_u16_ptr)(uintptr_t)(lds_line + addr);
 }
 
 // ---- The traversal (variants 6 and 7), in the mirrored frame with cell indices as float bits (see above) ----------
@@ -1261,7 +1261,8 @@ __device__ __forceinline__ uint32_t quantise_pair(float a, float b, float off, f
     return (__float_as_uint(ta) & 0xffffu) | (__float_as_uint(tb) << 16);
 }
 
-constexpr unsigned kCarLdsBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges
+constexpr unsigned kCarRowBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges ...
+constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... and the start cell's line of the first-trip table
 
 template <int A>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
@@ -1289,11 +1290,20 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     const float gx = (lx - t.org_x) * t.inv_res;
     const float gy = (ly - t.org_y) * t.inv_res;
     float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
-    // the start cell and its 128-byte line of the first-trip table: the same for all 1080 rays
+    // The start cell and its 256-byte line of the first-trip table: the same for all 1080 rays, so the wave copies it
+    // into its LDS ONCE (one dword per lane; zeros when the sensor is off the grid: every ray then reads 0) and each
+    // round's 64 entries come from there.  As a global load per round it was 17 vector-memory instructions per car,
+    // each of them 16 quad requests to the L1 (which counts requests, not bytes: 84 M per launch kept it 77 % busy).
     const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
-    const char *first_line = nullptr;
-    if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
-        first_line = reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES) - 2 * RC_FIRST_BIAS;
+    const uint32_t lds_first = lds_row + kCarRowBytes;
+    {
+        uint32_t w = 0;
+        if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
+            w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES))[lane];
+        typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+        *(lds_u32_ptr)(uintptr_t)(lds_first + 4u * lane) = w;
+    }
+    const uint32_t first_line = lds_first - 2u * RC_FIRST_BIAS;          // (the slope bins are biased: first_trip_entry)
     // wave-uniform operands of the trip, in vector registers
     const TravConst kc = trav_const(t);
     const TravConst k = {pin_vgpr(kc.band_mh), pin_vgpr(kc.res), pin_vgpr(kc.kx), pin_vgpr(kc.ky), pin_vgpr(kc.c00)};
