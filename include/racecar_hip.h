@@ -262,6 +262,13 @@ enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, R
        RC_DBG_COUNT = 5 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
 
+/* In-kernel time stamps of the default scan (analysis only, like the knobs above): when `stamps` is non-NULL the next
+ * scans run an instrumented build of the one-wave-per-car kernel (1 car per env only) whose first `n_waves` waves write
+ * RC_STAMP_SLOTS uint64 each to the DEVICE buffer `stamps` - shader-clock values (s_memtime) at fixed points of the wave's
+ * life plus two counters; slot meanings: tools/scan_stamps.py.  NULL switches back to the production kernel. */
+#define RC_STAMP_SLOTS 32
+int rc_debug_scan_stamps(rc_env *env, uint64_t *stamps, int32_t n_waves);
+
 /* Host-only: the beam (cos, sin) and footprint tables the kernels use (float32 [1080][2], [34][2]). */
 void rc_spec_tables(float *beams_1080x2, float *footprint_34x2);
 

@@ -73,6 +73,7 @@ SYMBOLS = {
     "rc_reset_kernel_times": (C.c_int, [C.c_void_p]),
     "rc_set_raycast_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "rc_debug_set": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "rc_debug_scan_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
     "rc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

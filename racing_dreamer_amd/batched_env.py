@@ -304,6 +304,18 @@ class BatchedRaceEnv:
         tests/test_gpu_parity.py; the library itself reads nothing from the process environment."""
         L.check(self._lib.rc_debug_set(self._h, L.DEBUG_KNOBS[knob], int(value)))
 
+    def debug_scan_stamps(self, n_waves: int = 0) -> Optional[torch.Tensor]:
+        """In-kernel time stamps of the default scan (`rc_debug_scan_stamps`, analysis only; tools/scan_stamps.py): with
+        n_waves > 0 the following scans run the instrumented kernel and its first n_waves waves fill the returned
+        int64 [n_waves, 32] device tensor; n_waves = 0 switches back to the production kernel."""
+        if n_waves <= 0:
+            L.check(self._lib.rc_debug_scan_stamps(self._h, None, 0))
+            self._stamps = None
+            return None
+        self._stamps = torch.zeros((n_waves, 32), dtype=torch.int64, device=self.device)
+        L.check(self._lib.rc_debug_scan_stamps(self._h, self._stamps.data_ptr(), int(n_waves)))
+        return self._stamps
+
     def follow_the_gap(self, motor_straight: float = 0.6, motor_corner: float = 0.3) -> torch.Tensor:
         """Batched follow-the-gap agent (dreamer/dream.py:211-216 prefill): fills and returns `action_in`
         from the current LiDAR scans; pass None to step() to apply it."""

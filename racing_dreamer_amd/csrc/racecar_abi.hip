@@ -1103,6 +1103,14 @@ int rc_debug_set(rc_env *env, int32_t knob, int32_t value) {
     return RC_OK;
 }
 
+int rc_debug_scan_stamps(rc_env *env, uint64_t *stamps, int32_t n_waves) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (stamps != nullptr && n_waves <= 0) return fail(RC_ERR_INVALID, "n_waves must be positive");
+    env->launch.scan_stamps = reinterpret_cast<unsigned long long *>(stamps);
+    env->launch.scan_stamp_waves = stamps ? n_waves : 0;
+    return RC_OK;
+}
+
 int rc_set_raycast_variant(rc_env *env, int32_t variant) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (variant < 0 || variant > 7) return fail(RC_ERR_INVALID, "unknown raycast variant %d", variant);

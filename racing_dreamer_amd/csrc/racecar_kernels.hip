@@ -1110,7 +1110,7 @@ __device__ __forceinline__ uint32_t exact_other_cell_m(uint32_t est_T, uint32_t 
 template <bool FROM_PLANE>
 __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, const TravConst &k, float gx, float gy,
                                               float dx, float dy, float idx, float idy, int nx, int ny, int ix, int iy,
-                                              unsigned v, bool in_grid) {
+                                              unsigned v, bool in_grid, int *wave_trips = nullptr, int *wave_exact = nullptr) {
     const int pitch2 = t.cell_pitch * 2;
     const char *qb = reinterpret_cast<const char *>(qr);
     // mirrored origin, the origin of the position estimate, the start cell (i~ = ~i on a mirrored axis) and the part of
@@ -1128,6 +1128,7 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
     const float band2 = t.band2;
     float tt = 0.0f;
     auto trip = [&]() {
+        if (wave_trips) *wave_trips += 1;                                 // (instrumented build only: this LANE's trips)
         const uint32_t xe = add_ubyte<0>(v, Tx), ye = add_ubyte<1>(v, Ty);  // boundaries that leave the rectangle, as float bits
         const float ax = (__uint_as_float(xe) - kCellMagic) - gmx, ay = (__uint_as_float(ye) - kCellMagic) - gmy;
         const float txe = ax * fabsf(idx), tye = ay * fabsf(idy);
@@ -1140,6 +1141,7 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
         Ty = __float_as_uint(zy + kCellMagic);
         const float zo = select_mask(xm, zy, zx);                         // the other axis
         if (cmp_lt_f32_s(__builtin_amdgcn_fractf(zo + 0.5f), band2)) {    // within `band` of a boundary: exact count
+            if (wave_exact) *wave_exact += 1;
             const uint32_t tie = select_mask_u(xm, 1u, 0u);
             // the current cell on that axis = boundary - extent (the old Tx, Ty are not kept: no register copies per trip)
             // (the entry through an opaque copy: shared with the loop condition, `v & 255` would stay a separate
@@ -1264,10 +1266,37 @@ __device__ __forceinline__ uint32_t quantise_pair(float a, float b, float off, f
 constexpr unsigned kCarRowBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges ...
 constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... and the start cell's line of the first-trip table
 
-template <int A>
+// STAMPS: the instrumented build (rc_debug_scan_stamps): shader-clock values at fixed points of the wave's life and two
+// counters, RC_STAMP_SLOTS uint64 per wave - slot 0 entry, 1 car state arrived, 2 first-trip line staged and first round
+// prepared, 3 + i end of the wave's i-th round, 20 rounds done, 21 flush issued, 22 wave-level trips, 23 of which took
+// the exact path, 24 HW_ID, 25 / 26 trips per round (a nibble each).
+template <int A, bool STAMPS = false>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
-                                         const unsigned lane, const uint32_t lds_row) {
+                                         const unsigned lane, const uint32_t lds_row, unsigned long long *stamps = nullptr) {
     const RcTrackDev &t = p.trk;
+    auto stamp = [&](int slot) {
+        if (STAMPS && stamps != nullptr) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (lane == 0) stamps[slot] = now;
+        }
+    };
+    auto stamp_value = [&](int slot, unsigned long long value) {
+        if (STAMPS && stamps != nullptr && lane == 0) stamps[slot] = value;
+    };
+    int wave_trips = 0, wave_exact = 0, round_index = 0, trips_before = 0, total_trips = 0;
+    // phases of a round, summed over the wave's rounds in scalar registers (no stores in between): 27 wait for the
+    // previous round's loads, 28 prepare the next round, 29 traversal, 3 inter-car returns and transform, 4 LDS store,
+    // 30 round loop control
+    unsigned long long t_wait = 0, t_prep = 0, t_trav = 0, t_rest = 0, t_post = 0, t_store = 0, t_mark = 0;
+    auto phase = [&](unsigned long long &acc) {
+        if (STAMPS) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            acc += now - t_mark;
+            t_mark = now;
+        }
+    };
+    unsigned long long nib_lo = 0, nib_hi = 0;
+    stamp(0);
     // the wave's first beam pair does not depend on the car: requested before the car's state, so the two round trips
     // overlap (a wave's start-up - state, start cell, first-trip line - is serial latency that nothing else hides)
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
@@ -1285,6 +1314,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // component can be -0.0, which the spec would step as +.
     const bool legal = ((int)(fabsf(ct) <= 2.0f) & (int)(fabsf(st) <= 2.0f) & ((int)(fabsf(ct) >= 0.5f) | (int)(fabsf(st) >= 0.5f))) != 0;
     if (!legal) { ct = 1.0f; st = 0.0f; }
+    if (STAMPS) { asm volatile("" :: "v"(ct)); stamp(1); }
     const float lx = car_x + RCS_LIDAR_X * ct;
     const float ly = car_y + RCS_LIDAR_X * st;
     const float gx = (lx - t.org_x) * t.inv_res;
@@ -1334,16 +1364,23 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // one round: prepare `nxt` for round + split, traverse `cur`, store.  false: this lane has no beam in the round
     auto stage = [&](int round, const Ray &cur, Ray &nxt) -> bool {
         if (oslot >= oend) return false;                                  // last round: 56 of 64 lanes
+        phase(t_rest);
         // `cur` was requested a whole round ago and has arrived: say so BEFORE the next round's loads go out, or the
         // compiler, unable to count the conditional loads in flight, waits for all of them at the first use of cur.v
         // (vmcnt(0), other counters untouched)
         __builtin_amdgcn_s_waitcnt(0x0F70);
+        phase(t_wait);
         if (round + split < kRounds) {
             prepare(bm, nxt);                                             // (the padded beams of the last round included)
             boff += bstep;
             if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
         }
-        float rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true);
+        if (STAMPS) asm volatile("" :: "v"(nxt.idx), "v"(nxt.idy));
+        phase(t_prep);
+        float rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
+                                        STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr);
+        if (STAMPS) asm volatile("" :: "v"(rng));
+        phase(t_trav);
         if (A > 1) {
             const unsigned env = car / A;
 #pragma unroll
@@ -1357,12 +1394,29 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         }
         if (p.lidar_transform == 1) rng = rng / RCS_MAX_RANGE - 0.5f;                 // dreamer/tools.py:274
         else if (p.lidar_transform == 2) rng = rng * (1.0f / RCS_MAX_RANGE);          // single_agent.py:92-99
+        if (STAMPS) asm volatile("" :: "v"(rng));
+        phase(t_post);
         *(lds_f32_ptr)(uintptr_t)oslot = rng;                             // staged: see the flush below
         oslot += ostep;
+        phase(t_store);
+        if (STAMPS) {                                                     // + this round's trips, a nibble per round
+            phase(t_rest);                                                // (the counting below is not charged to any phase)
+            // wave-level trips of the round = the most any lane made (the counters are per lane)
+            int most = 0;
+            for (int n = 1; n <= 15; ++n) most = __builtin_amdgcn_ballot_w64(wave_trips - trips_before >= n) != 0 ? n : most;
+            total_trips += most;
+            const unsigned long long n = (unsigned long long)most;
+            if (round_index < 16) nib_lo |= n << (4 * round_index); else nib_hi |= n << (4 * (round_index - 16));
+            trips_before = wave_trips;
+            ++round_index;
+            // (read the clock AFTER the counting: the builtin alone may be scheduled ahead of it)
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_mark) : "s"(most), "s"(nib_lo), "s"(nib_hi));
+        }
         return true;
     };
     Ray ra, rb;
     prepare(bm, ra);
+    if (STAMPS) { asm volatile("" :: "v"(ra.v)); stamp(2); t_mark = __builtin_amdgcn_s_memtime(); }
     boff += bstep;
     if ((int)part + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
     for (int round = (int)part; round < kRounds; round += 2 * split) {
@@ -1374,6 +1428,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // stores share one in-order counter on gfx9, so the first table load of the NEXT round also waited for the
     // store's acknowledgement from L2 (the scan ran 11 % faster with the stores removed).  Staged in LDS (its own
     // counter), the 17 rows go out back to back at the end and nothing waits for them.
+    stamp(20);
     char *out_bytes = reinterpret_cast<char *>(out);
     // Optional second copy of the row as uint16 (rc_set_compact_slab: the half-size record of the multi-GPU gather):
     // q = rne((value + q_off) * q_scale), 0 .. 65535 over the row's value range - taken from the same LDS row, so it
@@ -1404,6 +1459,20 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
             if (out16 != nullptr) *reinterpret_cast<uint16_t *>(out16 + (o >> 1)) = (uint16_t)quantise_pair(v, v, q_off, q_scale);
         }
     }
+    if (STAMPS) {
+        stamp(21);
+        stamp_value(22, (unsigned long long)total_trips);
+        stamp_value(23, (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wave_exact != 0)));   // lanes that ever took it
+        stamp_value(27, t_wait);
+        stamp_value(28, t_prep);
+        stamp_value(29, t_trav);
+        stamp_value(30, t_rest);
+        stamp_value(3, t_post);
+        stamp_value(4, t_store);
+        stamp_value(25, nib_lo);
+        stamp_value(26, nib_hi);
+        stamp_value(24, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)));   // HW_ID
+    }
 }
 
 template <int A>
@@ -1420,6 +1489,18 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
     if (car >= (unsigned)p.n_cars) return;
     scan_car<A>(p, car, part, split, lane, lds_row);
+}
+
+// The instrumented build of the same kernel (rc_debug_scan_stamps; one car per env, analysis only).
+__global__ __launch_bounds__(256) void rc_raycast_car_stamps_kernel(RcParams p, int split, unsigned long long *stamps, int n_waves) {
+    extern __shared__ uint32_t lds_words[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_words;
+    const uint32_t lds_row = __builtin_amdgcn_readfirstlane(lds_base + (threadIdx.x >> 6) * kCarLdsBytes);
+    const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
+    if (car >= (unsigned)p.n_cars) return;
+    scan_car<1, true>(p, car, part, split, lane, lds_row, wave < (unsigned)n_waves ? stamps + (size_t)wave * RC_STAMP_SLOTS : nullptr);
 }
 
 // lidar_occupancy (H11, dreamer/wrappers.py:390-408): ego-aligned 64x64 patch of the drivable area,
@@ -1856,7 +1937,7 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     hipFuncAttributes fa;
     for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_raycast_car_kernel<1>),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<2>), reinterpret_cast<const void *>(rc_raycast_car_kernel<3>),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<4>)}) {
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<4>), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel)}) {
         e = hipFuncGetAttributes(&fa, k);
         if (e != hipSuccess) return e;
         if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
@@ -1889,7 +1970,10 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
     if (li.raycast_variant == 7) {
         const int threads = li.car_threads, per = threads / 64;                     // waves per workgroup
         const long long waves = (long long)p.n_cars * li.car_split;
-        DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
+        if (li.scan_stamps != nullptr && p.cars_per_env == 1)
+            launch(rc_raycast_car_stamps_kernel, dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split, li.scan_stamps, li.scan_stamp_waves);
+        else
+            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
     } else if (li.raycast_variant == 6) {
         DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 6>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
     } else if (li.raycast_variant == 5) {
