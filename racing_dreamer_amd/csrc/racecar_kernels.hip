@@ -1139,8 +1139,17 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
         const float zx = __builtin_fmaf(tt, fabsf(dx), hx), zy = __builtin_fmaf(tt, fabsf(dy), hy);
         Tx = __float_as_uint(zx + kCellMagic);
         Ty = __float_as_uint(zy + kCellMagic);
-        const float zo = select_mask(xm, zy, zx);                         // the other axis
+        // the new cell's entry is requested at once, from the estimate: the band test and its branch are then off the
+        // chain load -> trip -> load that a wave's time consists of (a lane in the band asks again below)
+        // (as inline assembly, with its own wait at the end of the trip: the compiler sinks a C++ load below the branch)
+        unsigned vnew;
+        asm volatile("global_load_ushort %0, %1, %2" : "=v"(vnew) : "v"(mad_u24(Ty, pitch2, (Tx << 1) + qoff)), "s"(qb));
+        float zxo = zx, zyo = zy;
+        asm volatile("" : "+v"(zxo), "+v"(zyo));                          // (keeps the band test's arithmetic behind the request)
+        const float zo = select_mask(xm, zyo, zxo);                       // the other axis
         if (cmp_lt_f32_s(__builtin_amdgcn_fractf(zo + 0.5f), band2)) {    // within `band` of a boundary: exact count
+            // (first let the request above land: its register must not be handed to anything else while it is under way)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(vnew));
             if (wave_exact) *wave_exact += 1;
             const uint32_t tie = select_mask_u(xm, 1u, 0u);
             // the current cell on that axis = boundary - extent (the old Tx, Ty are not kept: no register copies per trip)
@@ -1153,8 +1162,10 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
                                                    select_mask(xm, fabsf(idy), fabsf(idx)), tt, tie);
             Tx = select_mask_u(xm, Tx, nT);
             Ty = select_mask_u(xm, nT, Ty);
+            vnew = *reinterpret_cast<const uint16_t *>(qb + mad_u24(Ty, pitch2, (Tx << 1) + qoff));
         }
-        v = *reinterpret_cast<const uint16_t *>(qb + mad_u24(Ty, pitch2, (Tx << 1) + qoff));
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(vnew));
+        v = vnew;
     };
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
     // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
