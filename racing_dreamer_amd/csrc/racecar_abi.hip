@@ -741,7 +741,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     const size_t quad_plane_bytes = align_up((size_t)cell_pitch * h * 2, 64);
     // First-trip table of the one-wave-per-car scan (variant 7): RC_FIRST_PLANES rectangles per cell, one per
     // quadrant and bin of the ray's slope |dy / dx| - built on the device by rc_build_first_kernel right after the
-    // upload (racecar_kernels.hip has the description); 256 B per cell: austria 65 MB, gbr 253 MB - sized for the
+    // upload (racecar_kernels.hip has the description); 512 B per cell: austria 130 MB, gbr 506 MB - sized for the
     // 288 GB of HBM, not for the L2 (a car reads one line of it per step).
     const size_t first_bytes = align_up((size_t)cell_pitch * h * RC_FIRST_PLANES * 2, 64);
     const size_t prog_bytes = align_up((size_t)h * w * 4, 64);

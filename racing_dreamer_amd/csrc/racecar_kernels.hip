@@ -932,10 +932,10 @@ __device__ __forceinline__ float min_with(float a, float hi) {
 // (tools/ubench/valu_issue4.hip), and this kernel is bound by exactly that issue rate.
 // ---- First-trip table (RcTrackDev::first_rect) --------------------------------------------------------------
 // All 1080 rays of a car start in the same cell, so the FIRST rectangle of every ray can come from a much richer
-// table than the four quadrant planes without any cache cost: a car reads one 256-byte line per step.  Per cell
+// table than the four quadrant planes without any cache cost: a car reads one 512-byte line per step.  Per cell
 // the line holds RC_FIRST_PLANES = 4 quadrants x RC_FIRST_BINS entries, the bin being the ray's slope |dy / dx|
-// in four steps per octave over 2^-4 .. 2^4 (the outer bins open-ended): exactly what the scan gets from the float
-// bits of |dy| * |1 / dx| (exponent and two mantissa bits) in two instructions.  An entry is a rectangle anchored at the cell like the plane entries, but
+// in eight steps per octave over 2^-4 .. 2^4 (the outer bins open-ended): exactly what the scan gets from the float
+// bits of |dy| * |1 / dx| (exponent and three mantissa bits) in two instructions.  An entry is a rectangle anchored at the cell like the plane entries, but
 // it only has to be free INSIDE THE SECTOR that rays of its bin can touch (start point anywhere in the cell, slope
 // anywhere in the bin, both widened by a margin far above the traversal's rounding) - its far corners may lie
 // inside walls.  The exit arithmetic is unchanged: a ray of that bin visits only sector cells before it leaves
@@ -1331,18 +1331,20 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     const float gx = (lx - t.org_x) * t.inv_res;
     const float gy = (ly - t.org_y) * t.inv_res;
     float *out = p.out.lidar + (size_t)car * RC_N_BEAMS;
-    // The start cell and its 256-byte line of the first-trip table: the same for all 1080 rays, so the wave copies it
-    // into its LDS ONCE (one dword per lane; zeros when the sensor is off the grid: every ray then reads 0) and each
+    // The start cell and its 512-byte line of the first-trip table: the same for all 1080 rays, so the wave copies it
+    // into its LDS ONCE (eight bytes per lane; zeros when the sensor is off the grid: every ray then reads 0) and each
     // round's 64 entries come from there.  As a global load per round it was 17 vector-memory instructions per car,
     // each of them 16 quad requests to the L1 (which counts requests, not bytes: 84 M per launch kept it 77 % busy).
     const int ix = __builtin_amdgcn_readfirstlane((int)floorf(gx)), iy = __builtin_amdgcn_readfirstlane((int)floorf(gy));
     const uint32_t lds_first = lds_row + kCarRowBytes;
     {
-        uint32_t w = 0;
+        static_assert(2 * RC_FIRST_PLANES == 64 * 8, "one 8-byte piece of the line per lane");
+        typedef unsigned v2u_t __attribute__((ext_vector_type(2)));
+        v2u_t w = {0u, 0u};
         if ((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)
-            w = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES))[lane];
-        typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
-        *(lds_u32_ptr)(uintptr_t)(lds_first + 4u * lane) = w;
+            w = reinterpret_cast<const v2u_t *>(reinterpret_cast<const char *>(t.first_rect) + ((size_t)iy * t.cell_pitch + ix) * (2 * RC_FIRST_PLANES))[lane];
+        typedef __attribute__((address_space(3))) v2u_t *lds_v2u_ptr;
+        *(lds_v2u_ptr)(uintptr_t)(lds_first + 8u * lane) = w;
     }
     const uint32_t first_line = lds_first - 2u * RC_FIRST_BIAS;          // (the slope bins are biased: first_trip_entry)
     // wave-uniform operands of the trip, in vector registers
@@ -1882,8 +1884,8 @@ hipError_t rck_build_spawn_table(const RcTrackDev &t, float4 *spawn_dev, hipStre
 
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s) {
     RcFirstBin bins[RC_FIRST_BINS];
-    // bin b = the float bits of the slope >> RC_FIRST_SHIFT, less RC_FIRST_BIAS: exponent -4 + b / 4 and the top two
-    // mantissa bits b % 4, i.e. the slopes [2^e (1 + m / 4), 2^e (1 + (m + 1) / 4)) - four LINEAR steps per octave
+    // bin b = the float bits of the slope >> RC_FIRST_SHIFT, less RC_FIRST_BIAS: exponent -4 + b / 8 and the top three
+    // mantissa bits b % 8, i.e. the slopes [2^e (1 + m / 8), 2^e (1 + (m + 1) / 8)) - eight LINEAR steps per octave
     constexpr int kPerOctave = RC_FIRST_BINS / 8, kMantBits = 23 - RC_FIRST_SHIFT;
     static_assert((1 << kMantBits) == kPerOctave && RC_FIRST_BIAS == (123u << kMantBits), "bins = exponent and top mantissa bits over 2^-4 .. 2^4");
     auto edge = [](int b) { return std::exp2(-4.0 + (double)(b / kPerOctave)) * (1.0 + (double)(b % kPerOctave) / kPerOctave); };
