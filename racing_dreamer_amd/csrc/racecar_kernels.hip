@@ -20,6 +20,7 @@
 #include <hip/hip_ext.h>
 #include <math.h>
 #include <cstdlib>
+#include <type_traits>
 
 #include "racecar_device.h"
 #include "racecar_internal.h"
@@ -1107,10 +1108,12 @@ __device__ __forceinline__ uint32_t exact_other_cell_m(uint32_t est_T, uint32_t 
 // The traversal proper: from start cell (ix, iy) with start entry v (FROM_PLANE: read from the ray's plane instead, 0
 // when !in_grid), direction (dx, dy) (finite, never -0.0), its reciprocals and sign masks nx, ny (-1 for a negative
 // component, 0 otherwise).  21 full-rate and 9 half-rate vector instructions per trip.
-template <bool FROM_PLANE>
+struct NothingBetween { __device__ __forceinline__ void operator()() const {} };
+template <bool FROM_PLANE, class Between = NothingBetween>
 __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, const TravConst &k, float gx, float gy,
                                               float dx, float dy, float idx, float idy, int nx, int ny, int ix, int iy,
-                                              unsigned v, bool in_grid, int *wave_trips = nullptr, int *wave_exact = nullptr) {
+                                              unsigned v, bool in_grid, int *wave_trips = nullptr, int *wave_exact = nullptr,
+                                              Between between = Between()) {
     const int pitch2 = t.cell_pitch * 2;
     const char *qb = reinterpret_cast<const char *>(qr);
     // mirrored origin, the origin of the position estimate, the start cell (i~ = ~i on a mirrored axis) and the part of
@@ -1127,31 +1130,38 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
     }
     const float band2 = t.band2;
     float tt = 0.0f;
-    auto trip = [&]() {
+    // A trip in two halves: `trip_head` ends with the REQUEST for the new cell's entry, `trip_tail` has the band test, the
+    // exact path and the wait.  The entry is requested from the estimate as soon as the cell is known - the band test and
+    // its branch are then off the chain entry -> trip -> request that a wave's time consists of (a lane in the band asks
+    // again in the tail) - and as inline assembly with its own wait: the compiler sinks a C++ load below the branch.
+    uint32_t xe = 0, ye = 0, xflag = 0;                                   // xflag: 1 = left through the x side (per lane: a lane
+    float zo = 0.0f;                                                      // mask in a scalar pair cannot live across `between`)
+    unsigned vnew = 0;
+    auto trip_head = [&]() {
         if (wave_trips) *wave_trips += 1;                                 // (instrumented build only: this LANE's trips)
-        const uint32_t xe = add_ubyte<0>(v, Tx), ye = add_ubyte<1>(v, Ty);  // boundaries that leave the rectangle, as float bits
+        xe = add_ubyte<0>(v, Tx); ye = add_ubyte<1>(v, Ty);               // boundaries that leave the rectangle, as float bits
         const float ax = (__uint_as_float(xe) - kCellMagic) - gmx, ay = (__uint_as_float(ye) - kCellMagic) - gmy;
         const float txe = ax * fabsf(idx), tye = ay * fabsf(idy);
         // leaves through the x side iff txe < tye (ties: y)
         const unsigned long long xm = cmp_lt_f32(txe, tye);
         tt = select_mask(xm, txe, tye);
-        // (an estimate, not a spec value - the exact path below covers its error: a fused multiply-add is welcome)
+        // (an estimate, not a spec value - the exact path covers its error: a fused multiply-add is welcome)
         const float zx = __builtin_fmaf(tt, fabsf(dx), hx), zy = __builtin_fmaf(tt, fabsf(dy), hy);
         Tx = __float_as_uint(zx + kCellMagic);
         Ty = __float_as_uint(zy + kCellMagic);
-        // the new cell's entry is requested at once, from the estimate: the band test and its branch are then off the
-        // chain load -> trip -> load that a wave's time consists of (a lane in the band asks again below)
-        // (as inline assembly, with its own wait at the end of the trip: the compiler sinks a C++ load below the branch)
-        unsigned vnew;
         asm volatile("global_load_ushort %0, %1, %2" : "=v"(vnew) : "v"(mad_u24(Ty, pitch2, (Tx << 1) + qoff)), "s"(qb));
         float zxo = zx, zyo = zy;
         asm volatile("" : "+v"(zxo), "+v"(zyo));                          // (keeps the band test's arithmetic behind the request)
-        const float zo = select_mask(xm, zyo, zxo);                       // the other axis
+        zo = select_mask(xm, zyo, zxo);                                   // the other axis
+        xflag = select_mask_u(xm, 1u, 0u);
+    };
+    auto trip_tail = [&]() {
         if (cmp_lt_f32_s(__builtin_amdgcn_fractf(zo + 0.5f), band2)) {    // within `band` of a boundary: exact count
-            // (first let the request above land: its register must not be handed to anything else while it is under way)
+            // (first let the request land: its register must not be handed to anything else while it is under way)
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(vnew));
             if (wave_exact) *wave_exact += 1;
-            const uint32_t tie = select_mask_u(xm, 1u, 0u);
+            const unsigned long long xm = cmp_ne_u32(xflag, 0u);
+            const uint32_t tie = xflag;
             // the current cell on that axis = boundary - extent (the old Tx, Ty are not kept: no register copies per trip)
             // (the entry through an opaque copy: shared with the loop condition, `v & 255` would stay a separate
             // instruction in every trip instead of folding into the compare's byte select)
@@ -1167,10 +1177,22 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(vnew));
         v = vnew;
     };
+    if (!std::is_same<Between, NothingBetween>::value) {
+        // The first trip peeled: `between` - the caller's work that does not depend on this ray, in the per-car kernel
+        // the preparation of the NEXT round - runs for ALL lanes while the first request is under way.  Pays where a SIMD
+        // holds few waves (4 096 cars: 0.0257 -> 0.0235 ms); with 8 waves per SIMD the others fill that time anyway and
+        // the second copy of the trip only costs (65 536 cars: 0.186 -> 0.191 ms), so the launcher picks it by batch size.
+        const bool started = (v & 255u) != 0;                             // false: the sensor sits in a stop cell
+        if (started) trip_head();
+        between();
+        if (!started) return 0.0f;
+        trip_tail();
+    } else if ((v & 255u) == 0) {
+        return 0.0f;                                                      // the sensor sits in a stop cell
+    }
     // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
     // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
-    if ((v & 255u) == 0) return 0.0f;                                     // the sensor sits in a stop cell
-    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) trip();
+    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) { trip_head(); trip_tail(); }
     // The one place where the mirrored frame is not bit-identical: a zero boundary time.  The spec's fl(b - g) is +0 and
     // its product with 1/d < 0 is -0.0, which the range then carries; here it is +0.  A ray that stops at time 0 never
     // left its origin; it crossed x at all only if it started on the far face of its column, and when it crossed both
@@ -1281,7 +1303,9 @@ constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... an
 // counters, RC_STAMP_SLOTS uint64 per wave - slot 0 entry, 1 car state arrived, 2 first-trip line staged and first round
 // prepared, 3 + i end of the wave's i-th round, 20 rounds done, 21 flush issued, 22 wave-level trips, 23 of which took
 // the exact path, 24 HW_ID, 25 / 26 trips per round (a nibble each).
-template <int A, bool STAMPS = false>
+// OVERLAP: the next round is prepared under the first request of the current one (ray_traverse's `between`) instead of
+// ahead of the traversal.
+template <int A, bool STAMPS = false, bool OVERLAP = false>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
                                          const unsigned lane, const uint32_t lds_row, unsigned long long *stamps = nullptr) {
     const RcTrackDev &t = p.trk;
@@ -1383,15 +1407,25 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         // (vmcnt(0), other counters untouched)
         __builtin_amdgcn_s_waitcnt(0x0F70);
         phase(t_wait);
-        if (round + split < kRounds) {
-            prepare(bm, nxt);                                             // (the padded beams of the last round included)
-            boff += bstep;
-            if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
+        // the next round is prepared while the first request of this one is under way (ray_traverse calls it there)
+        auto prepare_next = [&]() {
+            if (round + split < kRounds) {
+                prepare(bm, nxt);                                         // (the padded beams of the last round included)
+                boff += bstep;
+                if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
+            }
+        };
+        float rng;
+        if (OVERLAP) {
+            rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
+                                      STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr, prepare_next);
+        } else {
+            prepare_next();
+            if (STAMPS) asm volatile("" :: "v"(nxt.idx), "v"(nxt.idy));
+            phase(t_prep);
+            rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
+                                      STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr);
         }
-        if (STAMPS) asm volatile("" :: "v"(nxt.idx), "v"(nxt.idy));
-        phase(t_prep);
-        float rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
-                                        STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr);
         if (STAMPS) asm volatile("" :: "v"(rng));
         phase(t_trav);
         if (A > 1) {
@@ -1488,7 +1522,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     }
 }
 
-template <int A>
+template <int A, bool OVERLAP>
 __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int split) {
     // One car (or 1 / split of one) per wave and nothing more: several cars in sequence per wave were measured slower
     // (2 per wave + 6 %, 8 per wave + 20 %) - the hardware dispatcher balances 65 536 short waves better than any
@@ -1501,7 +1535,7 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const unsigned lane = threadIdx.x & 63u;
     const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
     if (car >= (unsigned)p.n_cars) return;
-    scan_car<A>(p, car, part, split, lane, lds_row);
+    scan_car<A, false, OVERLAP>(p, car, part, split, lane, lds_row);
 }
 
 // The instrumented build of the same kernel (rc_debug_scan_stamps; one car per env, analysis only).
@@ -1948,9 +1982,11 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     // rc_patch_kernel and rc_raycast_car_kernel address their dynamic LDS from LDS address 0: true only while they have
     // no static LDS
     hipFuncAttributes fa;
-    for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_raycast_car_kernel<1>),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<2>), reinterpret_cast<const void *>(rc_raycast_car_kernel<3>),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<4>), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel)}) {
+    for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, false>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, false>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, true>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, true>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, true>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, true>)}) {
         e = hipFuncGetAttributes(&fa, k);
         if (e != hipSuccess) return e;
         if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
@@ -1983,10 +2019,13 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
     if (li.raycast_variant == 7) {
         const int threads = li.car_threads, per = threads / 64;                     // waves per workgroup
         const long long waves = (long long)p.n_cars * li.car_split;
-        if (li.scan_stamps != nullptr && p.cars_per_env == 1)
+        if (li.scan_stamps != nullptr && p.cars_per_env == 1) {
             launch(rc_raycast_car_stamps_kernel, dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split, li.scan_stamps, li.scan_stamp_waves);
-        else
-            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
+        } else if (li.car_split > 1) {    // small batch, few waves per SIMD: prepare the next round under the first request
+            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, true>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
+        } else {
+            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, false>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
+        }
     } else if (li.raycast_variant == 6) {
         DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 6>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
     } else if (li.raycast_variant == 5) {
