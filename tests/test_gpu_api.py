@@ -276,3 +276,37 @@ def test_handles_share_the_tables_of_one_track_and_lds_limit_only_grows():
     b.step_random(seed=2, step=0)
     small.close()
     b.close()
+
+
+def test_instrumented_scan_gives_the_same_ranges_and_sane_stamps():
+    """rc_debug_scan_stamps: the instrumented build of the one-wave-per-car scan (tools/scan_stamps.py) must produce the
+    very ranges of the production kernel, stamp a wave's life in increasing shader-clock order and count at least one
+    wave-level trip per round; switching it off restores the production kernel."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    n = 20000                                            # one wave per car (more than 48 waves per CU)
+    a = BatchedRaceEnv("columbia", n, 1, auto_reset=True)
+    b = BatchedRaceEnv("columbia", n, 1, auto_reset=True)
+    a.reset(mode="random", seed=3)
+    b.reset(mode="random", seed=3)
+    stamps = b.debug_scan_stamps(n)
+    for k in range(3):
+        va = a.step_random(seed=11, step=k)
+        vb = b.step_random(seed=11, step=k)
+    torch.cuda.synchronize()
+    assert torch.equal(va["lidar"], vb["lidar"])
+    s = stamps.cpu().numpy()
+    assert (s[:, 0] > 0).all()
+    order = s[:, [0, 1, 2, 20, 21]]
+    assert (np.diff(order, axis=1) > 0).all(), "entry < state < first round prepared < rounds done < flush"
+    assert (s[:, 22] >= 17).mean() > 0.99 and (s[:, 22] < 17 * 16).all(), "wave-level trips per car"
+    life = (s[:, 21] - s[:, 0]).astype(np.float64)
+    assert 5e3 < life.mean() < 5e5
+    b.debug_scan_stamps(0)
+    stamps.zero_()
+    vb = b.step_random(seed=11, step=3)
+    va = a.step_random(seed=11, step=3)
+    torch.cuda.synchronize()
+    assert torch.equal(va["lidar"], vb["lidar"]) and int(stamps.abs().sum()) == 0
+    a.close()
+    b.close()

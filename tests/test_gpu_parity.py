@@ -318,9 +318,9 @@ def test_wall_corners_on_a_2040_cell_wide_map():
 
 @pytest.mark.parametrize("track_name", ["austria", "treitlstrasse_v2"])
 def test_rays_on_the_slope_bin_edges_of_the_first_trip_table(track_name):
-    """The default scan picks each ray's first rectangle by the bin of its slope |dy / dx| (four bins per octave from
+    """The default scan picks each ray's first rectangle by the bin of its slope |dy / dx| (eight bins per octave from
     the float bits), and that rectangle is only certified for slopes inside the bin: 12 288 poses per track turned
-    so that one beam's slope sits on a bin edge (2^e (1 + m / 4), both axes, all quadrants) give or take a few ulps
+    so that one beam's slope sits on a bin edge (2^e (1 + m / 8), both axes, all quadrants) give or take a few ulps
     of the heading, from sensor positions all over the track."""
     import torch
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
@@ -333,7 +333,7 @@ def test_rays_on_the_slope_bin_edges_of_the_first_trip_table(track_name):
     ly = cl[:, 1] + rng.uniform(-0.4, 0.4, n)
     cb, sb = ro.beam_table()
     k = rng.integers(0, 1080, n)
-    edges = np.array([2.0 ** e * (1 + m / 4) for e in range(-5, 5) for m in range(4)])
+    edges = np.array([2.0 ** e * (1 + m / 8) for e in range(-5, 5) for m in range(8)])
     slope = rng.choice(edges, n)
     ang = np.arctan2(slope * rng.choice([-1.0, 1.0], n), rng.choice([-1.0, 1.0], n))       # world angle of the aimed beam
     th = ang - np.arctan2(sb[k].astype(np.float64), cb[k].astype(np.float64))
