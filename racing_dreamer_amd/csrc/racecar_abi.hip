@@ -276,6 +276,10 @@ void set_band(rc_env *env) {
     t.band = std::ldexp((float)(std::max(t.w, t.h) + 2), (l2 <= -10 && l2 >= -40) ? l2 : -21);
     t.band_mh = t.band - 0.5f;
     t.band2 = 2.0f * t.band;
+    // With the shipped band every trip provably moves its ray at least one cell along the exit axis (racecar_kernels.hip,
+    // ray_traverse), so the loop ends at the ring of stop cells; a narrower validation band voids that proof, and the
+    // scan then runs the build whose loop counts its trips.
+    env->launch.scan_guarded = (l2 <= -10 && l2 >= -40 && l2 != -21) ? 1 : 0;
 }
 
 // Point every output field at `arena` (layout of make_layout).  The action input buffer is NOT part of this: it

@@ -88,6 +88,7 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t ray_blocks, ray_threads;
     int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one wave per workgroup
     int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
+    int32_t scan_guarded;        // 1: the scan's trip loop carries its trip-count guard (set while the validation band is in force)
     int32_t patch_blocks, patch_threads;
     unsigned long long *scan_stamps;   // rc_debug_scan_stamps: device buffer of the instrumented scan, else null
     int32_t scan_stamp_waves;

@@ -1125,7 +1125,12 @@ __device__ __forceinline__ uint32_t exact_other_cell_m(uint32_t est_T, uint32_t 
 // when !in_grid), direction (dx, dy) (finite, never -0.0), its reciprocals and sign masks nx, ny (-1 for a negative
 // component, 0 otherwise).  21 full-rate and 9 half-rate vector instructions per trip.
 struct NothingBetween { __device__ __forceinline__ void operator()() const {} };
-template <bool FROM_PLANE, class Between = NothingBetween>
+// GUARD: the trip loop also counts its trips.  It does not need to: with the shipped band a trip puts the ray into the
+// cell behind the exit boundary (exactly, see above), at least one cell further along the exit axis, and never back on
+// the other one, so after at most w + h trips the ray stands in a stop cell - the grid is ringed by them.  The counter
+// (four scalar instructions per trip merged into the loop's lane mask: 2.2 % of the scan) is therefore compiled only
+// into the builds that run when that proof does not hold: the per-ray variant 6 and any run with a validation band.
+template <bool FROM_PLANE, class Between = NothingBetween, bool GUARD = true>
 __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, const TravConst &k, float gx, float gy,
                                               float dx, float dy, float idx, float idy, int nx, int ny, int ix, int iy,
                                               unsigned v, bool in_grid, int *wave_trips = nullptr, int *wave_exact = nullptr,
@@ -1206,9 +1211,12 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
     } else if ((v & 255u) == 0) {
         return 0.0f;                                                      // the sensor sits in a stop cell
     }
-    // every trip moves at least one cell towards the ray's quadrant and the grid is ringed by stop cells, so the
-    // loop ends within w + h trips; the counter only bounds a logic error (the ray then reads "no return")
-    for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) { trip_head(); trip_tail(); }
+    if (GUARD) {
+        // (the counter only bounds a logic error or a mis-set band: the ray then reads "no return")
+        for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) { trip_head(); trip_tail(); }
+    } else {
+        while ((v & 255u) != 0) { trip_head(); trip_tail(); }
+    }
     // The one place where the mirrored frame is not bit-identical: a zero boundary time.  The spec's fl(b - g) is +0 and
     // its product with 1/d < 0 is -0.0, which the range then carries; here it is +0.  A ray that stops at time 0 never
     // left its origin; it crossed x at all only if it started on the far face of its column, and when it crossed both
@@ -1321,7 +1329,7 @@ constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... an
 // the exact path, 24 HW_ID, 25 / 26 trips per round (a nibble each).
 // OVERLAP: the next round is prepared under the first request of the current one (ray_traverse's `between`) instead of
 // ahead of the traversal.
-template <int A, bool STAMPS = false, bool OVERLAP = false>
+template <int A, bool STAMPS = false, bool OVERLAP = false, bool GUARD = true>
 __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, const unsigned part, const int split,
                                          const unsigned lane, const uint32_t lds_row, unsigned long long *stamps = nullptr) {
     const RcTrackDev &t = p.trk;
@@ -1433,13 +1441,13 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         };
         float rng;
         if (OVERLAP) {
-            rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
+            rng = ray_traverse<false, decltype(prepare_next), GUARD>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
                                       STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr, prepare_next);
         } else {
             prepare_next();
             if (STAMPS) asm volatile("" :: "v"(nxt.idx), "v"(nxt.idy));
             phase(t_prep);
-            rng = ray_traverse<false>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
+            rng = ray_traverse<false, NothingBetween, GUARD>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
                                       STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr);
         }
         if (STAMPS) asm volatile("" :: "v"(rng));
@@ -1538,7 +1546,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     }
 }
 
-template <int A, bool OVERLAP>
+template <int A, bool OVERLAP, bool GUARD>
 __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int split) {
     // One car (or 1 / split of one) per wave and nothing more: several cars in sequence per wave were measured slower
     // (2 per wave + 6 %, 8 per wave + 20 %) - the hardware dispatcher balances 65 536 short waves better than any
@@ -1551,7 +1559,7 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const unsigned lane = threadIdx.x & 63u;
     const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
     if (car >= (unsigned)p.n_cars) return;
-    scan_car<A, false, OVERLAP>(p, car, part, split, lane, lds_row);
+    scan_car<A, false, OVERLAP, GUARD>(p, car, part, split, lane, lds_row);
 }
 
 // The instrumented build of the same kernel (rc_debug_scan_stamps; one car per env, analysis only).
@@ -1999,10 +2007,12 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     // no static LDS
     hipFuncAttributes fa;
     for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, false>),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, false>),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, true>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, true>),
-                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, true>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, true>)}) {
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, false, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, false, false>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, false, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, false, false>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, true, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, true, false>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, true, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, true, false>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<1, false, true>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, false, true>),
+                          reinterpret_cast<const void *>(rc_raycast_car_kernel<3, false, true>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, false, true>)}) {
         e = hipFuncGetAttributes(&fa, k);
         if (e != hipSuccess) return e;
         if (fa.sharedSizeBytes != 0) return hipErrorInvalidValue;
@@ -2037,10 +2047,12 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
         const long long waves = (long long)p.n_cars * li.car_split;
         if (li.scan_stamps != nullptr && p.cars_per_env == 1) {
             launch(rc_raycast_car_stamps_kernel, dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split, li.scan_stamps, li.scan_stamp_waves);
+        } else if (li.scan_guarded) {     // a validation band is in force: the build whose trip loop counts its trips
+            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, false, true>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
         } else if (li.car_split > 1) {    // small batch, few waves per SIMD: prepare the next round under the first request
-            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, true>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
+            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, true, false>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
         } else {
-            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, false>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
+            DISPATCH_A(p.cars_per_env, launch((rc_raycast_car_kernel<kA, false, false>), dim3((unsigned)((waves + per - 1) / per)), dim3(threads), (size_t)per * kCarLdsBytes, s, p, li.car_split));
         }
     } else if (li.raycast_variant == 6) {
         DISPATCH_A(p.cars_per_env, launch((rc_raycast_kernel<kA, 6>), dim3(li.ray_blocks), dim3(li.ray_threads), 0, s, p, total));
