@@ -9,7 +9,11 @@ from racing_dreamer_amd.track_assets import load_track
 from oracle import racecar_oracle as ro, c_oracle
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
-for name in ("austria", "columbia", "barcelona", "gbr", "treitlstrasse_v2"):
+names = ("austria", "columbia", "barcelona", "gbr", "treitlstrasse_v2")
+if len(sys.argv) > 2 and sys.argv[2] == "all":           # python tools/soak.py 1000 all: every compiled track
+    from racing_dreamer_amd.track_assets import available_tracks
+    names = tuple(available_tracks())
+for name in names:
     t = load_track(name)
     t0 = time.perf_counter()
     env = BatchedRaceEnv(t, 16384, 1, auto_reset=True)
