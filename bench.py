@@ -2,6 +2,7 @@
 """Benchmark of the hot path: env-steps/s of the batched racing env on N MI355X (one process per GPU).
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 8 --steps 200 --warmup 20          (starts its own 8 ranks, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
 
@@ -19,6 +20,9 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import signal
+import socket
+import subprocess
 import sys
 import time
 
@@ -55,23 +59,63 @@ def parse_args():
                     help="N>1: steps per all-gather (each collective carries that many per-step records: same bytes, "
                          "fewer launches; needs staging copies, so 1 - no copy, the collective reads the record in "
                          "place - is the default)")
-    ap.add_argument("--gather-via", default="torch", choices=["torch", "abi"],
-                    help="transport of the collective: torch.distributed (RCCL inside PyTorch) or the C-ABI's own "
-                         "rc_gather_trajectory (RCCL bound by libracecar_hip.so; unique id passed through torch.distributed)")
+    ap.add_argument("--gather-via", default="torch", choices=["torch", "abi", "p2p"],
+                    help="transport of the gather: torch.distributed (RCCL inside PyTorch), the C-ABI's own "
+                         "rc_gather_trajectory (RCCL bound by libracecar_hip.so; unique id passed through torch.distributed) "
+                         "or rc_gather_trajectory_p2p (direct peer copies over hipIpc handles, one copy stream per peer)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-gather-modes", action="store_true", help="N>1: skip the short legs that time the other gather modes")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for functional tests on one GPU)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="N>1 started without a launcher: seconds after which the ranks this process started are killed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ftg", dest="no_cpu_baseline_ftg", action="store_true", help="skip the follow-the-gap secondary figure")
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations of BASELINE.json")
     ap.add_argument("--cpu-envs", type=int, default=0, help="envs in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--numpy-envs", type=int, default=4096, help="batch of the vectorised-NumPy CPU leg (SURVEY.md 8d)")
+    ap.add_argument("--no-numpy-baseline", action="store_true", help="skip the vectorised-NumPy CPU leg (one step takes seconds)")
     ap.add_argument("--raycast-variant", type=int, default=None)
     ap.add_argument("--debug-knob", action="append", default=[], metavar="NAME=VALUE",
                     help="experiment knob passed to rc_debug_set (ray_threads, ray_split, ray_wg_per_cu, band_log2)")
     return ap.parse_args()
+
+
+def self_launch(n_ranks, timeout_s):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves - one child running
+    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` - BEFORE this process has touched the
+    GPU (nothing above imports torch), pass the ranks' output through (rank 0 prints the JSON line), and exit with the
+    child's code: non-zero if any rank failed, 124 if the ranks did not finish within `timeout_s` (the whole process
+    group this function started is then killed - by its id, nothing else).  Never re-executes a process that has
+    initialised the GPU."""
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and hipIpc* need on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        rc = child.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {n_ranks} ranks did not finish within {timeout_s:.0f} s - killing them", file=sys.stderr)
+        try:
+            os.killpg(child.pid, signal.SIGTERM)
+            child.wait(timeout=10)
+        except (ProcessLookupError, subprocess.TimeoutExpired):
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+        rc = 124
+    except KeyboardInterrupt:
+        os.killpg(child.pid, signal.SIGTERM)
+        rc = 130
+    sys.exit(rc)
 
 
 def cpu_baseline(track, cars, obs_type, repeat, n_envs):
@@ -81,40 +125,83 @@ def cpu_baseline(track, cars, obs_type, repeat, n_envs):
 
 
 class Gatherer:
-    """One gather mode of the N > 1 run: where the record lies, how it is sent, what it costs on the links."""
+    """One gather mode of the N > 1 run: where the record lies, how it is sent, what it costs on the links.
+
+    With one collective per step (`every == 1`) EVERY payload is read in place from a double-buffered source - the compact
+    slab pair for `full-u16` (`rotate_compact`), a pair of output arenas for `full` and `summary` (`rc_set_arena`) - so the
+    step that follows a collective writes the OTHER buffer and the collective never reads a record that is being
+    overwritten (the header of rc_gather_trajectory demands exactly that of its caller).  `every > 1` goes through
+    TrajectoryGather's staging copies."""
 
     def __init__(self, env, mode, every, via, dist_mod):
+        import torch
         from racing_dreamer_amd.distributed import TrajectoryGather, gather_link_model
         self.env, self.mode, self.via = env, mode, via
         self.world = dist_mod.get_world_size()
-        if mode == "full-u16" and getattr(env, "compact", None) is None:
-            env.enable_compact(buffers=2)
+        if mode == "full-u16":
+            if getattr(env, "compact", None) is None:
+                env.enable_compact(buffers=2)
+        elif getattr(env, "compact", None) is not None:
+            env.disable_compact()               # this leg's scan does not write the uint16 rows, its step does not copy the summary
+        self.in_place = every == 1 or via != "torch"
+        self.arenas, self._k = None, 0
+        if self.in_place and mode in ("full", "summary"):
+            second = torch.zeros(env.arena_nbytes + 64, dtype=torch.uint8, device=env.device)
+            pad = (-second.data_ptr()) % 64
+            self.arenas = [None, second[pad:pad + env.arena_nbytes]]       # None = the env's own arena
+            self._keep = second
         src = env.gather_source(mode)
         self.bytes = int(src.numel())
         self.model = gather_link_model(self.bytes, self.world)
-        self.in_place = every == 1 and mode == "full-u16"       # double-buffered source: no staging copy
         self.tg = None
         if via == "torch":
             self.tg = TrajectoryGather(src, every=every, stage=not self.in_place)
-        else:
-            import torch
-            self.dst = torch.empty(self.world * self.bytes, dtype=torch.uint8, device=env.device)
+        elif via == "abi":
+            self.dst = [torch.empty(self.world * self.bytes, dtype=torch.uint8, device=env.device) for _ in range(2)]
+        self.includes = {"full-u16": "scan writes fp32 + uint16 rows; 76 B/car summary copied behind it; collective of 2 236 B/car",
+                         "full": "collective of the fp32 record (4 396 B/car) read in place from alternating arenas",
+                         "summary": "collective of pose..time (76 B/car) read in place from alternating arenas"}[mode]
+
+    def _source(self):
+        env = self.env
+        if self.mode == "full-u16":
+            return env.compact
+        view = env._arena_view if self.arenas[self._k] is None else self.arenas[self._k]
+        if self.mode == "full":
+            return view[:env.slab.numel()]
+        off = env.summary_slab.data_ptr() - env._arena_view.data_ptr()
+        return view[off:off + env.summary_slab.numel()]
 
     def after_step(self):
         env = self.env
         if self.via == "abi":
-            env.gather_wait(host_sync=False)            # the previous collective wrote `dst`; order behind it
-            env.gather(self.mode, self.dst)
+            # the collective before last wrote dst[k]: order this one behind it, then send the record just produced
+            env.gather_wait(host_sync=False)
+            env.gather(self.mode, self.dst[self._k & 1])
+        elif self.via == "p2p":
+            env.gather_p2p(self.mode)
         else:
-            self.tg.launch(env.gather_source(self.mode))
+            self.tg.launch(self._source())
         if self.mode == "full-u16":
             env.rotate_compact()
+        elif self.arenas is not None:
+            self._k ^= 1
+            env.set_arena(self.arenas[self._k])
 
     def wait(self):
         if self.via == "abi":
             self.env.gather_wait(host_sync=True)
+        elif self.via == "p2p":
+            self.env.gather_p2p_wait(host_sync=True)
         else:
             self.tg.wait()
+
+    def close(self):
+        """Leave the env as it was found: outputs in its own arena."""
+        self.wait()
+        if self.arenas is not None:
+            self.env.set_arena(None)
+            self._k = 0
 
 
 def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="random"):
@@ -162,6 +249,8 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus, args.launch_timeout)          # does not return
     import torch
     import torch.distributed as dist
 
@@ -169,17 +258,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks", file=sys.stderr)
-            sys.exit(2)
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     distributed = world > 1 or (args.force_gather and "RANK" in os.environ)
     dev = local_rank % max(torch.cuda.device_count(), 1)      # ranks > GPUs only in --backend gloo functional tests
     torch.cuda.set_device(dev)
+    comm_ranks = None
     if distributed:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group("gloo")
+        # what the communicator itself says about its size: one contribution per rank, summed by the collective
+        one = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        comm_ranks = int(one.item())
 
     from racing_dreamer_amd import _lib as L
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
@@ -199,6 +292,7 @@ def main():
     env.reset(mode="random", seed=0)
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     via = args.gather_via
+    abi_ranks = None
     if distributed and via == "abi":
         if args.backend != "nccl":
             via = "torch"                       # RCCL wants one GPU per rank; the gloo functional tests share one
@@ -206,8 +300,24 @@ def main():
             ids = [BatchedRaceEnv.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             env.comm_init(ids[0], rank, world)
+            abi_ranks = env.comm_count()
     every = max(1, args.gather_every)
-    gather = Gatherer(env, gather_mode, every, via, dist) if gather_mode != "none" else None
+    if via == "p2p" and every != 1:
+        raise SystemExit("--gather-via p2p sends one record per gather (--gather-every 1)")
+
+    def make_gatherer(mode):
+        if mode == "none":
+            return None
+        if via == "p2p":                        # the peers' buffers depend on the payload: (re)connect per mode
+            if getattr(env, "_p2p_mode", None) is not None:
+                env.p2p_teardown()
+            blob = env.p2p_setup(mode, rank, world)
+            blobs = [None] * world
+            dist.all_gather_object(blobs, blob)
+            env.p2p_connect(blobs)
+        return Gatherer(env, mode, every, via, dist)
+
+    gather = make_gatherer(gather_mode)
 
     # the rollout loop works on the env's own stream (no cross-stream event waits between the step's kernels and
     # the collective's dependency on them); `barrier()` synchronises the whole device
@@ -215,8 +325,7 @@ def main():
 
     def one_step(k, repeat=None, g=None):
         env.step_random(seed=1, step=k, repeat=repeat)        # actions drawn inside the dynamics kernel (Philox, on device)
-        g = gather if g is None else g
-        if g:
+        if g is not None:
             g.after_step()
 
     def barrier():
@@ -225,11 +334,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def finish(g):
+        if g is not None:
+            g.wait()
+        env.sync()
+
     for k in range(args.warmup):
-        one_step(k)
-    if gather is not None:
-        gather.wait()
-    env.sync()
+        one_step(k, g=gather)
+    finish(gather)
     env.reset_kernel_times()
     # start / stop timestamps attached to every launch of the DOMINANT kernel (the scan) on the stream it runs on;
     # timing the two small kernels as well would cost the timed region 6 us per step, so they get a pass of their
@@ -238,64 +350,104 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(args.warmup + k)
-    if gather is not None:
-        gather.wait()
-    env.sync()
+        one_step(args.warmup + k, g=gather)
+    finish(gather)
     barrier()
     dt = time.perf_counter() - t0
     env.set_profiling(False)
     ktimes = env.kernel_times()
+    scan_symbol = env.scan_kernel_name()
     # the other kernels of the step: a short untimed pass with all timers on
     env.reset_kernel_times()
     env.set_profiling(True, kernels=[L.K_PATCH, L.K_DYNAMICS])
     for k in range(min(args.steps, 50)):
-        one_step(args.warmup + args.steps + k)
-    if gather is not None:
-        gather.wait()
-    env.sync()
+        one_step(args.warmup + args.steps + k, g=gather)
+    finish(gather)
     env.set_profiling(False)
     for name, v in env.kernel_times().items():
         if name != "rc_raycast_kernel":
             ktimes[name] = v
     step_no = args.warmup + 2 * args.steps
 
+    # secondary figure: the reference's own setting, action_repeat 4 with the scan once per agent step
+    # (dreamer/dream.py:55) - a quarter of the steps, same barriers, same payload as the headline
+    r4_steps = max(args.steps // 4, 5)
+    barrier()
+    t1 = time.perf_counter()
+    for k in range(r4_steps):
+        one_step(step_no + k, repeat=4, g=gather)
+    finish(gather)
+    barrier()
+    dt4 = time.perf_counter() - t1
+    step_no += r4_steps
+    headline_bytes = gather.bytes if gather is not None else 0
+    headline_in_place = gather.in_place if gather is not None else True
+    if gather is not None:
+        gather.close()
+
     # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
-    # sequence): what the headline's choice of payload costs, measured rather than argued
-    mode_legs = {}
+    # sequence): what the headline's choice of payload costs, measured rather than argued.  Each leg sets the env up for
+    # its own payload only (`includes` says what its step carried); `none` is the pure simulation rate.
+    mode_legs, leg_includes = {}, {}
     if distributed and not args.no_gather_modes:
         n_leg = max(args.steps // 4, 5)
         for m in GATHER_MODES:
             if m == gather_mode:
                 continue
-            g = Gatherer(env, m, every, via, dist) if m != "none" else False
+            if m == "none" and getattr(env, "compact", None) is not None:
+                env.disable_compact()
+            g = make_gatherer(m)
+            leg_includes[m] = g.includes if g is not None else "no collective, no uint16 rows, no summary copy: the simulation alone"
             for k in range(3):
                 one_step(step_no + k, g=g)
-            if g:
-                g.wait()
+            finish(g)
             barrier()
             t1 = time.perf_counter()
             for k in range(n_leg):
                 one_step(step_no + 3 + k, g=g)
-            if g:
-                g.wait()
-            env.sync()
+            finish(g)
             barrier()
             mode_legs[m] = [time.perf_counter() - t1, n_leg]
             step_no += 3 + n_leg
+            if g is not None:
+                g.close()
+    if getattr(env, "_p2p_mode", None) is not None:
+        env.p2p_teardown()
+        env._p2p_mode = None
 
-    # secondary figure: the reference's own setting, action_repeat 4 with the scan once per agent step
-    # (dreamer/dream.py:55) - a quarter of the steps, same barriers
-    r4_steps = max(args.steps // 4, 5)
-    barrier()
-    t1 = time.perf_counter()
-    for k in range(r4_steps):
-        one_step(step_no + k, repeat=4)
-    if gather is not None:
-        gather.wait()
-    env.sync()
-    barrier()
-    dt4 = time.perf_counter() - t1
+    # N > 1: the payload DESIGN.md 6 recommends instead of per-step records - every rank keeps its records in a
+    # device-resident ring and what crosses the links is the TRAINING BATCH: ShardedReplay.sample(50 windows x 50 steps)
+    # once per step (far more often than a learner asks for one)
+    batch_leg = None
+    if distributed and not args.no_gather_modes:
+        from racing_dreamer_amd.replay import ShardedReplay, TrajectoryRing
+        if getattr(env, "compact", None) is not None:
+            env.disable_compact()
+        length, cap = 50, 64
+        batch = -(-50 // world) * world
+        ring = TrajectoryRing(env, cap)
+        for k in range(length + 4):                   # fill: a window needs `length` records
+            ring.step_random(seed=1, step=step_no + k)
+        step_no += length + 4
+        rep = ShardedReplay(ring)
+        gen = torch.Generator(device=env.device)
+        gen.manual_seed(1234 + rank)
+        fields = ("lidar", "action", "reward", "discount")
+        out = rep.sample(batch, length, fields=fields, generator=gen)        # warm-up
+        batch_bytes = sum(int(out[f].numel() * out[f].element_size()) for f in fields) // world
+        n_leg = max(args.steps // 4, 5)
+        env.sync()
+        barrier()
+        t1 = time.perf_counter()
+        for k in range(n_leg):
+            ring.step_random(seed=1, step=step_no + k)
+            rep.sample(batch, length, fields=fields, generator=gen)
+        env.sync()
+        barrier()
+        batch_leg = [time.perf_counter() - t1, n_leg, batch_bytes, batch, length]
+        step_no += n_leg
+        ring.detach()
+        del rep, ring
 
     # secondary figure: the long-ray case of SURVEY.md 8d - cars driven along the track by the follow-the-gap agent
     # (the reference's other prefill policy, dreamer/dream.py:211-216) instead of crashing into walls with random
@@ -329,13 +481,15 @@ def main():
                        "line, long rays) instead of random actions; includes the agent's kernel"}
 
     if distributed:
-        times = [dt, dt4] + [v[0] for v in mode_legs.values()]
+        times = [dt, dt4] + [v[0] for v in mode_legs.values()] + ([batch_leg[0]] if batch_leg else [])
         tmax = torch.tensor(times, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         times = [float(v) for v in tmax.tolist()]
         dt, dt4 = times[0], times[1]
         for (m, v), t in zip(mode_legs.items(), times[2:]):
             v[0] = t
+        if batch_leg:
+            batch_leg[0] = times[-1]
 
     total_envs = args.envs * world
     env_steps = total_envs * args.steps * args.repeat
@@ -344,27 +498,32 @@ def main():
     out = None
     if rank == 0:
         ray = ktimes["rc_raycast_kernel"]
-        # the symbol rocprofv3 lists: the default scan (variant 7) is rc_raycast_car_kernel<A>, variants 0-6 rc_raycast_kernel<A, V>
-        variant = 7 if args.raycast_variant is None else args.raycast_variant
-        ray_symbol = f"rc_raycast_car_kernel<{args.cars}>" if variant == 7 else f"rc_raycast_kernel<{args.cars}, {variant}>"
         ray_s = ray["avg_ms"] * 1e-3
         achieved = RAYCAST_BYTES_PER_CAR * n_cars / ray_s / 1e9 if ray_s > 0 else 0.0
-        traffic = valu = None
+        # HBM traffic and instruction counts of the scan are PMC figures: they cannot be collected inside this run (the
+        # counters need rocprofv3 passes of their own), so they are quoted from the committed profile of the SAME
+        # workload (track, batch, obs_type, default scan) and are null for any other - `traffic_source` says which file
+        traffic = valu = traffic_source = None
         tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tp):
+        key = f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}"
+        if os.path.exists(tp) and args.raycast_variant is None and not args.debug_knob and scan_symbol.endswith("false, false>"):
             with open(tp) as f:
                 prof = json.load(f)
-            traffic = prof.get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
-            valu = prof.get("_valu_wave_insts", {}).get(f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}")
+            traffic = prof.get(key)
+            valu = prof.get("_valu_wave_insts", {}).get(key)
+            if traffic is not None:
+                traffic_source = prof.get("_source", "profiles/hbm_traffic.json") + " (builder-run rocprofv3 --pmc passes of this workload; not measured in this run)"
         if not distributed:
             gather_txt = "no collective (one rank)"
-        elif gather is None:
+        elif gather_mode == "none":
             gather_txt = "NO trajectory gather (--gather none)"
         else:
-            gather_txt = (f"every step's trajectory record all-gathered over RCCL as `{gather_mode}` ({gather.bytes} B per GPU "
-                          f"per step, {'read in place from a double-buffered slab' if gather.in_place else 'from staging copies'}, "
-                          f"one collective per {every} step{'s' if every > 1 else ''}, transport {via}, overlapped with the "
-                          f"following step; the gathered buffer is overwritten by the next collective - no consumer in this benchmark)")
+            how = {"torch": "RCCL all-gather through torch.distributed", "abi": "RCCL all-gather through rc_gather_trajectory",
+                   "p2p": "direct peer copies through rc_gather_trajectory_p2p (hipIpc, one copy stream per peer)"}[via]
+            gather_txt = (f"every step's trajectory record gathered on every rank as `{gather_mode}` ({headline_bytes} B per GPU "
+                          f"per step, {'read in place from a double-buffered source' if headline_in_place else 'from staging copies'}, "
+                          f"one gather per {every} step{'s' if every > 1 else ''}, {how}, overlapped with the "
+                          f"following step; the gathered buffer is overwritten two gathers later - no consumer in this benchmark)")
         out = {
             "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -378,11 +537,15 @@ def main():
                 "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
                 "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
                 "obs_type": args.obs_type, "action_repeat": args.repeat,
-                "parallelism": f"env-sharded x{world}", "gather": gather_mode,
+                "parallelism": f"env-sharded x{world}", "gather": gather_mode, "gather_via": via if distributed else None,
+                # the size of the job as the communicator reports it (sum over ranks of 1 through the backend's own
+                # all-reduce; ncclCommCount of the C-ABI's communicator when that transport is used)
+                "rccl_ranks": comm_ranks if (distributed and args.backend == "nccl") else None,
+                "comm_backend": args.backend if distributed else None, "comm_ranks": comm_ranks, "abi_comm_ranks": abi_ranks,
             },
             "roofline": {
-                "bound": "hbm", "kernel": ray_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "bound": "hbm", "kernel": scan_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
                 "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
                 "rays_per_s": n_cars * 1080 / ray_s if ray_s > 0 else 0.0,
@@ -390,8 +553,8 @@ def main():
                 # profile, and the rate they retire at per SIMD (1 024 SIMDs) at the duration measured here
                 "valu_wave_insts_per_launch": valu,
                 "valu_insts_per_simd_per_us": (valu / 1024 / (ray_s * 1e6)) if (valu and ray_s > 0) else None,
-                "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by VALU work "
-                        "of the grid traversal, not by HBM (SURVEY.md §8d); see DESIGN.md §5",
+                "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by the instruction stream "
+                        "of the grid traversal, not by HBM (SURVEY.md §8d); the >= 40 % HBM target is NOT met; DESIGN.md §4.2",
             },
             "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
             "action_repeat_4": {"env_steps_per_s": total_envs * r4_steps * 4 / dt4,
@@ -409,8 +572,18 @@ def main():
                     e.update(ms_per_step=dt / args.steps * 1e3, env_steps_per_s=value, steps=args.steps, headline=True)
                 elif m in mode_legs:
                     t, n = mode_legs[m]
-                    e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n)
+                    e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n,
+                             includes=leg_includes.get(m))
                 table[m] = e
+            if batch_leg:
+                t, n, nbytes, batch, length = batch_leg
+                e = gather_link_model(nbytes, world)
+                e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n,
+                         includes=f"records kept in a {64}-slot device ring per rank (rc_set_arena, no copy); every step "
+                                  f"ShardedReplay.sample({batch} windows x {length} steps: lidar, action, reward, discount) "
+                                  f"all-gathered over torch.distributed - {nbytes} B per rank per sample; the sampler's "
+                                  f"rejection loop synchronises the host once per sample")
+                table["batch"] = e
             out["gather_modes"] = table
         if ftg is not None:
             out["follow_the_gap"] = ftg
@@ -426,9 +599,11 @@ def main():
                      "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
             out["configs"] = [time_config(*c) for c in cfgs]
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
             from oracle import cpu_baseline as cb
+            out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
             out["cpu_baseline"]["single_env"] = cb.run_single_env()      # BASELINE.json configs[0]: the B = 1 CPU step()
+            if not args.no_numpy_baseline:
+                out["cpu_baseline"]["numpy_batch"] = cb.run_numpy_batch(track, n_envs=args.numpy_envs)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

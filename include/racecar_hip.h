@@ -218,6 +218,7 @@ int rc_compact_layout(rc_env *env, size_t *lidar_u16_bytes, size_t *summary_offs
 int rc_comm_library(const char *path);
 int rc_comm_unique_id(void *out_128_bytes, size_t bytes);
 int rc_comm_init(rc_env *env, const void *unique_id, size_t bytes, int32_t rank, int32_t world);
+int rc_comm_count(rc_env *env, int32_t *ranks);      /* ncclCommCount of the handle's communicator */
 
 /* All-gather of the last step's record over the communicator: dev_dst receives world x rc_gather_bytes(mode) bytes,
  * rank r's record at r * rc_gather_bytes(mode).  RC_GATHER_FULL = the rc_trajectory_slab bytes (fp32 LiDAR),
@@ -230,6 +231,28 @@ enum { RC_GATHER_FULL = 0, RC_GATHER_FULL_U16 = 1, RC_GATHER_SUMMARY = 2 };
 size_t rc_gather_bytes(rc_env *env, int32_t mode);
 int rc_gather_trajectory(rc_env *env, int32_t mode, void *dev_dst, size_t dst_bytes);
 int rc_gather_wait(rc_env *env, int32_t host_sync);
+
+/* ---- The same all-gather as DIRECT PEER COPIES (on the xGMI full mesh each rank's record should cross
+ * each link once - N - 1 concurrent copies into the peers' buffers - where a ring passes it on N - 1 times).  No RCCL:
+ * hipIpc memory handles, one copy stream per peer, sequence flags in uncached device memory.
+ *   rc_p2p_setup    allocates this rank's destination (two slots of world x rc_gather_bytes(mode)) and flag block and
+ *                   writes an RC_P2P_EXPORT_BYTES blob; the caller hands every rank's blob to every rank (file, socket,
+ *                   MPI, torch.distributed - the library does not care), rank r's at offset r * RC_P2P_EXPORT_BYTES;
+ *   rc_p2p_connect  opens the peers' buffers;
+ *   rc_gather_trajectory_p2p   sends the last step's record (the source of `mode`, see rc_gather_trajectory; the caller
+ *                   double-buffers it the same way) into slot k & 1 of every rank, k = 0, 1, ... counting the calls:
+ *                   queued behind the work on the handle's stream, runs on streams of its own;
+ *   rc_gather_p2p_wait         orders the handle's stream (host_sync != 0: and the host) behind the arrival of every
+ *                   rank's record of the LAST issued gather and returns the slot: rank r's record at r * bytes.  The slot
+ *                   stays valid until the call that issues the gather after next; a peer that does not take part within
+ *                   RC_P2P_TIMEOUT_S (20 s) makes the host-synchronising wait return RC_ERR_COMM instead of blocking.
+ * Every rank must issue the same sequence of gathers.  Ranks may share a GPU (functional tests) or sit on one each. */
+#define RC_P2P_EXPORT_BYTES 256
+int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *export_out, size_t bytes);
+int rc_p2p_connect(rc_env *env, const void *exports_world_x_256, size_t bytes);
+int rc_gather_trajectory_p2p(rc_env *env);
+int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size_t *gathered_bytes);
+int rc_p2p_teardown(rc_env *env);
 
 /* Re-point the output fields (everything rc_get returns except RC_F_ACTION_IN, which stays where it is) at
  * another device buffer of at least rc_arena_bytes(), 64-byte aligned; NULL = back to the handle's own arena.
@@ -250,6 +273,10 @@ int rc_reset_kernel_times(rc_env *env);
 /* Raycast implementation selector, 0..7 (all variants return identical results; 7, the default, is the
  * fastest: per-cell, per-quadrant free rectangles, one wave per car; 0 is the cell-by-cell reference traversal). */
 int rc_set_raycast_variant(rc_env *env, int32_t variant);
+/* The symbol of the scan kernel the next rc_step launches, as rocprofv3 lists it (without namespace and argument list),
+ * e.g. "rc_raycast_car_kernel<1, false, false>": template arguments = cars per env, next round prepared under the first
+ * request (small batches), bounded trip loop. */
+int rc_scan_kernel_name(rc_env *env, char *out, size_t bytes);
 
 /* Experiment / validation knobs of the scan - NOT part of the product interface; every knob is 0 in production and
  * the library reads nothing from the process environment.  RAY_THREADS / RAY_SPLIT / RAY_WG_PER_CU: launch geometry
@@ -257,10 +284,20 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant);
  * max(w, h) * 2^value cells instead of 2^-21 - tests/test_gpu_parity.py narrows it to show that its corner-aimed rays
  * detect a band below the rounding bound.  Takes effect immediately (also after rc_load_track). */
 enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, RC_DBG_BAND_LOG2 = 3,
-       RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiments: bit 0 row-major runs, bit 1 plain stores,
-                                       bit 2 results transposed through LDS */
-       RC_DBG_COUNT = 5 };
+       RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiments: bit 1 plain instead of non-temporal stores;
+                                       bit 3 the round-2 kernel (four waves per car), whose bits 0 / 2 pick row-major
+                                       runs / results transposed through LDS */
+       RC_DBG_SCAN_BOUNDED = 5,     /* != 0: the scan runs the build whose trip loop carries a trip budget (see below) */
+       RC_DBG_COUNT = 6 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
+
+/* The default scan's trip loop is unbounded in the production build (its termination is a property of the tables and
+ * of the exact-count band, derived in racecar_kernels.hip; a bound costs 4 % of the scan).  The BOUNDED build of the same
+ * kernel - a wave-level budget of w + h + 2 trips per round; a ray that uses it up reads "no return" - runs (a) inside
+ * rc_load_track over every cell a sensor can stand in (a track whose tables make any ray overrun is refused), (b) while a
+ * validation band is set, (c) under RC_DBG_SCAN_BOUNDED.  rc_scan_overruns reports how many waves of this handle's
+ * bounded scans have used up a budget so far (0 unless a band was mis-set or a table is corrupt). */
+int rc_scan_overruns(rc_env *env, uint64_t *count);
 
 /* In-kernel time stamps of the default scan (analysis only, like the knobs above): when `stamps` is non-NULL the next
  * scans run an instrumented build of the one-wave-per-car kernel (1 car per env only) whose first `n_waves` waves write

@@ -74,6 +74,8 @@ def load():
         lib.oc_random_actions.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         for f in (lib.oc_reset, lib.oc_step_range, lib.oc_raycast_range, lib.oc_patch_range, lib.oc_random_actions):
             f.restype = None
+        lib.oc_spin.argtypes = [C.c_uint64]
+        lib.oc_spin.restype = C.c_uint64
         _lib = lib
     return _lib
 
@@ -141,7 +143,8 @@ class COracleEnv:
 
     # ------------------------------------------------------------------
     def _split(self, n):
-        k = self.threads
+        # several chunks per thread: the pool hands them out as threads become free (rays differ in length)
+        k = self.threads if self.threads == 1 else min(n, self.threads * 8)
         edges = [n * i // k for i in range(k + 1)]
         return [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
 
@@ -168,13 +171,15 @@ class COracleEnv:
         self._observe()
         return self.outputs()
 
-    def step(self, actions, repeat=1):
+    def step(self, actions, repeat=1, outputs=True):
+        """outputs=False: the results stay in the env's own arrays (self.arr, self.lidar, self.patch) and no per-step
+        copies are made - what the timed cpu_baseline leg uses, so that it times the simulator and not NumPy copies."""
         assert self.was_reset, "Must reset environment."
         act = np.ascontiguousarray(np.asarray(actions, np.float32).reshape(self.NC, 2))
         self._par(lambda a, b: self.lib.oc_step_range(C.byref(self.trk), C.byref(self.ccfg), C.byref(self.state),
                                                       act.ctypes.data, int(repeat), a, b), self.B)
         self._observe()
-        return self.outputs()
+        return self.outputs() if outputs else None
 
     def random_actions(self, seed, step):
         out = np.zeros((self.NC, 2), np.float32)

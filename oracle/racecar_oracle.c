@@ -446,3 +446,12 @@ void oc_patch_range(const oc_track *t, const oc_state *s, uint8_t *patch, int c0
         }
     }
 }
+
+/* CPU-share calibration for bench.py's cpu_baseline leg (oracle/cpu_baseline.py): a fixed amount of dependent integer
+ * work.  One call on one thread against T concurrent calls on T threads tells how many cores the process really gets
+ * (a container's CPU quota is not visible through sched_getaffinity). */
+uint64_t oc_spin(uint64_t iterations) {
+    uint64_t x = 0x9e3779b97f4a7c15ull;
+    for (uint64_t i = 0; i < iterations; ++i) x = x * 6364136223846793005ull + 1442695040888963407ull + (x >> 29);
+    return x;
+}

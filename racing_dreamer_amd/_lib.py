@@ -25,9 +25,10 @@ GATHER_FULL, GATHER_FULL_U16, GATHER_SUMMARY = range(3)
 GATHER_MODES = {"full": GATHER_FULL, "full-u16": GATHER_FULL_U16, "summary": GATHER_SUMMARY}
 
 # rc_debug_set knobs (experiments / validation only; all 0 in production)
-DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2, DBG_PATCH_VARIANT = range(5)
+DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2, DBG_PATCH_VARIANT, DBG_SCAN_BOUNDED = range(6)
 DEBUG_KNOBS = {"ray_threads": DBG_RAY_THREADS, "ray_split": DBG_RAY_SPLIT, "ray_wg_per_cu": DBG_RAY_WG_PER_CU,
-               "band_log2": DBG_BAND_LOG2, "patch_variant": DBG_PATCH_VARIANT}
+               "band_log2": DBG_BAND_LOG2, "patch_variant": DBG_PATCH_VARIANT, "scan_bounded": DBG_SCAN_BOUNDED}
+P2P_EXPORT_BYTES = 256
 
 K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_FTG, K_COUNT = range(7)
 KERNEL_NAMES = {K_DYNAMICS: "rc_dynamics_kernel", K_RAYCAST: "rc_raycast_kernel", K_PATCH: "rc_patch_kernel",
@@ -74,6 +75,14 @@ SYMBOLS = {
     "rc_set_raycast_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "rc_debug_set": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rc_debug_scan_stamps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    "rc_scan_overruns": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
+    "rc_scan_kernel_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "rc_comm_count": (C.c_int, [C.c_void_p, _P(C.c_int32)]),
+    "rc_p2p_setup": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]),
+    "rc_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rc_gather_trajectory_p2p": (C.c_int, [C.c_void_p]),
+    "rc_gather_p2p_wait": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
+    "rc_p2p_teardown": (C.c_int, [C.c_void_p]),
     "rc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
     "rc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_copy_from_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -298,6 +298,58 @@ class BatchedRaceEnv:
     def gather_wait(self, host_sync: bool = True) -> None:
         L.check(self._lib.rc_gather_wait(self._h, int(bool(host_sync))))
 
+    # ---- the same gather as direct peer copies (rc_gather_trajectory_p2p: hipIpc handles, one copy stream per peer) ----
+    def p2p_setup(self, mode: str, rank: int, world: int) -> bytes:
+        """Allocate this rank's destination and flags for peer-copy gathers of `mode`; returns the 256-byte blob the other
+        ranks need.  Hand every rank's blob (in rank order) to `p2p_connect` on every rank."""
+        buf = C.create_string_buffer(L.P2P_EXPORT_BYTES)
+        L.check(self._lib.rc_p2p_setup(self._h, L.GATHER_MODES[mode], int(rank), int(world), buf, L.P2P_EXPORT_BYTES))
+        self._p2p_mode, self._p2p_world = mode, int(world)
+        return buf.raw
+
+    def p2p_connect(self, blobs) -> None:
+        raw = b"".join(bytes(b) for b in blobs)
+        L.check(self._lib.rc_p2p_connect(self._h, C.create_string_buffer(raw, len(raw)), len(raw)))
+
+    def gather_p2p(self, mode: Optional[str] = None) -> None:
+        """Send the last step's record into every rank's buffer (asynchronous, behind the work on the env's stream)."""
+        if mode is not None and mode != self._p2p_mode:
+            raise ValueError(f"the peer-copy gather was set up for {self._p2p_mode!r}, not {mode!r}")
+        L.check(self._lib.rc_gather_trajectory_p2p(self._h))
+
+    def gather_p2p_wait(self, host_sync: bool = True):
+        """Order the env's stream (and the host) behind the arrival of the last issued gather; returns (device pointer,
+        bytes) of the gathered slot: rank r's record at r * bytes / world."""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        L.check(self._lib.rc_gather_p2p_wait(self._h, int(bool(host_sync)), C.byref(ptr), C.byref(nb)))
+        return ptr.value, nb.value
+
+    def gathered_p2p_host(self) -> np.ndarray:
+        """Host copy of the last gathered slot as uint8 [world, bytes per rank] (synchronising)."""
+        ptr, nb = self.gather_p2p_wait(host_sync=True)
+        out = np.empty(nb, np.uint8)
+        L.check(self._lib.rc_copy_from_device(self._h, ptr, out.ctypes.data, nb))
+        return out.reshape(self._p2p_world, -1)
+
+    def p2p_teardown(self) -> None:
+        L.check(self._lib.rc_p2p_teardown(self._h))
+
+    def comm_count(self) -> int:
+        n = C.c_int32()
+        L.check(self._lib.rc_comm_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    def scan_kernel_name(self) -> str:
+        buf = C.create_string_buffer(128)
+        L.check(self._lib.rc_scan_kernel_name(self._h, buf, 128))
+        return buf.value.decode()
+
+    def scan_overruns(self) -> int:
+        """Waves of this handle's BOUNDED scans that used up a round's trip budget (0 unless a band was mis-set)."""
+        n = C.c_uint64()
+        L.check(self._lib.rc_scan_overruns(self._h, C.byref(n)))
+        return int(n.value)
+
     def debug_set(self, knob: str, value: int) -> None:
         """Experiment / validation knobs of the scan (`rc_debug_set`; 0 = production behaviour): ray_threads,
         ray_split, ray_wg_per_cu, band_log2.  Used by tools/knob_sweep.sh and the band-sensitivity check of

@@ -36,14 +36,66 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# Kernels that hand a register to an asynchronous load through inline assembly and wait for it in a LATER assembly
+# statement (the scan's table request, racecar_kernels.hip: trip_head / trip_tail): between the two the compiler believes
+# the value is there.  That is safe as long as it keeps the value where the load will write it - it does not copy a live
+# register without need - but a spill of that register to scratch would store it BEFORE the load has landed.  So the build
+# refuses a library in which one of these kernels spills or uses scratch at all, and one that has fallen below the
+# occupancy the launch geometry assumes.
+NO_SPILL_KERNELS = ("rc_raycast_car_kernel", "rc_raycast_car_stamps_kernel", "rc_raycast_kernel", "rc_patch_car_kernel")
+MIN_WAVES_PER_SIMD = {"rc_raycast_car_kernel": 8, "rc_patch_car_kernel": 8}
+
+
+def check_resource_usage(remarks: str) -> None:
+    """Parse `-Rpass-analysis=kernel-resource-usage` remarks; raise if a kernel of NO_SPILL_KERNELS spills."""
+    import re
+    name, problems, seen = None, [], set()
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            continue
+        m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]): (\d+)", line)
+        if not m or name is None:
+            continue
+        kernel = next((k for k in NO_SPILL_KERNELS if k + "I" in name or name.endswith(k) or k + "E" in name), None)
+        if kernel is None:
+            continue
+        seen.add(kernel)
+        key, val = m.group(1), int(m.group(2))
+        if key.startswith("Occupancy"):
+            if val < MIN_WAVES_PER_SIMD.get(kernel, 1):
+                problems.append(f"{name}: {val} waves/SIMD < {MIN_WAVES_PER_SIMD[kernel]}")
+        elif key != "SGPRs Spill" and val != 0:
+            problems.append(f"{name}: {key} = {val}")
+    missing = [k for k in ("rc_raycast_car_kernel", "rc_patch_car_kernel") if k not in seen]
+    if missing:
+        raise RuntimeError(f"resource-usage remarks not found for {missing}: cannot verify that the scan does not spill")
+    if problems:
+        raise RuntimeError("build refused (see racing_dreamer_amd/build.py, NO_SPILL_KERNELS):\n  " + "\n  ".join(problems))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [find_hipcc(), *FLAGS, *[os.path.join(CSRC, s) for s in SOURCES], "-o", LIB_PATH]
+    tmp = LIB_PATH + ".new"
+    cmd = [find_hipcc(), *FLAGS, "-Rpass-analysis=kernel-resource-usage", *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
     if verbose:
         print("[racing_dreamer_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    other = [l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not l.startswith(("      |", " ")) and "hip-link" not in l]
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-8000:])
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    if other and verbose:
+        print("\n".join(other), file=sys.stderr)
+    try:
+        check_resource_usage(r.stderr)
+    except RuntimeError:
+        os.remove(tmp)
+        raise
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -2,6 +2,7 @@
 // stream-ordered launches.  No exceptions cross the boundary; errors are codes + rc_last_error().
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cmath>
@@ -9,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -99,6 +101,7 @@ struct Rccl {
     int (*CommInitRank)(void **, int, /* ncclUniqueId by value */ struct RcUid, int) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    int (*CommCount)(void *, int *) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
 };
 
@@ -109,6 +112,11 @@ struct Rccl {
 struct TrackTables {
     int device = 0;
     void *mem = nullptr;
+    // what the tables were built from, compared on a cache hit besides the 64-bit key: shape, geometry and a second,
+    // independent checksum of the arrays (a key collision must not hand a handle another track's tables)
+    int32_t h = 0, w = 0, pitch = 0, n_centerline = 0;
+    float res = 0.f, ox = 0.f, oy = 0.f;
+    uint64_t sum2 = 0;
     RcTrackDev t{};
     size_t lds_bytes = 0, lds_bytes_skip = 0, lds_bytes_packed = 0;
     ~TrackTables() {
@@ -127,9 +135,46 @@ uint64_t fnv1a(uint64_t h, const void *data, size_t n) {
     return h;
 }
 
+uint64_t wordsum(uint64_t acc, const void *data, size_t n) {     // position-weighted sum of the 32-bit words (n % 4 == 0)
+    const uint32_t *w = (const uint32_t *)data;
+    for (size_t i = 0; i < n / 4; ++i) acc += (uint64_t)w[i] * (2 * i + 1) + 0x9e3779b97f4a7c15ull;
+    return acc;
+}
+
 struct EventPair {
     hipEvent_t a, b;
     int kernel;
+};
+
+// ---- peer-copy all-gather (on the xGMI full mesh every shard crosses exactly one link once if each rank
+// copies its record straight into every peer's buffer - N - 1 concurrent copies - where a ring passes it N - 1 times).
+// Every rank owns: the destination, two slots of world x bytes (hipMalloc, exported over hipIpc), and a block of
+// sequence flags in uncached device memory that its PEERS write: arrived[p] = k + 1 when peer p's shard of gather k has
+// landed, released[p] = k + 1 when peer p allows gather k to be written into ITS slot k & 1.
+struct P2pExport {                 // what a rank hands to its peers (RC_P2P_EXPORT_BYTES)
+    hipIpcMemHandle_t dst, flags;
+    uint64_t bytes;                // per rank and slot
+    int32_t rank, world, mode, pid;
+    char pci[32];
+    char pad[RC_P2P_EXPORT_BYTES - 2 * sizeof(hipIpcMemHandle_t) - 8 - 16 - 32];
+};
+static_assert(sizeof(P2pExport) == RC_P2P_EXPORT_BYTES, "export blob size");
+
+struct P2p {
+    int rank = 0, world = 0, mode = 0;
+    size_t bytes = 0;              // one rank's record
+    char *dst = nullptr;           // [2][world][bytes], mine
+    uint32_t *flags = nullptr;     // arrived[64] | released[64] | timeouts, mine (uncached)
+    std::vector<char *> peer_dst;          // peers' destinations, opened (null for me)
+    std::vector<uint32_t *> peer_flags;    // peers' flag blocks, opened (null for me)
+    std::vector<hipStream_t> push;         // one stream per peer (the local copy runs on push[rank])
+    hipStream_t ctrl = nullptr;            // release + wait-for-release kernels; arrival waits
+    hipEvent_t ev_ready = nullptr, ev_go = nullptr, ev_arrived = nullptr, ev_local = nullptr;
+    uint32_t issued = 0;           // gathers issued so far
+    bool connected = false;
+    uint32_t *arrived() const { return flags; }
+    uint32_t *released() const { return flags + RC_P2P_MAX_RANKS; }
+    uint32_t *timeouts() const { return flags + 2 * RC_P2P_MAX_RANKS; }
 };
 
 }  // namespace
@@ -167,6 +212,7 @@ struct rc_env {
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
     bool gather_pending = false;
+    P2p *p2p = nullptr;                // peer-copy all-gather (rc_p2p_setup), else null
 };
 
 namespace {
@@ -278,8 +324,8 @@ void set_band(rc_env *env) {
     t.band2 = 2.0f * t.band;
     // With the shipped band every trip provably moves its ray at least one cell along the exit axis (racecar_kernels.hip,
     // ray_traverse), so the loop ends at the ring of stop cells; a narrower validation band voids that proof, and the
-    // scan then runs the build whose loop counts its trips.
-    env->launch.scan_guarded = (l2 <= -10 && l2 >= -40 && l2 != -21) ? 1 : 0;
+    // scan then runs the build whose loop is bounded by a trip budget (also on request: RC_DBG_SCAN_BOUNDED).
+    env->launch.scan_guarded = ((l2 <= -10 && l2 >= -40 && l2 != -21) || env->dbg[RC_DBG_SCAN_BOUNDED] != 0) ? 1 : 0;
 }
 
 // Point every output field at `arena` (layout of make_layout).  The action input buffer is NOT part of this: it
@@ -350,6 +396,7 @@ int load_rccl() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString)
         return fail(RC_ERR_COMM, "the RCCL library lacks an expected symbol");
@@ -527,7 +574,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         any_nstep |= a < cfg->cars_per_env && env->params.car_task[a] == RC_TASK_N_STEP_PROGRESS;
     }
     env->params.n_steps = cfg->n_steps;
-    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6 + 16) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0);
+    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6 + 16) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0) + 64;
     HIP_TRY_FREE(hipMalloc(&env->state_mem, state_bytes));
     HIP_TRY_FREE(hipMemsetAsync(env->state_mem, 0, state_bytes, env->stream));
     HIP_TRY_FREE(hipMalloc((void **)&env->mask_dev, ne));
@@ -545,6 +592,8 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         uint8_t **bp[] = {&s.wall, &s.opp, &s.wrong, &s.done, &s.trunc, &s.fresh};
         for (uint8_t **b : bp) { *b = (uint8_t *)m; m += nc; }
         s.nstep_hist = any_nstep ? (float *)m : nullptr;      // (nc * (48 + 6) + ne * 12 bytes in: 4-byte aligned)
+        if (any_nstep) m += nc * RC_NSTEP_MAX * 4;
+        env->params.scan_overrun = (uint32_t *)m;             // (zeroed with the rest)
     }
     bind_outputs(env, env->arena);
     env->actions_in = (float *)((char *)env->arena + env->layout.offset[RC_F_ACTION_IN]);
@@ -574,10 +623,13 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     return RC_OK;
 }
 
+static void p2p_free(rc_env *env);
+
 void rc_destroy(rc_env *env) {
     if (!env) return;
     (void)hipSetDevice(env->cfg.device);
     if (env->stream) (void)hipStreamSynchronize(env->stream);
+    p2p_free(env);
     if (env->comm_stream) (void)hipStreamSynchronize(env->comm_stream);
     if (env->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(env->comm);
     if (env->ev_ready) (void)hipEventDestroy(env->ev_ready);
@@ -608,7 +660,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(hipSetDevice(env->cfg.device));
     const size_t nwords = (size_t)h * pitch;
     // the same track already on this device (another handle of the process loaded it)?
-    uint64_t key = 0xcbf29ce484222325ull;
+    uint64_t key = 0xcbf29ce484222325ull, sum2 = 0;
     {
         const int32_t dims[4] = {h, w, pitch, n_centerline};
         const float geo[3] = {resolution, origin_x, origin_y};
@@ -618,6 +670,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         key = fnv1a(key, drivable_words, nwords * 4);
         key = fnv1a(key, progress, (size_t)h * w * 4);
         key = fnv1a(key, centerline, (size_t)n_centerline * 16);
+        sum2 = wordsum(wordsum(wordsum(wordsum(0, occ_words, nwords * 4), drivable_words, nwords * 4), progress, (size_t)h * w * 4),
+                       centerline, (size_t)n_centerline * 16);
     }
     std::lock_guard<std::mutex> track_lock(g_track_mutex);
     auto finish_load = [&](const std::shared_ptr<TrackTables> &tt) {
@@ -641,15 +695,20 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     if (!fits_patch && env->params.render_patch)
         return fail(RC_ERR_INVALID, "track bitmap %zu B (+ %d B of staging) does not fit the 160 KiB LDS (needed for obs_type lidar_occupancy)",
                     align_up(nwords * 4 + 4, 64), RC_PATCH_STAGE_BYTES);
+    for (auto it = g_track_cache.begin(); it != g_track_cache.end();)       // entries whose tables are gone
+        it = it->second.expired() ? g_track_cache.erase(it) : std::next(it);
     {
         auto it = g_track_cache.find({env->cfg.device, key});
         if (it != g_track_cache.end()) {
-            if (std::shared_ptr<TrackTables> tt = it->second.lock()) {
+            std::shared_ptr<TrackTables> tt = it->second.lock();
+            const bool same = tt && tt->h == h && tt->w == w && tt->pitch == pitch && tt->n_centerline == n_centerline &&
+                              tt->res == resolution && tt->ox == origin_x && tt->oy == origin_y && tt->sum2 == sum2;
+            if (same) {
                 HIP_TRY(hipStreamSynchronize(env->stream));       // nothing of this handle still reads its old track
                 finish_load(tt);
                 return RC_OK;
             }
-            g_track_cache.erase(it);
+            // (a different track under the same 64-bit key: build its tables; the map keeps the newer one)
         }
     }
     const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_kernel)
@@ -754,9 +813,16 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     const size_t spawn_bytes = align_up((size_t)n_centerline * 32, 64);
     const size_t total = 2 * bm_bytes + prog_bytes + cl_bytes + spawn_bytes + beam_bytes + foot_bytes + blk_bytes + packed_bytes + cell_bytes + 4 * quad_plane_bytes + first_bytes;
     HIP_TRY(hipStreamSynchronize(env->stream));
+    // from here on the handle has NO track until the new one is complete: a failure below (allocation, upload, validation)
+    // must not leave it launching on the tables it has just given up
+    env->has_track = false;
+    env->was_reset = false;
+    env->params.trk = RcTrackDev{};
     env->track.reset();                                    // (frees the old tables if no other handle shares them)
     std::shared_ptr<TrackTables> tt = std::make_shared<TrackTables>();
     tt->device = env->cfg.device;
+    tt->h = h; tt->w = w; tt->pitch = pitch; tt->n_centerline = n_centerline;
+    tt->res = resolution; tt->ox = origin_x; tt->oy = origin_y; tt->sum2 = sum2;
     HIP_TRY(hipMalloc(&tt->mem, total));
     char *m = (char *)tt->mem;
     RcTrackDev &t = tt->t;
@@ -800,6 +866,14 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     HIP_TRY(rck_build_first_table(t, (uint16_t *)t.first_rect, env->stream));
     HIP_TRY(rck_build_spawn_table(t, (float4 *)t.spawn, env->stream));
     HIP_TRY(hipStreamSynchronize(env->stream));
+    {   // the new tables under the bounded scan, from every cell a sensor can stand in: a table that sends a ray in circles
+        // fails HERE, with a message, and not as a hung wave in the unbounded production loop
+        unsigned long long n_scans = 0;
+        unsigned n_overruns = 0;
+        HIP_TRY(rck_validate_tables(t, std::ldexp((float)(std::max(w, h) + 2), -21), env->stream, &n_scans, &n_overruns));
+        if (n_overruns != 0)
+            return fail(RC_ERR_INVALID, "track tables failed validation: %u of %llu validation scans used up their trip budget", n_overruns, n_scans);
+    }
     g_track_cache[{env->cfg.device, key}] = tt;
     finish_load(tt);
     return RC_OK;
@@ -1053,6 +1127,16 @@ int rc_comm_init(rc_env *env, const void *unique_id, size_t bytes, int32_t rank,
     return RC_OK;
 }
 
+int rc_comm_count(rc_env *env, int32_t *ranks) {
+    if (!env || !ranks) return fail(RC_ERR_INVALID, "NULL argument");
+    if (!env->comm) return fail(RC_ERR_INVALID, "rc_comm_init has not been called on this handle");
+    if (!g_rccl.CommCount) return fail(RC_ERR_COMM, "the RCCL library lacks ncclCommCount");
+    int n = 0;
+    NCCL_TRY(g_rccl.CommCount(env->comm, &n));
+    *ranks = n;
+    return RC_OK;
+}
+
 size_t rc_gather_bytes(rc_env *env, int32_t mode) {
     if (!env) return 0;
     switch (mode) {
@@ -1096,6 +1180,162 @@ int rc_gather_wait(rc_env *env, int32_t host_sync) {
     return RC_OK;
 }
 
+// ---- peer-copy all-gather ------------------------------------------------------------------------------------------
+static void p2p_free(rc_env *env) {
+    P2p *x = env->p2p;
+    if (!x) return;
+    (void)hipSetDevice(env->cfg.device);
+    for (hipStream_t st : x->push) if (st) { (void)hipStreamSynchronize(st); }
+    if (x->ctrl) (void)hipStreamSynchronize(x->ctrl);
+    for (char *d : x->peer_dst) if (d) (void)hipIpcCloseMemHandle(d);
+    for (uint32_t *f : x->peer_flags) if (f) (void)hipIpcCloseMemHandle(f);
+    for (hipStream_t st : x->push) if (st) (void)hipStreamDestroy(st);
+    if (x->ctrl) (void)hipStreamDestroy(x->ctrl);
+    for (hipEvent_t e : {x->ev_ready, x->ev_go, x->ev_arrived, x->ev_local}) if (e) (void)hipEventDestroy(e);
+    if (x->dst) (void)hipFree(x->dst);
+    if (x->flags) (void)hipFree(x->flags);
+    delete x;
+    env->p2p = nullptr;
+}
+
+int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *export_out, size_t bytes) {
+    if (!env || !export_out) return fail(RC_ERR_INVALID, "NULL argument");
+    if (bytes < RC_P2P_EXPORT_BYTES) return fail(RC_ERR_INVALID, "export buffer must hold %d bytes", RC_P2P_EXPORT_BYTES);
+    if (world < 1 || world > RC_P2P_MAX_RANKS || rank < 0 || rank >= world)
+        return fail(RC_ERR_INVALID, "rank %d outside world of %d (at most %d ranks)", rank, world, RC_P2P_MAX_RANKS);
+    if (env->p2p) return fail(RC_ERR_INVALID, "the handle already has a peer-copy gather: rc_p2p_teardown first");
+    const size_t n = rc_gather_bytes(env, mode);
+    if (n == 0) return fail(RC_ERR_INVALID, "unknown gather mode %d", mode);
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    P2p *x = new (std::nothrow) P2p();
+    if (!x) return fail(RC_ERR_NOMEM, "out of host memory");
+    env->p2p = x;
+    x->rank = rank; x->world = world; x->mode = mode; x->bytes = n;
+    x->peer_dst.assign(world, nullptr);
+    x->peer_flags.assign(world, nullptr);
+    x->push.assign(world, nullptr);
+#define P2P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { p2p_free(env); return fail(RC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
+    P2P_TRY(hipMalloc((void **)&x->dst, 2 * (size_t)world * n));
+    // the flags are written by other GPUs' kernels and polled by this one's: uncached memory, so that a poll sees them
+    P2P_TRY(hipExtMallocWithFlags((void **)&x->flags, 4096, hipDeviceMallocUncached));
+    P2P_TRY(hipMemset(x->flags, 0, 4096));
+    for (int p = 0; p < world; ++p) P2P_TRY(hipStreamCreateWithFlags(&x->push[p], hipStreamNonBlocking));
+    P2P_TRY(hipStreamCreateWithFlags(&x->ctrl, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&x->ev_ready, &x->ev_go, &x->ev_arrived, &x->ev_local}) P2P_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    P2pExport ex;
+    std::memset(&ex, 0, sizeof(ex));
+    P2P_TRY(hipIpcGetMemHandle(&ex.dst, x->dst));
+    P2P_TRY(hipIpcGetMemHandle(&ex.flags, x->flags));
+    ex.bytes = n; ex.rank = rank; ex.world = world; ex.mode = mode; ex.pid = (int32_t)getpid();
+    P2P_TRY(hipDeviceGetPCIBusId(ex.pci, sizeof(ex.pci), env->cfg.device));
+    std::memcpy(export_out, &ex, sizeof(ex));
+    return RC_OK;
+}
+
+int rc_p2p_connect(rc_env *env, const void *exports, size_t bytes) {
+    if (!env || !exports) return fail(RC_ERR_INVALID, "NULL argument");
+    P2p *x = env->p2p;
+    if (!x) return fail(RC_ERR_INVALID, "rc_p2p_setup has not been called on this handle");
+    if (x->connected) return fail(RC_ERR_INVALID, "already connected");
+    if (bytes < (size_t)x->world * RC_P2P_EXPORT_BYTES) return fail(RC_ERR_INVALID, "need %d export blobs of %d bytes", x->world, RC_P2P_EXPORT_BYTES);
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    for (int p = 0; p < x->world; ++p) {
+        P2pExport ex;
+        std::memcpy(&ex, (const char *)exports + (size_t)p * RC_P2P_EXPORT_BYTES, sizeof(ex));
+        if (ex.rank != p || ex.world != x->world || ex.mode != x->mode || ex.bytes != x->bytes)
+            return fail(RC_ERR_INVALID, "export blob %d does not match (rank %d, world %d, mode %d, %llu bytes)", p, ex.rank, ex.world, ex.mode,
+                        (unsigned long long)ex.bytes);
+        if (p == x->rank) continue;
+        // a peer on another GPU: let this device's copy engines and kernels reach its memory
+        int pdev = -1;
+        if (hipDeviceGetByPCIBusId(&pdev, ex.pci) == hipSuccess && pdev >= 0 && pdev != env->cfg.device) {
+            hipError_t pe = hipDeviceEnablePeerAccess(pdev, 0);
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                return fail(RC_ERR_HIP, "hipDeviceEnablePeerAccess(%d) failed: %s", pdev, hipGetErrorString(pe));
+            (void)hipGetLastError();
+        }
+        HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_dst[p], ex.dst, hipIpcMemLazyEnablePeerAccess));
+        HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_flags[p], ex.flags, hipIpcMemLazyEnablePeerAccess));
+    }
+    x->connected = true;
+    return RC_OK;
+}
+
+int rc_gather_trajectory_p2p(rc_env *env) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    P2p *x = env->p2p;
+    if (!x || !x->connected) return fail(RC_ERR_INVALID, "rc_p2p_setup / rc_p2p_connect have not been called on this handle");
+    const void *src;
+    size_t n;
+    int rc = gather_source(env, x->mode, &src, &n);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    const uint32_t k = x->issued, seq = k + 1u;
+    const size_t slot_off = (size_t)(k & 1u) * x->world * n, mine = slot_off + (size_t)x->rank * n;
+    // everything below is ordered behind what the env's stream holds now: the step that produced the record, and the
+    // caller's use of the slot that gather k overwrites (the buffer of gather k - 2)
+    HIP_TRY(hipEventRecord(x->ev_ready, env->stream));
+    HIP_TRY(hipStreamWaitEvent(x->ctrl, x->ev_ready, 0));
+    // 1. tell every peer that its gather k may be written into my slot k & 1 ...
+    RcP2pPost post;
+    std::memset(&post, 0, sizeof(post));
+    post.n = x->world; post.value = seq;
+    for (int p = 0; p < x->world; ++p) post.flag[p] = p == x->rank ? nullptr : x->peer_flags[p] + RC_P2P_MAX_RANKS + x->rank;
+    HIP_TRY(rck_p2p_post(post, x->ctrl));
+    // 2. ... and wait until every peer has said the same to me (posting comes first on every rank: no cycle)
+    HIP_TRY(rck_p2p_wait(x->released(), x->world, x->rank, seq, x->timeouts(), RC_P2P_TIMEOUT_S, x->ctrl));
+    HIP_TRY(hipEventRecord(x->ev_go, x->ctrl));
+    // 3. my record into every peer's slot, one stream (one link) per peer, each followed by its arrival flag
+    for (int p = 0; p < x->world; ++p) {
+        hipStream_t st = x->push[p];
+        if (p == x->rank) {
+            HIP_TRY(hipStreamWaitEvent(st, x->ev_ready, 0));
+            HIP_TRY(hipMemcpyAsync(x->dst + mine, src, n, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipEventRecord(x->ev_local, st));
+            continue;
+        }
+        HIP_TRY(hipStreamWaitEvent(st, x->ev_go, 0));
+        HIP_TRY(hipMemcpyAsync(x->peer_dst[p] + mine, src, n, hipMemcpyDefault, st));
+        RcP2pPost arrived;
+        std::memset(&arrived, 0, sizeof(arrived));
+        arrived.n = 1; arrived.value = seq;
+        arrived.flag[0] = x->peer_flags[p] + x->rank;
+        HIP_TRY(rck_p2p_post(arrived, st));
+    }
+    // 4. arrival of every peer's shard in my slot: polled on the control stream, behind the release handshake
+    HIP_TRY(rck_p2p_wait(x->arrived(), x->world, x->rank, seq, x->timeouts(), RC_P2P_TIMEOUT_S, x->ctrl));
+    HIP_TRY(hipStreamWaitEvent(x->ctrl, x->ev_local, 0));
+    HIP_TRY(hipEventRecord(x->ev_arrived, x->ctrl));
+    x->issued = seq;
+    return RC_OK;
+}
+
+int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size_t *gathered_bytes) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    P2p *x = env->p2p;
+    if (!x || !x->connected) return fail(RC_ERR_INVALID, "rc_p2p_setup / rc_p2p_connect have not been called on this handle");
+    if (x->issued == 0) return fail(RC_ERR_INVALID, "no gather has been issued");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(hipStreamWaitEvent(env->stream, x->ev_arrived, 0));       // later work on the env's stream sees the gathered bytes
+    if (host_sync) {
+        HIP_TRY(hipEventSynchronize(x->ev_arrived));
+        // my record has left when my copies are done (the peers' arrival flags follow them on the same streams)
+        for (int p = 0; p < x->world; ++p) HIP_TRY(hipStreamSynchronize(x->push[p]));
+        uint32_t late = 0;
+        HIP_TRY(hipMemcpy(&late, x->timeouts(), sizeof(late), hipMemcpyDeviceToHost));
+        if (late != 0) return fail(RC_ERR_COMM, "peer-copy gather: %u flag wait(s) timed out after %.0f s (a peer did not post)", late, (double)RC_P2P_TIMEOUT_S);
+    }
+    if (gathered_dev) *gathered_dev = x->dst + (size_t)((x->issued - 1u) & 1u) * x->world * x->bytes;
+    if (gathered_bytes) *gathered_bytes = (size_t)x->world * x->bytes;
+    return RC_OK;
+}
+
+int rc_p2p_teardown(rc_env *env) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    p2p_free(env);
+    return RC_OK;
+}
+
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (knob < 0 || knob >= RC_DBG_COUNT) return fail(RC_ERR_INVALID, "unknown debug knob %d", knob);
@@ -1107,11 +1347,33 @@ int rc_debug_set(rc_env *env, int32_t knob, int32_t value) {
     return RC_OK;
 }
 
+int rc_scan_overruns(rc_env *env, uint64_t *count) {
+    if (!env || !count) return fail(RC_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    uint32_t v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, env->params.scan_overrun, sizeof(v), hipMemcpyDeviceToHost, env->stream));
+    HIP_TRY(hipStreamSynchronize(env->stream));
+    *count = v;
+    return RC_OK;
+}
+
 int rc_debug_scan_stamps(rc_env *env, uint64_t *stamps, int32_t n_waves) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (stamps != nullptr && n_waves <= 0) return fail(RC_ERR_INVALID, "n_waves must be positive");
     env->launch.scan_stamps = reinterpret_cast<unsigned long long *>(stamps);
     env->launch.scan_stamp_waves = stamps ? n_waves : 0;
+    return RC_OK;
+}
+
+int rc_scan_kernel_name(rc_env *env, char *out, size_t bytes) {
+    if (!env || !out || bytes == 0) return fail(RC_ERR_INVALID, "NULL argument");
+    if (!env->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called first");
+    const RcLaunchInfo &li = env->launch;
+    const int a = env->cfg.cars_per_env;
+    if (li.raycast_variant != 7) snprintf(out, bytes, "rc_raycast_kernel<%d, %d>", a, li.raycast_variant);
+    else if (li.scan_stamps != nullptr && a == 1) snprintf(out, bytes, "rc_raycast_car_stamps_kernel");
+    else if (li.scan_guarded) snprintf(out, bytes, "rc_raycast_car_kernel<%d, false, true>", a);
+    else snprintf(out, bytes, "rc_raycast_car_kernel<%d, %s, false>", a, li.car_split > 1 ? "true" : "false");
     return RC_OK;
 }
 

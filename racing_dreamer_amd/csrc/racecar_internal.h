@@ -81,6 +81,7 @@ struct RcParams {
     uint32_t seed_lo, seed_hi;
     int32_t car_task[4];         // task per car slot (resolved: never -1)
     int32_t n_steps;             // window of RC_TASK_N_STEP_PROGRESS [sub-steps]
+    uint32_t *scan_overrun;      // device counter: waves of the BOUNDED scan build that used up a round's trip budget
 };
 
 struct RcLaunchInfo {            // per-handle launch geometry decided at rc_load_track
@@ -88,7 +89,7 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t ray_blocks, ray_threads;
     int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one wave per workgroup
     int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
-    int32_t scan_guarded;        // 1: the scan's trip loop carries its trip-count guard (set while the validation band is in force)
+    int32_t scan_guarded;        // 1: the scan runs the build whose trip loop is bounded (validation band, RC_DBG_SCAN_BOUNDED)
     int32_t patch_blocks, patch_threads;
     unsigned long long *scan_stamps;   // rc_debug_scan_stamps: device buffer of the instrumented scan, else null
     int32_t scan_stamp_waves;
@@ -103,11 +104,22 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
                                  // (identical results)
 };
 
+#define RC_P2P_MAX_RANKS 64
+#define RC_P2P_TIMEOUT_S 20.0                   // bound of a flag poll (a peer that never posts: an error, not a hung queue)
+struct RcP2pPost {               // one store per lane: flag[p] = value (null entries skipped)
+    uint32_t *flag[RC_P2P_MAX_RANKS];
+    uint32_t value;
+    int32_t n;
+};
+hipError_t rck_p2p_post(const RcP2pPost &post, hipStream_t s);
+hipError_t rck_p2p_wait(const uint32_t *flags, int n, int skip, uint32_t value, uint32_t *timeouts, double limit_s, hipStream_t s);
+
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
 void rck_set_launch_events(hipEvent_t start, hipEvent_t stop);   // attach start / stop timestamps to the NEXT launch of this thread
 hipError_t rck_set_lds_limits(size_t lds_bytes);
 hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch, quad_plane_bytes
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch
+hipError_t rck_validate_tables(const RcTrackDev &t, float band, hipStream_t s, unsigned long long *n_scans, unsigned *n_overruns);   // bounded scan from every free cell
 hipError_t rck_build_spawn_table(const RcTrackDev &t, float4 *spawn_dev, hipStream_t s);   // needs centerline, progress, geometry
 struct RcRandomActions { int32_t on; uint32_t seed_lo, seed_hi, step; };   // on != 0: draw the actions in the dynamics kernel
 hipError_t rck_launch_dynamics(const RcParams &p, float *actions, int repeat, const RcRandomActions &ra, hipStream_t s);

@@ -1125,16 +1125,17 @@ __device__ __forceinline__ uint32_t exact_other_cell_m(uint32_t est_T, uint32_t 
 // when !in_grid), direction (dx, dy) (finite, never -0.0), its reciprocals and sign masks nx, ny (-1 for a negative
 // component, 0 otherwise).  21 full-rate and 9 half-rate vector instructions per trip.
 struct NothingBetween { __device__ __forceinline__ void operator()() const {} };
-// GUARD: the trip loop also counts its trips.  It does not need to: with the shipped band a trip puts the ray into the
-// cell behind the exit boundary (exactly, see above), at least one cell further along the exit axis, and never back on
-// the other one, so after at most w + h trips the ray stands in a stop cell - the grid is ringed by them.  The counter
-// (four scalar instructions per trip merged into the loop's lane mask: 2.2 % of the scan) is therefore compiled only
-// into the builds that run when that proof does not hold: the per-ray variant 6 and any run with a validation band.
+// GUARD: the bounded form of the trip loop (a wave-level trip budget, see the loop).  The loop does not need one: with the
+// shipped band a trip puts the ray into the cell behind the exit boundary (exactly, see above), at least one cell further
+// along the exit axis, and never back on the other one, so after at most w + h trips the ray stands in a stop cell - the
+// grid is ringed by them.  The bound costs 4 % of the scan, so it is compiled into the builds that run when that proof
+// does not cover the run: the validation scan of rc_load_track, any run with a validation band or RC_DBG_SCAN_BOUNDED,
+// and the per-ray variant 6.
 template <bool FROM_PLANE, class Between = NothingBetween, bool GUARD = true>
 __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackDev &t, const TravConst &k, float gx, float gy,
                                               float dx, float dy, float idx, float idy, int nx, int ny, int ix, int iy,
                                               unsigned v, bool in_grid, int *wave_trips = nullptr, int *wave_exact = nullptr,
-                                              Between between = Between()) {
+                                              Between between = Between(), int *overrun = nullptr) {
     const int pitch2 = t.cell_pitch * 2;
     const char *qb = reinterpret_cast<const char *>(qr);
     // mirrored origin, the origin of the position estimate, the start cell (i~ = ~i on a mirrored axis) and the part of
@@ -1212,8 +1213,30 @@ __device__ __forceinline__ float ray_traverse(const uint16_t *qr, const RcTrackD
         return 0.0f;                                                      // the sensor sits in a stop cell
     }
     if (GUARD) {
-        // (the counter only bounds a logic error or a mis-set band: the ray then reads "no return")
-        for (int guard = 4096; (v & 255u) != 0 && guard != 0; --guard) { trip_head(); trip_tail(); }
+        // THE BOUNDED FORM of the loop: a wave-level trip budget of w + h + 2, counted on the scalar unit behind the trip's
+        // table request.  A lane goes on while the width byte of its entry exceeds `kz`, which is 0 - "not a stop cell" -
+        // until the budget is used up and 255 from then on: every lane then counts as stopped, and the unfinished ones
+        // read "no return" (their entry is not 0).  With the shipped band the budget is never used up (every trip moves
+        // every unfinished ray at least one cell along its exit axis, see above); a corrupted table line or a mis-set band
+        // ends in "no return" and a count in RcParams::scan_overrun instead of a hung wave.
+        // Cost, A/B on one box (profiles/r03_a_ab_trip_bound.txt): 0.1789 -> 0.1864 ms at 65 536 cars (+ 4.2 %; nothing at
+        // 4 096) for its three instructions per trip - the "shadow" of the request is already full of the band test - against
+        // + 2.2 % for the per-lane counter of round 2; a per-pair count in a loop body of two trips and a scalar threshold
+        // operand of the compare (`inverse_ballot`) both made the compiler's loop control longer than what they saved.
+        // So the bound is not in the production loop: it runs (a) over every spawn pose of a track when its tables are
+        // built (rc_load_track fails if any ray overruns), (b) whenever a validation band is set, (c) on request
+        // (RC_DBG_SCAN_BOUNDED), and always in the per-ray variant 6.
+        int budget = t.w + t.h + 2;
+        uint32_t kz = 0u;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(kz));
+        while ((v & 255u) > kz) {
+            trip_head();
+            int lim;
+            asm volatile("s_sub_u32 %0, %0, 1\n\ts_cselect_b32 %1, 255, 0" : "+s"(budget), "=s"(lim) : : "scc");
+            asm volatile("v_mov_b32 %0, %1" : "=v"(kz) : "s"(lim));
+            trip_tail();
+        }
+        if (overrun != nullptr && budget < 0) *overrun = 1;               // (wave-uniform)
     } else {
         while ((v & 255u) != 0) { trip_head(); trip_tail(); }
     }
@@ -1343,6 +1366,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         if (STAMPS && stamps != nullptr && lane == 0) stamps[slot] = value;
     };
     int wave_trips = 0, wave_exact = 0, round_index = 0, trips_before = 0, total_trips = 0;
+    int overrun = 0;                                                      // bounded build: a round used up its trip budget
     // phases of a round, summed over the wave's rounds in scalar registers (no stores in between): 27 wait for the
     // previous round's loads, 28 prepare the next round, 29 traversal, 3 inter-car returns and transform, 4 LDS store,
     // 30 round loop control
@@ -1442,13 +1466,13 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         float rng;
         if (OVERLAP) {
             rng = ray_traverse<false, decltype(prepare_next), GUARD>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
-                                      STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr, prepare_next);
+                                      STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr, prepare_next, GUARD ? &overrun : nullptr);
         } else {
             prepare_next();
             if (STAMPS) asm volatile("" :: "v"(nxt.idx), "v"(nxt.idy));
             phase(t_prep);
             rng = ray_traverse<false, NothingBetween, GUARD>(t.quad_rect, t, k, gx, gy, cur.dx, cur.dy, cur.idx, cur.idy, cur.nx, cur.ny, ixv, iyv, cur.v, true,
-                                      STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr);
+                                      STAMPS ? &wave_trips : nullptr, STAMPS ? &wave_exact : nullptr, NothingBetween(), GUARD ? &overrun : nullptr);
         }
         if (STAMPS) asm volatile("" :: "v"(rng));
         phase(t_trav);
@@ -1495,11 +1519,13 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         if (round + split >= kRounds) break;
         if (!stage(round + split, rb, ra)) break;
     }
+    if (GUARD && overrun != 0 && p.scan_overrun != nullptr && lane == 0) atomicAdd(p.scan_overrun, 1u);
     // Flush the wave's ranges from LDS to the output row.  A store per round costs more than its 256 bytes: loads and
     // stores share one in-order counter on gfx9, so the first table load of the NEXT round also waited for the
     // store's acknowledgement from L2 (the scan ran 11 % faster with the stores removed).  Staged in LDS (its own
     // counter), the 17 rows go out back to back at the end and nothing waits for them.
     stamp(20);
+    if (GUARD && p.out.lidar == nullptr) return;                          // the validation scan of rc_load_track keeps no ranges
     char *out_bytes = reinterpret_cast<char *>(out);
     // Optional second copy of the row as uint16 (rc_set_compact_slab: the half-size record of the multi-GPU gather):
     // q = rne((value + q_off) * q_scale), 0 .. 65535 over the row's value range - taken from the same LDS row, so it
@@ -1758,6 +1784,188 @@ __global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_it
     }
 }
 
+// ---- lidar_occupancy, ONE WAVE PER CAR (default since round 3; rc_patch_kernel above is the round-2 form, kept behind
+// patch_variant bit 3 for A/B runs) ------------------------------------------------------------------------------
+// Same taps, same results; what changed is who renders what.  The round-2 kernel gave a car to four waves of 64 runs
+// (16 pixels each): every wave paid the per-car setup - three dependent global round trips for pose, flag and heading,
+// four 32-bit multiplies, the window tests: a third of its instructions - and the wave that held the four corner blocks
+// ran the tested loop (14 instructions per pixel instead of 7) for ALL of its 64 runs, while its 16-byte pieces of the
+// first and last 16 rows reached HBM as partial lines (1.27 x the algorithmic bytes).  Here a wave renders a whole car:
+// * the car is wave-uniform, so pose and heading arrive in ONE scalar 16-byte load (the packed copy the scan uses) next
+//   to the flag word, and the setup is paid once per 4 096 pixels;
+// * a lane renders four runs, one per 16-row group g, and a store instruction writes group g of every lane: lanes
+//   4 i .. 4 i + 3 hold the four pieces of row 16 g + i, so every store covers whole 64-byte lines (16 rows = 1 KB of
+//   consecutive bytes) - no line is split between waves or between instructions;
+// * only the 64 runs in the corner blocks (rows 0-15 and 48-63, columns 0-15 and 48-63) can be cut by the reference's
+//   220-cell crop window (they lie within 15.8 pixels of two patch edges whatever the heading).  In group 0 they are
+//   the lanes with l & 3 in {0, 3}; group 3 stores its pieces in the order 1, 0, 3, 2 (column block (l & 3) ^ 1: still
+//   whole lines per instruction), so there they are the lanes with l & 3 in {1, 2}: EVERY lane owns exactly one corner
+//   run.  Each lane renders its corner run in one slot (the tested loop, taken only if some run of the wave is in fact
+//   cut) and its three other runs with the test-free loop; two selects per word put the results back in group order.
+//   4 096 pixels of a cut car cost 16 (13 + 3 x 7) instructions per lane instead of 16 (14 + 3 x 7) per lane of FOUR
+//   waves of which one ran 64 tested runs: 8.5 against 8.75 per pixel, plus the setup once instead of four times.
+// The non-corner slots keep the end-tap test of the round-2 kernel as a safety net (a wave-uniform branch to a rolled
+// per-tap loop that is never taken if the 15.8-pixel bound holds).
+template <bool CLAMP>
+__device__ __forceinline__ void patch_run_tested(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
+                                                 uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t wx, uint32_t wy,
+                                                 uint32_t span_fix, uint32_t zero_addr, uint32_t (&words)[4]) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        // inside the window <=> both window-relative coordinates (unsigned: below the window = huge) are <= 220 cells - 1 ulp
+        const uint32_t far = max((uint32_t)X - wx, (uint32_t)Y - wy);
+        const unsigned long long ok = cmp_le_u32(far, span_fix);
+        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, xmax) : (uint32_t)X;
+        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, ymax) : (uint32_t)Y;
+        const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19);
+        const uint32_t byte = lds[select_mask(ok, addr, zero_addr)];
+        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, 16, 3), 1);
+        words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
+        X += a;
+        Y += b;
+    }
+}
+
+// the rolled form of the same (the safety net of the non-corner slots: code size, not speed)
+__device__ __forceinline__ void patch_run_rolled(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
+                                                 uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t wx, uint32_t wy,
+                                                 uint32_t span_fix, uint32_t zero_addr, uint32_t (&words)[4]) {
+#pragma unroll 1
+    for (int w4 = 0; w4 < 4; ++w4) {
+        uint32_t acc = 0u;
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const bool ok = max((uint32_t)X - wx, (uint32_t)Y - wy) <= span_fix;
+            const uint32_t xc = min((uint32_t)X, xmax), yc = min((uint32_t)Y, ymax);
+            const uint32_t addr = (yc >> 16) * pitch_b + (xc >> 19);
+            const uint32_t byte = lds[ok ? addr : zero_addr];
+            acc |= ((byte >> ((xc >> 16) & 7u)) & 1u) << (8 * k);
+            X += a;
+            Y += b;
+        }
+        words[w4] = acc;
+    }
+}
+
+template <bool CLAMP, bool NT>
+__device__ __forceinline__ void patch_car(const RcParams &p, const unsigned car, const unsigned lane, const int icx, const int icy,
+                                          const int a, const int b) {
+    const RcTrackDev &t = p.trk;
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
+    const lds_u8_ptr lds_bytes = (lds_u8_ptr)(uint32_t)0;                // the bitmap starts at LDS address 0 (rck_set_lds_limits)
+    const uint32_t pitch_b = (uint32_t)t.pitch * 4u;
+    const uint32_t xmax = ((uint32_t)(t.w - 1) << 16) | 0xffffu, ymax = ((uint32_t)(t.h - 1) << 16) | 0xffffu;
+    const uint32_t zero_addr = (uint32_t)(t.h * t.pitch) * 4u;          // the all-zero word behind the bitmap
+    // the reference's [-110, 110) crop window around the start cell, in 16.16
+    const uint32_t wx = (uint32_t)(icx - RCS_PATCH_WINDOW_I) << 16, wy = (uint32_t)(icy - RCS_PATCH_WINDOW_I) << 16;
+    const uint32_t span_fix = ((uint32_t)(2 * RCS_PATCH_WINDOW_I) << 16) - 1u;
+    const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;
+    const int rl = (int)(lane >> 2), cb = (int)(lane & 3u);
+    const bool corner_first = cb == 0 || cb == 3;          // this lane's corner run is in group 0 (else in group 3)
+    // start taps of a run: (row, first column c0)
+    auto start = [&](int row, int c0, int &X, int &Y) {
+        X = mad_i24(c0, a, mad_i24(row, b, x00));
+        Y = mad_i24(c0, b, mad_i24(-row, a, y00));
+    };
+    auto ends_inside = [&](int X, int Y) {
+        const uint32_t f0 = max((uint32_t)X - wx, (uint32_t)Y - wy);
+        const uint32_t f1 = max((uint32_t)(X + 15 * a) - wx, (uint32_t)(Y + 15 * b) - wy);
+        return max(f0, f1) <= span_fix;
+    };
+    // piece (row, column block) of the car's 4 KB lies at 16-byte index 4 row + block: groups 0 - 2 at 64 g + lane, group 3
+    // (pieces in the order 1, 0, 3, 2) at 192 + (lane ^ 1)
+    v4u_t *out = reinterpret_cast<v4u_t *>(p.out.patch) + (size_t)car * 256u;
+    auto store = [&](int g, const uint32_t (&w)[4]) {
+        const v4u_t px = {w[0], w[1], w[2], w[3]};
+        v4u_t *dst = out + 64 * g + (g == 3 ? (lane ^ 1u) : lane);
+        if (NT) __builtin_nontemporal_store(px, dst);
+        else *dst = px;
+    };
+    // slot A: the corner run - group 0 piece cb for the lanes with cb in {0, 3}, group 3 piece cb ^ 1 for the others
+    uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+    {
+        int X, Y;
+        start(corner_first ? rl : 48 + rl, corner_first ? 16 * cb : 16 * (cb ^ 1), X, Y);
+        // the end taps of every corner run inside the window, which is convex: so is every tap of the wave
+        if (__builtin_amdgcn_ballot_w64(!ends_inside(X, Y)) == 0) patch_run<CLAMP>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, wa);
+        else patch_run_tested<CLAMP>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, wx, wy, span_fix, zero_addr, wa);
+    }
+    // slot B: the lane's piece of the OTHER outer group (columns 16 - 47: never cut); then groups 1 and 2
+#pragma unroll 1
+    for (int s = 0; s < 3; ++s) {
+        const int row = s == 0 ? (corner_first ? 48 + rl : rl) : 16 * s + rl;
+        const int c0 = (s == 0 && corner_first) ? 16 * (cb ^ 1) : 16 * cb;
+        int X, Y;
+        start(row, c0, X, Y);
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (__builtin_amdgcn_ballot_w64(!ends_inside(X, Y)) == 0) patch_run<CLAMP>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, w);
+        else patch_run_rolled(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, wx, wy, span_fix, zero_addr, w);
+        if (s == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wb[i] = w[i];
+        } else {
+            store(s, w);
+        }
+    }
+    uint32_t g0[4], g3[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        g0[i] = corner_first ? wa[i] : wb[i];
+        g3[i] = corner_first ? wb[i] : wa[i];
+    }
+    store(0, g0);
+    store(3, g3);
+}
+
+template <bool NT>
+__global__ __launch_bounds__(1024) void rc_patch_car_kernel(RcParams p) {
+    extern __shared__ uint32_t lds_words[];
+    const RcTrackDev &t = p.trk;
+    stage_bitmap(lds_words, t.drv_words, t.h * t.pitch + 1);        // + the all-zero word behind the bitmap (rc_load_track)
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned waves = gridDim.x * (blockDim.x >> 6);
+    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+    // cars are dealt to the waves of the grid in turn (a wave's cars are `waves` apart: neighbouring waves write
+    // neighbouring patches).  The car is wave-uniform, so its state - x, y, cos, sin in one 16-byte load from the packed
+    // copy the scan uses, and the flag word - comes through the SCALAR unit: vector loads share one in-order counter with
+    // the stores, and every car would start by waiting for the previous car's 4 KB to be acknowledged.  (Inline assembly
+    // with its own wait: the compiler takes the loads for vector ones because the kernel also stores.)
+    for (unsigned car = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); car < (unsigned)p.n_cars;
+         car = __builtin_amdgcn_readfirstlane(car + waves)) {
+        typedef float v4f_t __attribute__((ext_vector_type(4)));
+        v4f_t sp;
+        uint32_t fresh_word;
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(sp), "=&s"(fresh_word) : "s"(p.st.scan_pose + car), "s"(reinterpret_cast<const uint32_t *>(p.st.fresh) + (car >> 2)) : "memory");
+        const uint32_t fresh = (fresh_word >> (8u * (car & 3u))) & 255u;
+        int icx, icy;
+        cell_of(t, sp.x, sp.y, icx, icy);
+        icx = __builtin_amdgcn_readfirstlane(icx);
+        icy = __builtin_amdgcn_readfirstlane(icy) + 1;
+        // a car tens of thousands of cells away from the grid (a diverged state) sees nothing; it also keeps X, Y in range
+        const bool sane = (unsigned)(icx + 16384) < 32768u && (unsigned)(icy + 16384) < 32768u;
+        if (fresh != 0u || !sane) {              // reset observation is all zeros, dreamer/wrappers.py:413
+            v4u_t *out = reinterpret_cast<v4u_t *>(p.out.patch) + (size_t)car * 256u + lane;
+            const v4u_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (NT) __builtin_nontemporal_store(z, out + 64 * g);
+                else out[64 * g] = z;
+            }
+            continue;
+        }
+        const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(sp.z * RCS_PATCH_STEP_Q16));
+        const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(sp.w * RCS_PATCH_STEP_Q16));
+        // window inside the grid (a property of the car)?  then no tap can leave the grid and nothing is clamped
+        const int lx = icx - RCS_PATCH_WINDOW_I, ly = icy - RCS_PATCH_WINDOW_I, span = 2 * RCS_PATCH_WINDOW_I - 1;
+        const bool inside = lx >= 0 && ly >= 0 && lx + span <= t.w - 1 && ly + span <= t.h - 1;
+        if (inside) patch_car<false, NT>(p, car, lane, icx, icy, a, b);
+        else patch_car<true, NT>(p, car, lane, icx, icy, a, b);
+    }
+}
+
 // Follow-the-gap on the device: one wave per car, lane l owns the 13 consecutive beams FTG_LO + 13 l ...
 // Wave-level steps use shuffles only: (value, index) arg-min for the closest return, and an ordered
 // tree reduction of run summaries (leading / trailing / best run of gap beams) for the widest gap.
@@ -1969,6 +2177,93 @@ hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, 
 }
 
 
+// Validation of a freshly built track's tables (rc_load_track): the BOUNDED build of the default scan from every cell a
+// sensor can stand in - the centre of every non-stop cell, two opposite headings, so that all 4 x 64 first-trip entries of
+// the cell and both signs of every direction are used - with no output kept.  A ray that uses up its trip budget (a table
+// entry that sends it in circles or off the grid's ring) is counted; the caller refuses the track if any did.
+__global__ __launch_bounds__(256) void rc_validation_poses_kernel(RcTrackDev t, float4 *__restrict__ poses, uint32_t *__restrict__ count) {
+    const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (unsigned)t.h * (unsigned)t.w) return;
+    const int ix = (int)(gid % (unsigned)t.w), iy = (int)(gid / (unsigned)t.w);
+    if (bit_at(t.ray_words, t.pitch, ix, iy)) return;                     // stop cell (wall or ring): no sensor scans from here
+    const float cx = t.org_x + ((float)ix + 0.5f) * t.res, cy = t.org_y + ((float)iy + 0.5f) * t.res;
+    float sn, cs;
+    sincos32(0.3f, sn, cs);
+    const unsigned k = atomicAdd(count, 2u);
+    poses[k] = make_float4(cx - RCS_LIDAR_X * cs, cy - RCS_LIDAR_X * sn, cs, sn);          // sensor at the cell's centre
+    poses[k + 1] = make_float4(cx + RCS_LIDAR_X * cs, cy + RCS_LIDAR_X * sn, -cs, -sn);
+}
+
+hipError_t rck_validate_tables(const RcTrackDev &t, float band, hipStream_t s, unsigned long long *n_scans, unsigned *n_overruns) {
+    const size_t cells = (size_t)t.h * t.w;
+    float4 *poses = nullptr;
+    uint32_t *counters = nullptr, host[2] = {0u, 0u};
+    hipError_t e = hipMalloc((void **)&poses, 2 * cells * sizeof(float4));
+    if (e == hipSuccess) e = hipMalloc((void **)&counters, 2 * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(counters, 0, 2 * sizeof(uint32_t), s);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rc_validation_poses_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, s, t, poses, counters);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host, counters, sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess && host[0] != 0u) {
+        RcParams p{};
+        p.trk = t;
+        p.trk.band = band; p.trk.band_mh = band - 0.5f; p.trk.band2 = 2.0f * band;
+        p.st.scan_pose = poses;
+        p.num_envs = p.n_cars = (int32_t)host[0];
+        p.cars_per_env = 1;
+        p.scan_overrun = counters + 1;
+        const int threads = 64;
+        hipLaunchKernelGGL((rc_raycast_car_kernel<1, false, true>), dim3(host[0]), dim3(threads), kCarLdsBytes, s, p, 1);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(host, counters, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    if (poses) (void)hipFree(poses);
+    if (counters) (void)hipFree(counters);
+    *n_scans = host[0];
+    *n_overruns = host[1];
+    return e;
+}
+
+// ---- flags of the peer-copy all-gather (rc_gather_trajectory_p2p): sequence numbers in uncached device memory that a
+// PEER's kernel writes (over xGMI) and the owner's kernel polls.  Both kernels are one wave; the poll is bounded (wall
+// clock) and reports a time-out instead of hanging the queue.
+__global__ __launch_bounds__(64) void rc_p2p_post_kernel(RcP2pPost post) {
+    // lane p stores `value` into flag p (a pointer into peer p's flag block, or null)
+    const unsigned l = threadIdx.x;
+    if (l < (unsigned)post.n && post.flag[l] != nullptr)
+        __hip_atomic_store(post.flag[l], post.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(64) void rc_p2p_wait_kernel(const uint32_t *flags, int n, int skip, uint32_t value, uint32_t *timeouts,
+                                                         unsigned long long limit_ticks) {
+    // lane p waits until flags[p] >= value (sequence numbers only grow); every lane leaves the loop at the deadline
+    const unsigned l = threadIdx.x;
+    const unsigned long long t0 = wall_clock64();
+    bool late = false;
+    if (l < (unsigned)n && (int)l != skip) {
+        while (__hip_atomic_load(flags + l, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < value) {
+            if (wall_clock64() - t0 > limit_ticks) { late = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (late) atomicAdd(timeouts, 1u);
+}
+
+hipError_t rck_p2p_post(const RcP2pPost &post, hipStream_t s) {
+    hipLaunchKernelGGL(rc_p2p_post_kernel, dim3(1), dim3(64), 0, s, post);
+    return hipGetLastError();
+}
+
+hipError_t rck_p2p_wait(const uint32_t *flags, int n, int skip, uint32_t value, uint32_t *timeouts, double limit_s, hipStream_t s) {
+    hipLaunchKernelGGL(rc_p2p_wait_kernel, dim3(1), dim3(64), 0, s, flags, n, skip, value, timeouts,
+                       (unsigned long long)(limit_s * 1.0e8));        // wall_clock64 counts at 100 MHz
+    return hipGetLastError();
+}
+
 hipError_t rck_set_lds_limits(size_t lds_bytes) {
     hipError_t e;
     const int b = (int)lds_bytes;
@@ -2002,11 +2297,13 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<3, 6>))
     SET((rc_raycast_kernel<4, 6>))
     SET(rc_patch_kernel)
+    SET(rc_patch_car_kernel<true>)
+    SET(rc_patch_car_kernel<false>)
 #undef SET
     // rc_patch_kernel and rc_raycast_car_kernel address their dynamic LDS from LDS address 0: true only while they have
     // no static LDS
     hipFuncAttributes fa;
-    for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel),
+    for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_patch_car_kernel<true>), reinterpret_cast<const void *>(rc_patch_car_kernel<false>), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<1, false, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, false, false>),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<3, false, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, false, false>),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<1, true, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, true, false>),
@@ -2074,7 +2371,16 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_PATCH * (RC_PATCH / 16);
-    launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes + RC_PATCH_STAGE_BYTES, s, p, total, li.patch_variant);
+    if (li.patch_variant & 8) {           // the round-2 kernel (four waves per car), kept for A/B runs
+        launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes + RC_PATCH_STAGE_BYTES, s, p, total, li.patch_variant);
+    } else {
+        // persistent 16-wave workgroups, the bitmap staged once per workgroup; as many as stay resident
+        const int per_cu = li.lds_bytes <= 80 * 1024 ? 2 : 1;
+        const long long need = ((long long)p.n_cars + 15) / 16, resident = (long long)li.n_cu * per_cu;
+        const int blocks = (int)(need < resident ? need : resident);
+        if (li.patch_variant & 2) launch(rc_patch_car_kernel<false>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);     // experiment: plain stores
+        else launch(rc_patch_car_kernel<true>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);
+    }
     return hipGetLastError();
 }
 

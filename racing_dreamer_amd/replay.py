@@ -86,6 +86,11 @@ class TrajectoryRing:
         self._advance()
         return self.env.step(actions, repeat=repeat)
 
+    def step_random(self, seed: int, step: int, repeat=None) -> Dict[str, torch.Tensor]:
+        """env.step_random() (actions drawn on the device) recorded as the next ring record."""
+        self._advance()
+        return self.env.step_random(seed, step, repeat=repeat)
+
     def latest(self) -> Dict[str, torch.Tensor]:
         return self.env.views
 

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "racecar_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(rc_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_every_declared_symbol_is_exported_and_bound(hip_lib):
@@ -99,3 +99,30 @@ def test_missing_library_fails_loudly(tmp_path):
         assert raised
     finally:
         _lib._lib = saved
+
+
+def test_build_refuses_a_scan_kernel_that_spills():
+    """The scan hands a register to an asynchronous load in inline assembly and waits for it in a later statement: a spill
+    of that register would store it before the load has landed.  The build parses the compiler's resource
+    remarks and refuses such a library."""
+    import pytest
+    from racing_dreamer_amd import build
+    head = "k.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_121rc_raycast_car_kernelILi1ELb0ELb0EEEv8RcParamsi [-Rpass-analysis=kernel-resource-usage]\n"
+    patch = ("k.hip:1:1: remark: Function Name: _ZN12_GLOBAL__N_119rc_patch_car_kernelILb1EEEv8RcParams [-Rpass-analysis=kernel-resource-usage]\n"
+             "k.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+             "k.hip:1:1: remark:     Occupancy [waves/SIMD]: 8 [-Rpass-analysis=kernel-resource-usage]\n")
+    ok = head + ("k.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+                 "k.hip:1:1: remark:     Occupancy [waves/SIMD]: 8 [-Rpass-analysis=kernel-resource-usage]\n"
+                 "k.hip:1:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n") + patch
+    build.check_resource_usage(ok)
+    with pytest.raises(RuntimeError, match="VGPRs Spill = 3"):
+        build.check_resource_usage(ok.replace("VGPRs Spill: 0", "VGPRs Spill: 3", 1))
+    with pytest.raises(RuntimeError, match="ScratchSize"):
+        build.check_resource_usage(ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 16"))
+    with pytest.raises(RuntimeError, match="7 waves/SIMD < 8"):
+        build.check_resource_usage(ok.replace("Occupancy [waves/SIMD]: 8", "Occupancy [waves/SIMD]: 7", 1))
+    with pytest.raises(RuntimeError, match="not found"):
+        build.check_resource_usage(patch)
+    other = ok + ("k.hip:9:1: remark: Function Name: _ZN12_GLOBAL__N_118rc_dynamics_kernelILi4EEEv8RcParamsPfijjj [-Rpass-analysis=kernel-resource-usage]\n"
+                  "k.hip:9:1: remark:     VGPRs Spill: 12 [-Rpass-analysis=kernel-resource-usage]\n")
+    build.check_resource_usage(other)           # kernels without such loads may spill

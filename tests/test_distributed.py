@@ -209,3 +209,19 @@ def test_sharded_replay_gathers_the_training_batch_not_the_records():
     assert owner.tolist() == a["rank"].tolist()
     r = a["reward"]
     assert np.all(r[:, 1:] - r[:, :-1] == 1.0)                      # windows are consecutive steps
+
+
+def test_bench_starts_its_own_ranks_and_reports_their_failure():
+    """`python bench.py --gpus 2` without a launcher: the process starts two ranks itself (before touching any GPU) and
+    exits with their code.  On this GPU-less box both ranks fail at the first HIP call - which is the point: the failure
+    of a rank reaches the caller as a non-zero exit, not as a hang or a silent success."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: tests/test_gpu_bench.py covers the successful run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--envs", "64", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode not in (0, 2), r.stderr[-1500:]          # (2 was round 2's "needs torch.distributed.run")
+    assert r.stderr.count("No HIP GPUs are available") >= 2 and "{" not in r.stdout

@@ -28,7 +28,7 @@ def _json_line(stdout):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--envs", "4096", "--track",
-                        "columbia", "--cpu-envs", "256"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "columbia", "--cpu-envs", "256", "--numpy-envs", "256"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
@@ -37,8 +37,16 @@ def test_bench_single_gpu_contract():
     rf = d["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["launches"] == 8
+    # the symbol rocprofv3 lists for the scan this run launched (4 096 cars: several waves per car, the overlapped build),
+    # and PMC figures only for the workload they were profiled on - this is not it
+    assert rf["kernel"] == "rc_raycast_car_kernel<1, true, false>" and rf["traffic"] is None and rf["traffic_source"] is None
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    # the threads the baseline ran on are the cores the process really has (cgroup quota / measured share), and the
+    # all-thread rate is a real multiple of the one-thread rate measured in the same leg
+    assert cb["cores"] == cb["cores_effective"] <= cb["cpu_share"]["sched_getaffinity"]
+    assert cb["speedup_all_over_one_thread"] >= 0.5 * cb["cores_effective"] or cb["cores_effective"] == 1
+    assert cb["numpy_batch"]["value"] > 0 and "256 envs" in cb["numpy_batch"]["sample"]
     # the other single-GPU configurations of BASELINE.json ride in the same line
     cfgs = d["configs"]
     assert [c["envs"] * c["cars_per_env"] for c in cfgs] == [4096, 65536, 65536]
@@ -48,6 +56,29 @@ def test_bench_single_gpu_contract():
         r = c["roofline"]
         assert c["ms_per_step"] > 0 and 0 < r["step_frac"] < 1 and 0 < r["raycast_frac"] < 1
         assert r["step_bytes"] == c["envs"] * c["cars_per_env"] * (4479 + (4096 if c["obs_type"] == "lidar_occupancy" else 0))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher around it (the way the driver starts the N = 1 line): the process
+    starts its two ranks itself, rank 0's single JSON line comes through, and the communicator's own rank count is in it."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
+                        "--envs", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["config"]["comm_ranks"] == 2
+    assert d["config"]["comm_backend"] == "gloo" and d["config"]["rccl_ranks"] is None      # (RCCL needs a GPU per rank)
+    assert set(d["gather_modes"]) == {"full-u16", "full", "summary", "none", "batch"}
+
+
+def test_bench_two_ranks_peer_copy_transport():
+    """The same two ranks with the gather as direct peer copies (hipIpc works between processes on one device)."""
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--gather-via", "p2p", "--steps", "6",
+                        "--warmup", "2", "--envs", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _json_line(r.stdout)
+    assert d["config"]["gather_via"] == "p2p" and "rc_gather_trajectory_p2p" in d["config"]["workload"]
+    gm = d["gather_modes"]
+    assert all(gm[m]["ms_per_step"] > 0 for m in ("full-u16", "full", "summary", "none", "batch"))
 
 
 def test_bench_two_ranks_functional():
@@ -61,7 +92,10 @@ def test_bench_two_ranks_functional():
     # the headline of an N > 1 run carries the whole record (uint16 LiDAR), and says so; the other payloads are timed beside it
     assert d["config"]["gather"] == "full-u16" and "full-u16" in d["config"]["workload"] and "cpu_baseline" not in d
     gm = d["gather_modes"]
-    assert set(gm) == {"full-u16", "full", "summary", "none"} and gm["full-u16"]["headline"] is True
+    assert set(gm) == {"full-u16", "full", "summary", "none", "batch"} and gm["full-u16"]["headline"] is True
+    # the pure-simulation leg really is that: nothing of the uint16 record is produced in it
+    assert "simulation alone" in gm["none"]["includes"] and "in place" in gm["full"]["includes"]
+    assert gm["batch"]["bytes_per_gpu_per_step"] == 25 * 50 * (1080 * 4 + 8 + 4 + 4)
     assert gm["full-u16"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 2236, rel=0.01)
     assert gm["full"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 4396, rel=0.01)
     assert gm["summary"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 76, rel=0.05)

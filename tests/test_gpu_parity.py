@@ -210,6 +210,37 @@ def test_default_raycast_dense_poses(track_name):
         got = got.cpu().numpy().reshape(n, 1080)
         bad = np.nonzero((got != want) | (np.signbit(got) != np.signbit(want)))     # -0.0 (zero-length first step) included
         assert bad[0].size == 0, (track_name, variant, bad[0][:5], bad[1][:5], got[bad][:5], want[bad][:5])
+    # ... and the BOUNDED build of the default scan (trip budget in the loop: what rc_load_track validated the tables
+    # with, what runs under a validation band): the same ranges, no budget used up
+    env.set_raycast_variant(7)
+    assert env.scan_kernel_name() == "rc_raycast_car_kernel<1, false, false>"
+    env.debug_set("scan_bounded", 1)
+    assert env.scan_kernel_name() == "rc_raycast_car_kernel<1, false, true>"
+    got = env.set_pose(poses)["lidar"].cpu().numpy().reshape(n, 1080)
+    assert np.array_equal(got, want) and env.scan_overruns() == 0
+    env.close()
+
+
+def test_a_mis_set_band_ends_in_no_return_not_in_a_hung_wave():
+    """The production scan's trip loop has no bound (its termination is proven for the shipped band); a band far below the
+    rounding bound makes rays re-enter their cell for ever.  The library then runs the bounded build: the step terminates,
+    the stuck rays read 'no return', and the overrun counter says so; back on the shipped band everything is as before."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    env = BatchedRaceEnv("austria", 8192, 1, auto_reset=True)
+    env.reset(mode="random", seed=0)
+    for k in range(20):
+        env.step_random(seed=1, step=k)
+    ref = env.views["lidar"].clone()
+    assert env.scan_overruns() == 0
+    env.debug_set("band_log2", -30)
+    assert env.scan_kernel_name().endswith("true>")
+    env.step_random(seed=1, step=20)
+    env.sync()
+    stuck = float((env.views["lidar"] == 15.0).float().mean())
+    assert env.scan_overruns() > 0 and stuck > 10 * float((ref == 15.0).float().mean())
+    env.debug_set("band_log2", 0)
+    assert env.scan_kernel_name() == "rc_raycast_car_kernel<1, false, false>"
     env.close()
 
 
