@@ -143,8 +143,10 @@ class COracleEnv:
 
     # ------------------------------------------------------------------
     def _split(self, n):
-        # several chunks per thread: the pool hands them out as threads become free (rays differ in length)
-        k = self.threads if self.threads == 1 else min(n, self.threads * 8)
+        # several chunks per thread: the pool hands them out as threads become free (rays differ in length); not so many
+        # that handing them out costs more than they take
+        k = self.threads if self.threads == 1 else max(self.threads, min(n // 8, self.threads * 4))
+        k = max(1, min(k, n))
         edges = [n * i // k for i in range(k + 1)]
         return [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
 

@@ -28,7 +28,7 @@ def _json_line(stdout):
 
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--envs", "4096", "--track",
-                        "columbia", "--cpu-envs", "256", "--numpy-envs", "256"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+                        "columbia", "--cpu-envs", "4096", "--numpy-envs", "256"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _json_line(r.stdout)
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
