@@ -185,6 +185,17 @@ int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat);
  * motor = motor_corner if |steering| > 0.35 else motor_straight (values in the caller's action convention). */
 int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner);
 
+/* The REFERENCE's follow-the-gap law on the device (ros_agent/agents/follow_the_gap/src/agent.py:128-193: forward arc
+ * of +-90 deg clipped at the look-ahead distance, disparities found with 10-degree median / maximum filters and extended
+ * by the vehicle's half-width, heading = mean angle of the beams at or above the 83.3rd percentile; :200-234: steering =
+ * 1.4 heading - 0.1 d(heading)/dt clipped to +-24 deg, speed 6 m/s less up to 30 % with the steering angle, at most 4/5
+ * of the free distance below 5 m, at least 1.5 m/s).  Writes (motor, steering) into RC_F_ACTION_IN - the node's speed over
+ * the car's top speed, its steering angle over the car's steering limit, in the caller's action convention (the remap of
+ * rc_config is inverted when it is on).  dt = seconds per agent step (the derivative term; none on an episode's first
+ * command).  detail_dev: optional device float32 [n, 4] = heading [rad], free distance [m], steering angle [rad], speed
+ * [m/s].  The generic bubble / widest-gap agent above stays available as rc_follow_the_gap. */
+int rc_follow_the_gap_reference(rc_env *env, float dt, float *detail_dev);
+
 int rc_get(rc_env *env, int32_t field, void **dev_ptr, size_t *bytes);
 int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes);
 /* The trajectory record of the last step as one contiguous device slab (fields LIDAR..TIME,

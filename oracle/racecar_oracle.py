@@ -217,6 +217,108 @@ def follow_the_gap(lidar, motor_straight=0.6, motor_corner=0.3):
     return out
 
 
+# ----------------------------------------------------------------------------- the reference's follow-the-gap law, fp32 spec
+# What rc_follow_the_gap_reference computes, operation for operation: the law of the reference's ROS node
+# (ros_agent/agents/follow_the_gap/src/agent.py:128-234; restated in float64 and pinned to the node's own outputs in
+# oracle/ftg_reference_port.py / tests/test_golden_ftg.py) in IEEE binary32 with a defined order of operations, so that the
+# device kernel can be compared bit for bit.  Differences from the float64 law, all below 1e-5 rad except the last:
+#  * the arc's beam angles and all range arithmetic in fp32; arccos by the polynomial below;
+#  * the means are taken over integers: the mean beam INDEX of the chosen beams (the angle is affine in it) and the chosen
+#    ranges rounded to 2^-19 m - sums of integers do not depend on the order in which a wave adds them up;
+#  * the percentile is NumPy's, to the bit: the 601st smallest adjusted range a plus 2^-43 of the gap to the 602nd, b
+#    ((n - 1) q / 100 = 600.0000000000001 for the node's q: np.percentile's `a + (b - a) * t`, t = 2^-43), evaluated in
+#    binary64 - whether the beams that hold exactly a are at or above it depends on the size of that gap, and they can be a
+#    whole plateau of equal ranges (the extension writes equal values).
+FTGR_FIRST, FTGR_N, FTGR_WIDTH, FTGR_RANK = 179, 721, 39, 600
+FTGR_INC = f32(1.5 * np.pi / 1079)
+FTGR_AMIN = f32(-0.75 * np.pi)
+FTGR_LOOKAHEAD = f32(2.0 * (7.0 ** 2 / (2.0 * 8.26)))
+FTGR_W2 = f32((0.3302 * 1.2) ** 2)
+FTGR_MAX_STEER = f32(np.deg2rad(24.0))
+FTGR_DEG5 = f32(np.deg2rad(5.0))
+
+
+def acos32(x):
+    """arccos in fp32 by asin's minimax polynomial on [-0.5, 0.5] (cephes asinf) and the half-angle identities; one IEEE
+    operation per operator, correctly rounded sqrt.  NaN for |x| > 1."""
+    x = np.asarray(x, f32)
+
+    def asin_small(t):                                   # |t| <= 0.5
+        z = t * t
+        pz = ((((f32(4.2163199048e-2) * z + f32(2.4181311049e-2)) * z + f32(4.5470025998e-2)) * z + f32(7.4953002686e-2)) * z
+              + f32(1.6666752422e-1)) * z
+        return pz * t + t
+
+    with np.errstate(invalid="ignore"):
+        big = np.abs(x) > f32(0.5)
+        half = np.sqrt((f32(1.0) - np.abs(x)) * f32(0.5))
+        a_big = f32(2.0) * asin_small(np.where(big, half, f32(0.0)))
+        a_big = np.where(x < 0, f32(3.14159274101257324) - a_big, a_big)
+        a_small = f32(1.57079637050628662) - asin_small(np.where(big, f32(0.0), x))
+        out = np.where(big, a_big, a_small).astype(f32)
+        return np.where(np.abs(x) <= f32(1.0), out, f32(np.nan)).astype(f32)
+
+
+def ftgr_angles():
+    return (np.arange(FTGR_FIRST, FTGR_FIRST + FTGR_N).astype(f32) * FTGR_INC + FTGR_AMIN).astype(f32)
+
+
+def follow_the_gap_reference(lidar, prev_heading, dt, max_steering=None, max_velocity=None):
+    """lidar float32 [n, 1080] in metres (the env's beam order), prev_heading float32 [n] (NaN = none yet), dt seconds per
+    agent step.  Returns dict: action float32 [n, 2] = (motor, steering) in [-1, 1] - the node's speed over the car's top
+    speed, its steering angle over the car's steering limit -, heading, heading_distance, steering_angle, speed [n]."""
+    lidar = np.asarray(lidar, f32).reshape(-1, N_BEAMS)
+    n = len(lidar)
+    max_steering = MAX_STEER if max_steering is None else f32(max_steering)
+    max_velocity = MAX_VEL if max_velocity is None else f32(max_velocity)
+    ang = ftgr_angles()
+    # arc element a = ROS beam 179 + a = env beam 900 - a
+    r = np.minimum(np.maximum(lidar[:, 900 - np.arange(FTGR_N)], f32(0.0)), FTGR_LOOKAHEAD).astype(f32)
+    jump = np.abs(r[:, 1:] - r[:, :-1]).astype(f32)                               # [n, 720]
+    half_w = FTGR_WIDTH // 2
+    peak_pad = np.pad(jump, ((0, 0), (half_w, half_w)), mode="symmetric")
+    med_pad = np.pad(jump, ((0, 0), (half_w, half_w)), mode="edge")
+    win = np.lib.stride_tricks.sliding_window_view
+    peak = win(peak_pad, FTGR_WIDTH, axis=1).max(axis=2)
+    cand = (jump == peak) & (jump > f32(0.2))
+    adjusted = r.copy()
+    for c, a in zip(*np.nonzero(cand)):
+        med = np.sort(med_pad[c, a:a + FTGR_WIDTH])[half_w]
+        if not (jump[c, a] > med * f32(9.0)):
+            continue
+        near = min(r[c, max(a - 1, 0)], r[c, a], r[c, a + 1])                     # (a >= 1 for every disparity)
+        two = f32(2.0) * (near * near)
+        with np.errstate(all="ignore"):
+            cosv = (two - FTGR_W2) / two
+            half = acos32(cosv)
+        if np.isnan(half):
+            ia = ib = 0
+        else:
+            lo = ((ang[a] - half) - ang[0]) / FTGR_INC
+            hi = ((ang[a] + half) - ang[0]) / FTGR_INC
+            ia, ib = (int(np.clip(np.trunc(v), 0, FTGR_N - 1)) for v in (lo, hi))
+        adjusted[c, ia:ib + 1] = np.minimum(adjusted[c, ia:ib + 1], near)
+    srt = np.sort(adjusted, axis=1).astype(np.float64)
+    thr = srt[:, FTGR_RANK] + (srt[:, FTGR_RANK + 1] - srt[:, FTGR_RANK]) * 2.0 ** -43        # binary64, one rounding (the add)
+    chosen = (adjusted.astype(np.float64) >= thr[:, None]) & (adjusted < MAX_RANGE)
+    count = chosen.sum(axis=1).astype(f32)
+    sum_k = (chosen * np.arange(FTGR_N)[None, :]).sum(axis=1).astype(f32)
+    heading = (((sum_k / count) + f32(FTGR_FIRST)) * FTGR_INC + FTGR_AMIN).astype(f32)
+    q = np.rint(r * f32(524288.0)).astype(np.uint32)                              # 2^19 counts per metre
+    sum_q = (q * chosen).sum(axis=1, dtype=np.uint64).astype(np.uint32).astype(f32)
+    hd = ((sum_q / count) * f32(1.0 / 524288.0)).astype(f32)
+    prev = np.asarray(prev_heading, f32).reshape(n)
+    dt = f32(dt)
+    with np.errstate(invalid="ignore"):
+        d_term = np.where(np.isnan(prev), f32(0.0), (f32(0.1) * (prev - heading)) / dt).astype(f32)
+    steer = np.minimum(np.maximum(f32(1.4) * heading - d_term, -FTGR_MAX_STEER), FTGR_MAX_STEER).astype(f32)
+    speed = np.where(np.abs(steer) > FTGR_DEG5, f32(6.0) - (np.abs(steer) / FTGR_MAX_STEER) * f32(1.8), f32(6.0)).astype(f32)
+    speed = np.where(hd < f32(5.0), np.minimum(speed, (hd / f32(5.0)) * f32(4.0)), speed).astype(f32)
+    speed = np.maximum(speed, f32(1.5)).astype(f32)
+    action = np.stack([clamp32(speed / max_velocity, f32(-1.0), f32(1.0)), clamp32(steer / max_steering, f32(-1.0), f32(1.0))], 1).astype(f32)
+    return dict(action=action, heading=heading, heading_distance=hd, steering_angle=steer, speed=speed)
+
+
 # ----------------------------------------------------------------------------- the env
 class OracleConfig:
     def __init__(self, num_envs=1, cars_per_env=1, laps=10, time_limit=180.0,

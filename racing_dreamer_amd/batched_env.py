@@ -376,6 +376,17 @@ class BatchedRaceEnv:
         self._exit()
         return self.views["action_in"]
 
+    def follow_the_gap_reference(self, dt: Optional[float] = None, detail: bool = False):
+        """The reference's own follow-the-gap law (ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent:
+        fills and returns `action_in`; with detail=True also a float32 [n_cars, 4] tensor of heading, free distance,
+        steering angle and speed.  dt defaults to the env's agent step (0.01 s x action_repeat)."""
+        dt = 0.01 * self.action_repeat if dt is None else float(dt)
+        det = torch.empty((self.n_cars, 4), dtype=torch.float32, device=self.device) if detail else None
+        self._enter()
+        L.check(self._lib.rc_follow_the_gap_reference(self._h, dt, det.data_ptr() if detail else None))
+        self._exit()
+        return (self.views["action_in"], det) if detail else self.views["action_in"]
+
     def fill_random_actions(self, seed: int, step: int) -> None:
         L.check(self._lib.rc_fill_random_actions(self._h, C.c_uint64(seed), C.c_uint32(step)))
 

@@ -213,6 +213,7 @@ struct rc_env {
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
     bool gather_pending = false;
     P2p *p2p = nullptr;                // peer-copy all-gather (rc_p2p_setup), else null
+    float *ftg_prev = nullptr;         // rc_follow_the_gap_reference: previous heading per car (NaN = none), allocated on first use
 };
 
 namespace {
@@ -639,6 +640,7 @@ void rc_destroy(rc_env *env) {
     for (EventPair &ep : env->free_events) { (void)hipEventDestroy(ep.a); (void)hipEventDestroy(ep.b); }
     if (env->own_arena && env->arena) (void)hipFree(env->arena);
     if (env->state_mem) (void)hipFree(env->state_mem);
+    if (env->ftg_prev) (void)hipFree(env->ftg_prev);
     env->track.reset();
     if (env->mask_dev) (void)hipFree(env->mask_dev);
     if (env->own_stream && env->stream) (void)hipStreamDestroy(env->stream);
@@ -952,6 +954,20 @@ int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner) {
     if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
     HIP_TRY(hipSetDevice(env->cfg.device));
     TIMED(env, RC_K_FTG, rck_launch_ftg(env->params, env->actions_in, motor_straight, motor_corner, env->stream));
+    return RC_OK;
+}
+
+int rc_follow_the_gap_reference(rc_env *env, float dt, float *detail_dev) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (!env->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+    if (!(dt > 0.f)) return fail(RC_ERR_INVALID, "dt must be > 0 (seconds per agent step)");
+    if (env->cfg.lidar_transform != RC_LIDAR_METRES) return fail(RC_ERR_INVALID, "rc_follow_the_gap_reference reads the scan in metres (lidar_transform RC_LIDAR_METRES)");
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    if (!env->ftg_prev) {
+        HIP_TRY(hipMalloc((void **)&env->ftg_prev, (size_t)env->n_cars * sizeof(float)));
+        HIP_TRY(hipMemsetAsync(env->ftg_prev, 0xff, (size_t)env->n_cars * sizeof(float), env->stream));      // all ones: a NaN
+    }
+    TIMED(env, RC_K_FTG, rck_launch_ftg_reference(env->params, env->actions_in, env->ftg_prev, dt, detail_dev, env->stream));
     return RC_OK;
 }
 

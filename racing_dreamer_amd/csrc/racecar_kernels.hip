@@ -2083,6 +2083,205 @@ __global__ __launch_bounds__(256) void rc_ftg_kernel(RcParams p, float *__restri
     }
 }
 
+// ---- The REFERENCE's follow-the-gap law on the device (ros_agent/agents/follow_the_gap/src/agent.py:128-234 of the
+// reference: disparity extender + percentile heading + P/D steering) - oracle/racecar_oracle.py, follow_the_gap_reference,
+// is the binary32 spec this kernel follows operation for operation; oracle/ftg_reference_port.py restates the node in
+// float64 and tests/golden/ftg_golden.npz pins both to the node's own outputs.  One wave per car; arc element
+// a = ROS beam 179 + a = this build's beam 900 - a, 721 of them, lane l holds a = l + 64 k.
+#define FR_FIRST 179
+#define FR_N 721
+#define FR_HALF 19                      // the 10-degree filter: 39 beams
+#define FR_PER_LANE 12
+// (binary32 values of the oracle's float64 expressions, as hexadecimal literals: no decimal rounding in between)
+constexpr float kFrInc = 0x1.1e3842p-8f;                 // fp32(1.5 pi / 1079) = 0.004367367
+constexpr float kFrAmin = -0x1.2d97c8p+1f;               // fp32(-0.75 pi)
+constexpr float kFrLookahead = 0x1.7ba938p+2f;           // fp32(2 x 7^2 / (2 x 8.26)) = 5.9322033
+constexpr float kFrW2 = 0x1.418c7p-3f;                   // fp32((1.2 x 0.3302)^2) = 0.15700614
+constexpr float kFrMaxSteer = 0x1.aceeap-2f;             // fp32(24 deg)
+constexpr float kFrDeg5 = 0x1.657184p-4f;                // fp32(5 deg)
+
+__device__ __forceinline__ float fr_asin_small(float t) {            // |t| <= 0.5 (cephes asinf)
+    const float z = t * t;
+    const float pz = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z;
+    return pz * t + t;
+}
+__device__ __forceinline__ float fr_acos(float x) {                  // racecar_oracle.acos32
+    const float ax = fabsf(x);
+    if (!(ax <= 1.0f)) return __builtin_nanf("");
+    if (ax > 0.5f) {
+        const float a = 2.0f * fr_asin_small(__fsqrt_rn((1.0f - ax) * 0.5f));
+        return x < 0.0f ? 3.14159274101257324f - a : a;
+    }
+    return 1.57079637050628662f - fr_asin_small(x);
+}
+__device__ __forceinline__ float fr_angle(int a) { return (float)(FR_FIRST + a) * kFrInc + kFrAmin; }
+__device__ __forceinline__ int wave_count(bool c) { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(c)); }
+
+__global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float *__restrict__ actions, float *__restrict__ prev_heading,
+                                                               float dt, float *__restrict__ detail) {
+    const int lane = threadIdx.x & 63;
+    const int car = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (car >= p.n_cars) return;
+    __shared__ float lds_r[4][FR_PER_LANE * 64 + 2], lds_j[4][FR_PER_LANE * 64];
+    float *r = lds_r[threadIdx.x >> 6], *jump = lds_j[threadIdx.x >> 6];
+    const float *scan = p.out.lidar + (size_t)car * RC_N_BEAMS;
+    // the arc, clipped at the look-ahead distance (agent.py:141-146); consecutive lanes read consecutive beams
+    float rv[FR_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        const int a = lane + 64 * k;
+        float v = 0.0f;
+        if (a < FR_N) {
+            v = scan[900 - a];
+            v = v > 0.0f ? v : 0.0f;                                 // (also turns a NaN into 0)
+            v = v < kFrLookahead ? v : kFrLookahead;
+        }
+        rv[k] = v;
+        r[a] = v;
+    }
+    if (lane < 2) r[FR_PER_LANE * 64 + lane] = 0.0f;
+    __builtin_amdgcn_wave_barrier();
+    float jv[FR_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        const int a = lane + 64 * k;
+        jv[k] = a < FR_N - 1 ? fabsf(r[a + 1] - rv[k]) : 0.0f;      // agent.py:148
+        jump[a] = jv[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // disparities (agent.py:150-159): a jump that is the maximum of its 39-beam window (mirrored at the ends), exceeds 0.2 m
+    // and nine times the window's median (ends repeated) - the median only where the first two tests pass
+    float adj[FR_PER_LANE];
+    bool cand[FR_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        const int a = lane + 64 * k;
+        adj[k] = a < FR_N ? rv[k] : INFINITY;                         // (slots beyond the arc: above every rank)
+        float peak = 0.0f;
+        if (a < FR_N - 1) {
+            for (int w = -FR_HALF; w <= FR_HALF; ++w) {
+                int i = a + w;
+                i = i < 0 ? -i - 1 : (i >= FR_N - 1 ? 2 * (FR_N - 1) - i - 1 : i);
+                const float v = jump[i];
+                peak = v > peak ? v : peak;
+            }
+        }
+        cand[k] = a < FR_N - 1 && jv[k] == peak && jv[k] > 0.2f;
+    }
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(cand[k]);
+        while (todo != 0) {
+            const int l = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int ac = l + 64 * k;                                // wave-uniform
+            // median of the window: lane m < 39 holds sample m; its rank = samples below it (ties by position)
+            int i = ac - FR_HALF + lane;
+            i = i < 0 ? 0 : (i > FR_N - 2 ? FR_N - 2 : i);
+            const float mine = jump[i];
+            int rank = 0;
+#pragma unroll
+            for (int m = 0; m < 2 * FR_HALF + 1; ++m) {
+                const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), m));
+                rank += (o < mine || (o == mine && m < lane)) ? 1 : 0;
+            }
+            const unsigned long long is_med = __builtin_amdgcn_ballot_w64(lane <= 2 * FR_HALF && rank == FR_HALF);
+            const float med = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __builtin_ctzll(is_med)));
+            const float jc = jump[ac];
+            if (!(jc > med * 9.0f)) continue;
+            // extend the nearer side by the half-width of the vehicle as seen at that range (agent.py:165-176)
+            const float near = fminf(fminf(r[ac > 0 ? ac - 1 : 0], r[ac]), r[ac + 1]);
+            const float two = 2.0f * (near * near);
+            const float half = fr_acos((two - kFrW2) / two);
+            int ia = 0, ib = 0;
+            if (half == half) {
+                const float a0 = fr_angle(0), at = fr_angle(ac);
+                const float lo = ((at - half) - a0) / kFrInc, hi = ((at + half) - a0) / kFrInc;
+                ia = (int)lo; ib = (int)hi;
+                ia = ia < 0 ? 0 : (ia > FR_N - 1 ? FR_N - 1 : ia);
+                ib = ib < 0 ? 0 : (ib > FR_N - 1 ? FR_N - 1 : ib);
+            }
+#pragma unroll
+            for (int e = 0; e < FR_PER_LANE; ++e) {
+                const int a = lane + 64 * e;
+                if (a >= ia && a <= ib) adj[e] = adj[e] < near ? adj[e] : near;
+            }
+        }
+    }
+    // the 601st and 602nd smallest adjusted range (agent.py:183, np.percentile at q = 83.3): ranges are >= 0, so their
+    // bit patterns order like the values; binary search on the pattern, counts by ballot
+    uint32_t key[FR_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) key[k] = __float_as_uint(adj[k]);
+    uint32_t x600 = 0u;
+    for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t trial = x600 | (1u << bit);
+        int below = 0;
+#pragma unroll
+        for (int k = 0; k < FR_PER_LANE; ++k) below += wave_count(key[k] < trial);
+        if (below <= 600) x600 = trial;
+    }
+    int not_above = 0;
+    uint32_t next = 0x7f800000u;
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        not_above += wave_count(key[k] <= x600);
+        if (key[k] > x600 && key[k] < next) next = key[k];
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)next, off);
+        next = o < next ? o : next;
+    }
+    const uint32_t x601 = not_above >= 602 ? x600 : next;
+    // NumPy's linear interpolation at virtual index 600.0000000000001: a + (b - a) * 2^-43 in binary64
+    const double a64 = (double)__uint_as_float(x600), b64 = (double)__uint_as_float(x601);
+    const double thr = a64 + (b64 - a64) * 1.1368683772161603e-13;
+    int count = 0, sum_k = 0;
+    uint32_t sum_q = 0u;
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        const int a = lane + 64 * k;
+        const bool chosen = a < FR_N && (double)adj[k] >= thr && adj[k] < RCS_MAX_RANGE;      // np.digitize(...) == 2
+        count += wave_count(chosen);
+        if (chosen) {
+            sum_k += a;
+            sum_q += (uint32_t)__builtin_rintf(rv[k] * 524288.0f);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        sum_k += __shfl_xor(sum_k, off);
+        sum_q += (uint32_t)__shfl_xor((int)sum_q, off);
+    }
+    if (lane == 0) {
+        const float cnt = (float)count;
+        const float heading = (((float)sum_k / cnt) + (float)FR_FIRST) * kFrInc + kFrAmin;          // agent.py:184
+        const float hd = ((float)sum_q / cnt) * (1.0f / 524288.0f);                                 // agent.py:185
+        // agent.py:200-234 with PID.calculate (kp 1.4, kd 0.1): no derivative term on an episode's first command
+        const float prev = p.st.fresh[car] ? __builtin_nanf("") : prev_heading[car];
+        const float d_term = prev == prev ? (0.1f * (prev - heading)) / dt : 0.0f;
+        float steer = 1.4f * heading - d_term;
+        steer = steer > -kFrMaxSteer ? steer : -kFrMaxSteer;
+        steer = steer < kFrMaxSteer ? steer : kFrMaxSteer;
+        float speed = fabsf(steer) > kFrDeg5 ? 6.0f - (fabsf(steer) / kFrMaxSteer) * 1.8f : 6.0f;
+        if (hd < 5.0f) { const float lim = (hd / 5.0f) * 4.0f; speed = lim < speed ? lim : speed; }
+        speed = speed > 1.5f ? speed : 1.5f;
+        prev_heading[car] = heading;
+        // the car's actuators: target speed over its top speed, steering angle over its steering limit
+        float motor = clampf(speed / RCS_MAX_VEL, -1.0f, 1.0f), steering = clampf(steer / RCS_MAX_STEER, -1.0f, 1.0f);
+        if (p.remap_actions) {                 // the caller's convention is ReduceActionSpace's (wrappers.py:128-130): invert it
+            motor = ((motor - p.act_lo0) * 2.0f) / (p.act_hi0 - p.act_lo0) - 1.0f;
+            steering = ((steering - p.act_lo1) * 2.0f) / (p.act_hi1 - p.act_lo1) - 1.0f;
+        }
+        actions[2 * car] = motor;
+        actions[2 * car + 1] = steering;
+        if (detail != nullptr) {
+            detail[4 * car] = heading; detail[4 * car + 1] = hd; detail[4 * car + 2] = steer; detail[4 * car + 3] = speed;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void rc_set_pose_kernel(RcParams p, const float *__restrict__ xyyaw) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.n_cars) return;
@@ -2387,6 +2586,12 @@ hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream
 hipError_t rck_launch_ftg(const RcParams &p, float *actions, float motor_straight, float motor_corner, hipStream_t s) {
     const int threads = 256, blocks = (p.n_cars + 3) / 4;
     launch(rc_ftg_kernel, dim3(blocks), dim3(threads), 0, s, p, actions, motor_straight, motor_corner);
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_ftg_reference(const RcParams &p, float *actions, float *prev_heading, float dt, float *detail, hipStream_t s) {
+    const int threads = 256, blocks = (p.n_cars + 3) / 4;
+    launch(rc_ftg_reference_kernel, dim3(blocks), dim3(threads), 0, s, p, actions, prev_heading, dt, detail);
     return hipGetLastError();
 }
 

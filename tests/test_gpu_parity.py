@@ -240,7 +240,7 @@ def test_a_mis_set_band_ends_in_no_return_not_in_a_hung_wave():
     stuck = float((env.views["lidar"] == 15.0).float().mean())
     assert env.scan_overruns() > 0 and stuck > 10 * float((ref == 15.0).float().mean())
     env.debug_set("band_log2", 0)
-    assert env.scan_kernel_name() == "rc_raycast_car_kernel<1, false, false>"
+    assert env.scan_kernel_name().endswith("false>")          # (8 192 cars: two waves per car, the overlapped build)
     env.close()
 
 
@@ -701,6 +701,44 @@ def test_follow_the_gap_kernel_matches_oracle_and_drives():
     assert crashes <= n // 50                                 # random actions crash every env within ~100 steps
     assert float((out["progress_total"] - prog0).mean()) > 0.05 or crashes > 0
     env.close()
+
+
+def test_reference_follow_the_gap_law_on_the_device():
+    """rc_follow_the_gap_reference - the law of the reference's own ROS node (agent.py:128-234) - bit for bit against its
+    binary32 spec (oracle.follow_the_gap_reference, itself within 3e-7 rad of the node's outputs: tests/test_golden_ftg.py)
+    on live scans, headings carried from step to step (the derivative term) and dropped at episode starts; in both action
+    conventions; and it drives: hardly a crash where random actions crash every env."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    n = 1024
+    for remap in (False, True):
+        env = BatchedRaceEnv("austria", n, 1, auto_reset=True, remap_actions=remap, action_repeat=4)
+        out = env.reset(mode="random", seed=5)
+        prog0 = out["progress_total"].clone()
+        prev = np.full(n, np.nan, np.float32)
+        crashes = 0
+        for k in range(150):
+            act, det = env.follow_the_gap_reference(detail=True)
+            if k < 12 or k % 25 == 0:
+                torch.cuda.synchronize()
+                fresh = out["fresh"].cpu().numpy().reshape(n) != 0
+                want = ro.follow_the_gap_reference(out["lidar"].cpu().numpy().reshape(n, 1080),
+                                                   np.where(fresh, np.float32(np.nan), prev), 0.04)
+                d = det.cpu().numpy()
+                for j, name in enumerate(("heading", "heading_distance", "steering_angle", "speed")):
+                    assert np.array_equal(d[:, j], want[name]), (remap, k, name, np.abs(d[:, j] - want[name]).max())
+                a = want["action"]
+                if remap:                       # the caller's convention: ReduceActionSpace inverted (wrappers.py:128-130)
+                    lo, hi = np.float32([0.005, -1.0]), np.float32([1.0, 1.0])
+                    a = ((a - lo) * np.float32(2.0)) / (hi - lo) - np.float32(1.0)
+                assert np.array_equal(act.cpu().numpy().reshape(n, 2), a.astype(np.float32)), (remap, k)
+            prev = det[:, 0].cpu().numpy().copy()
+            out = env.step(None)
+            crashes += int(out["done"].sum())
+        torch.cuda.synchronize()
+        assert crashes <= n // 20, crashes
+        assert float((out["progress_total"] - prog0).mean()) > 0.05 or crashes > 0
+        env.close()
 
 
 def test_full_size_two_cars_32768_envs_match_oracle():
