@@ -114,35 +114,74 @@ class ChangingTrackMultiAgentRaceEnv(_ChangingTrack):
 
 
 class _Vectorized:
-    """Synchronous list-of-envs vector env (baselines/racing/environment/environment.py:5).  For large
-    batches use racing_dreamer_amd.BatchedRaceEnv directly: it steps every env in one kernel launch."""
+    """Synchronous vector env over a list of scenarios (baselines/racing/environment/environment.py:5,40).  Envs whose
+    scenarios agree (track, agents, tasks: `scenario_key`) share ONE device handle - a BatchedRaceEnv with B = their
+    number: one launch and one device-to-host copy per step for the whole group - and a list over several tracks becomes
+    one handle per track.  Env i of the list is env i of the job: its random resets are drawn from its own stream (the
+    Philox key holds the env's index in its group), so a vector env of n equal scenarios is n DIFFERENT envs, where n
+    separately built B = 1 envs with one seed would all be the same one."""
 
-    def __init__(self, envs):
-        self._envs = envs
-        self.observation_space = [e.observation_space for e in envs]
-        self.action_space = [e.action_space for e in envs]
+    def __init__(self, scenarios, device: int = 0, single: bool = False):
+        from .multi_agent_race import RaceCore, scenario_key
+        self._single = single
+        multi = [s.as_multi() if single else s for s in scenarios]
+        groups = {}
+        for i, sc in enumerate(multi):
+            groups.setdefault(scenario_key(sc), []).append(i)
+        self._cores, self._where = [], [None] * len(multi)
+        for members in groups.values():
+            core = RaceCore(multi[members[0]], len(members), device=device)
+            for slot, i in enumerate(members):
+                self._where[i] = (len(self._cores), slot)
+            self._cores.append((core, members))
+        self._scenarios = list(scenarios)
+        self._ids = [[a.id for a in sc.agents] for sc in multi]
+        pick = (lambda space, ids: space[ids[0]]) if single else (lambda space, ids: space)
+        self.observation_space = [pick(self._cores[c][0].observation_space, self._ids[i]) for i, (c, _) in enumerate(self._where)]
+        self.action_space = [pick(self._cores[c][0].action_space, self._ids[i]) for i, (c, _) in enumerate(self._where)]
+
+    @property
+    def num_device_handles(self) -> int:
+        return len(self._cores)
+
+    def _scatter(self, per_core):
+        """per_core[c] = list over that core's slots -> list over the envs of the vector env."""
+        out = [None] * len(self._where)
+        for i, (c, slot) in enumerate(self._where):
+            v = per_core[c][slot]
+            out[i] = v[self._ids[i][0]] if self._single else v
+        return out
 
     def step(self, actions):
-        res = [e.step(a) for e, a in zip(self._envs, actions)]
-        return tuple(list(x) for x in zip(*res))
+        res = []
+        for core, members in self._cores:
+            acts = [({self._ids[i][0]: actions[i]} if self._single else actions[i]) for i in members]
+            res.append(core.step(acts))
+        return tuple(self._scatter([r[k] for r in res]) for k in range(4))
 
     def reset(self, mode: str = "grid"):
-        return [e.reset(mode=mode) for e in self._envs]
+        return self._scatter([core.reset(mode=mode) for core, _ in self._cores])
 
     def render(self, mode: str = "follow", agents=None, **kw):
-        agents = agents or [None] * len(self._envs)
-        return [e.render(mode=mode, agent=a, **kw) for e, a in zip(self._envs, agents)]
+        from .rendering import render_view
+        agents = agents or [None] * len(self._where)
+        states = [core.fetch()[2] for core, _ in self._cores]
+        frames = []
+        for i, (c, slot) in enumerate(self._where):
+            track = self._cores[c][0].scenario.world.track
+            frames.append(render_view(track, states[c][slot], focus=agents[i] or self._ids[i][0], mode=mode))
+        return frames
 
     def close(self):
-        for e in self._envs:
-            e.close()
+        for core, _ in self._cores:
+            core.close()
 
 
 class VectorizedSingleAgentRaceEnv(_Vectorized):
     def __init__(self, scenarios: List[SingleAgentScenario], device: int = 0):
-        super().__init__([SingleAgentRaceEnv(s, device=device) for s in scenarios])
+        super().__init__(scenarios, device=device, single=True)
 
 
 class VectorizedMultiAgentRaceEnv(_Vectorized):
     def __init__(self, scenarios: List[MultiAgentScenario], device: int = 0):
-        super().__init__([MultiAgentRaceEnv(s, device=device) for s in scenarios])
+        super().__init__(scenarios, device=device, single=False)

@@ -220,3 +220,50 @@ def test_episode_recorder_on_the_hip_env_equals_the_oracle_recording(tmp_path):
             assert a[k].dtype == b[k].dtype and np.array_equal(a[k], b[k]), k
     assert count_steps(tmp_path / "hip") == sum(len(e["reward"]) - 1 for e in eps_d)
     env.close()
+
+
+def test_vector_env_steps_eight_envs_with_one_launch(tmp_path):
+    """VectorizedMultiAgentRaceEnv / VectorizedSingleAgentRaceEnv on the HIP backend: eight same-track envs are ONE handle
+    (one dynamics + one scan launch and one device-to-host copy per step), equal to the oracle's B = 8 env; a two-track
+    list is two handles."""
+    from racing_dreamer_amd import compat
+    compat.install()
+    from racecar_gym import SingleAgentScenario
+    from racecar_gym.envs import VectorizedMultiAgentRaceEnv, VectorizedSingleAgentRaceEnv
+    from racecar_gym.envs.multi_agent_race import MultiAgentScenario
+    from helpers import make_oracle
+    from oracle import racecar_oracle as ro
+    from racing_dreamer_amd.track_assets import load_track
+    path = _scenario(tmp_path, "austria", ("A", "B"))
+    vec = VectorizedMultiAgentRaceEnv([MultiAgentScenario.from_spec(path) for _ in range(8)])
+    assert vec.num_device_handles == 1
+    core = vec._cores[0][0]
+    core.env.set_profiling(True)
+    ora = make_oracle(load_track("austria"), num_envs=8, cars_per_env=2)
+    obs = vec.reset(mode="random_ball")
+    oo = ora.reset(mode=ro.RESET_RANDOM_BALL, seed=0)
+    steps = 25
+    for k in range(steps):
+        for e in range(8):
+            for i, aid in enumerate("AB"):
+                assert np.array_equal(obs[e][aid]["lidar"], oo["lidar"][2 * e + i].astype(np.float64)), (k, e, aid)
+        a = ro.random_actions(3, k, 16)
+        obs, rew, done, info = vec.step([{aid: {"motor": a[2 * e + i, 0], "steering": a[2 * e + i, 1]} for i, aid in enumerate("AB")}
+                                         for e in range(8)])
+        oo = ora.step(a)
+        for e in range(8):
+            for i, aid in enumerate("AB"):
+                c = 2 * e + i
+                assert rew[e][aid] == float(oo["reward"][c]) and done[e][aid] == bool(oo["done"][c]), (k, e, aid)
+                assert info[e][aid]["progress"] == float(oo["progress"][c]) and info[e][aid]["wall_collision"] == bool(oo["wall_collision"][c])
+    kt = core.env.kernel_times()
+    assert kt["rc_dynamics_kernel"]["launches"] == steps and kt["rc_raycast_kernel"]["launches"] == steps + 1   # (+ the reset's scan)
+    vec.close()
+    single = [SingleAgentScenario.from_spec(_scenario(tmp_path, t)) for t in ("columbia", "austria", "columbia")]
+    vec = VectorizedSingleAgentRaceEnv(single)
+    assert vec.num_device_handles == 2
+    obs = vec.reset(mode="grid")
+    assert np.array_equal(obs[0]["lidar"], obs[2]["lidar"]) and not np.array_equal(obs[0]["lidar"], obs[1]["lidar"])
+    obs, rew, done, info = vec.step([{"motor": np.array([0.4]), "steering": np.array([0.1])}] * 3)
+    assert rew[0] == rew[2] and info[0]["progress"] == info[2]["progress"] and len(obs) == 3
+    vec.close()

@@ -152,3 +152,55 @@ def test_reference_baselines_wrapper_stack_runs_on_the_shim(ref_wrappers, monkey
         assert 1 <= steps <= 10                                                                 # 40 sub-steps / repeat 4
         assert {"wrong_way", "progress", "lap", "wall_collision", "time"} <= set(info)
         assert np.isfinite(total)
+
+
+def test_vector_env_is_one_batched_handle_per_track(ref_wrappers, monkeypatch):
+    """VectorizedSingleAgentRaceEnv (baselines/racing/environment/environment.py:5,40): eight envs of one scenario sit on ONE
+    backend handle with B = 8 - and behave like eight independent envs, each with its own reset stream: env i of the list
+    equals a lone oracle env whose global index is i, step for step.  A list over two tracks becomes two handles; results
+    come back in list order."""
+    from oracle import c_oracle
+    from oracle import racecar_oracle as ro
+    from racecar_gym import SingleAgentScenario
+    from racecar_gym.envs import VectorizedSingleAgentRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    monkeypatch.chdir(os.path.join(REF, "baselines"))
+    scen = [SingleAgentScenario.from_spec("scenarios/max_progress/columbia.yml", rendering=False) for _ in range(8)]
+    vec = VectorizedSingleAgentRaceEnv(scenarios=scen)
+    assert vec.num_device_handles == 1 and vec._cores[0][0].env.B == 8 and len(vec.action_space) == 8
+    t = load_track("columbia")
+    agent = scen[0].agent
+    p = agent.task_params
+    lone = []
+    for i in range(8):
+        cfg = ro.OracleConfig(num_envs=1, first_env=i, laps=int(p.get("laps", 10)), time_limit=float(p.get("time_limit", 180.0)),
+                              terminate_on_collision=bool(p.get("terminate_on_collision", True)),
+                              collision_reward=float(p.get("collision_reward", 0.0)))
+        lone.append(c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg))
+    obs = vec.reset(mode="random")
+    want = [e.reset(mode=ro.RESET_RANDOM, seed=0) for e in lone]
+    poses = np.stack([o["pose"] for o in obs])
+    assert len({tuple(np.round(q, 6)) for q in poses}) == 8              # eight different spawn poses, not one eight times
+    rng = np.random.default_rng(0)
+    for k in range(12):
+        for i in range(8):
+            assert np.array_equal(obs[i]["lidar"], want[i]["lidar"][0].astype(np.float64)), (k, i)
+            assert np.array_equal(obs[i]["pose"], want[i]["pose"][0].astype(np.float64)), (k, i)
+        a = rng.uniform(-1, 1, (8, 2)).astype(np.float32)
+        obs, rew, done, info = vec.step([{"motor": np.array([a[i, 0]]), "steering": np.array([a[i, 1]])} for i in range(8)])
+        want = [lone[i].step(a[i:i + 1]) for i in range(8)]
+        for i in range(8):
+            assert rew[i] == float(want[i]["reward"][0]) and done[i] == bool(want[i]["done"][0]), (k, i)
+            assert info[i]["progress"] == float(want[i]["progress"][0]) and info[i]["lap"] == int(want[i]["lap"][0])
+    vec.close()
+    mixed = [SingleAgentScenario.from_spec(f"scenarios/max_progress/{name}.yml", rendering=False)
+             for name in ("columbia", "austria", "columbia", "austria", "austria")]
+    vec = VectorizedSingleAgentRaceEnv(scenarios=mixed)
+    assert vec.num_device_handles == 2 and sorted(c.env.B for c, _ in vec._cores) == [2, 3]
+    obs = vec.reset(mode="grid")
+    assert len(obs) == 5 and np.array_equal(obs[0]["pose"], obs[2]["pose"]) and np.array_equal(obs[1]["pose"], obs[4]["pose"])
+    obs, rew, done, info = vec.step([{"motor": np.array([0.5]), "steering": np.array([0.0])}] * 5)
+    assert len(obs) == len(rew) == len(done) == len(info) == 5 and all(isinstance(d, bool) for d in done)
+    frames = vec.render(mode="birds_eye")
+    assert len(frames) == 5 and frames[0].shape == frames[1].shape and frames[0].ndim == 3
+    vec.close()
