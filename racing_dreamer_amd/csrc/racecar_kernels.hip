@@ -1343,6 +1343,25 @@ __device__ __forceinline__ uint32_t quantise_pair(float a, float b, float off, f
     return (__float_as_uint(ta) & 0xffffu) | (__float_as_uint(tb) << 16);
 }
 
+#ifdef RC_EXP_DIR_TABLE
+// TIMING EXPERIMENT (not a shipped path: results differ from the spec): beam directions and their
+// reciprocals from a table indexed by the heading quantised to a quarter of the beam spacing, instead of the rotation of
+// the beam table by the car's (cos, sin) and two Newton reciprocals per ray.  Four interleaved sub-tables (heading index
+// mod 4), so that a wave's 64 rays read 1 KB of consecutive entries.
+#define RC_DIR_NK 2624
+#define RC_DIR_OFF 1816
+__device__ const float4 *g_dir_table = nullptr;
+__global__ void rc_build_dir_table_kernel(float4 *tbl) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= 4 * RC_DIR_NK) return;
+    const int sub = g / RC_DIR_NK, k = g % RC_DIR_NK - RC_DIR_OFF;
+    const double q = (1.5 * 3.14159265358979323846 / 1079.0) / 4.0;
+    const double th = q * (double)(4 * k + sub) + 0.75 * 3.14159265358979323846;
+    const float dx = (float)cos(th), dy = (float)sin(th);
+    tbl[g] = make_float4(dx, dy, 1.0f / dx, 1.0f / dy);
+}
+#endif
+
 constexpr unsigned kCarRowBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges ...
 constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... and the start cell's line of the first-trip table
 
@@ -1384,7 +1403,16 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     // overlap (a wave's start-up - state, start cell, first-trip line - is serial latency that nothing else hides)
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
     unsigned boff = lane * 8u + 512u * part;                             // byte offset of this lane's beam pair
+#ifdef RC_EXP_DIR_TABLE
+    const float yaw = p.st.theta[car];
+    const int hq = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(yaw * (4.0f / 0.004367367f)));
+    const int sub = hq & 3, base = (hq - sub) >> 2;
+    const char *dir_row = reinterpret_cast<const char *>(g_dir_table + sub * RC_DIR_NK + base + RC_DIR_OFF);
+    unsigned doff = lane * 16u + 1024u * part;                           // entry k = base - beam: descending addresses
+    float4 bm = *reinterpret_cast<const float4 *>(dir_row - doff);
+#else
     float2 bm = *reinterpret_cast<const float2 *>(beams + boff);
+#endif
     // all four state words in one scalar 16-byte load
     const float4 sp = p.st.scan_pose[car];
     float ct = sp.z, st = sp.w;
@@ -1439,10 +1467,15 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     struct Ray { float dx, dy, idx, idy; int nx, ny; unsigned v; };
     // (dx, dy) = (ct cb - st sb, ct sb + st cb), one rounding per operator: four products, a subtract and an add - plain
     // full-rate instructions (the packed forms issue at half rate and need their operands swizzled into pairs)
+#ifdef RC_EXP_DIR_TABLE
+    auto prepare = [&](float4 b, Ray &r) {
+        r.dx = b.x; r.dy = b.y; r.idx = b.z; r.idy = b.w;
+#else
     auto prepare = [&](float2 b, Ray &r) {
         r.dx = ct * b.x - st * b.y;
         r.dy = ct * b.y + st * b.x;
         ray_reciprocals(r.dx, r.dy, r.idx, r.idy);
+#endif
         r.nx = sign_mask(r.dx); r.ny = sign_mask(r.dy);
         r.v = first_trip_entry(first_line, r.dy, r.idx, r.nx, r.ny);
     };
@@ -1460,7 +1493,12 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
             if (round + split < kRounds) {
                 prepare(bm, nxt);                                         // (the padded beams of the last round included)
                 boff += bstep;
+#ifdef RC_EXP_DIR_TABLE
+                doff += 2u * bstep;
+                if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float4 *>(dir_row - doff);
+#else
                 if (round + 2 * split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
+#endif
             }
         };
         float rng;
@@ -1513,7 +1551,12 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     prepare(bm, ra);
     if (STAMPS) { asm volatile("" :: "v"(ra.v)); stamp(2); t_mark = __builtin_amdgcn_s_memtime(); }
     boff += bstep;
+#ifdef RC_EXP_DIR_TABLE
+    doff += 2u * bstep;
+    if ((int)part + split < kRounds) bm = *reinterpret_cast<const float4 *>(dir_row - doff);
+#else
     if ((int)part + split < kRounds) bm = *reinterpret_cast<const float2 *>(beams + boff);
+#endif
     for (int round = (int)part; round < kRounds; round += 2 * split) {
         if (!stage(round, ra, rb)) break;
         if (round + split >= kRounds) break;
@@ -2538,6 +2581,18 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     const int total = p.n_cars * RC_N_BEAMS;
+#ifdef RC_EXP_DIR_TABLE
+    {
+        static float4 *tbl = nullptr;
+        if (tbl == nullptr) {
+            hipError_t e = hipMalloc((void **)&tbl, 4 * RC_DIR_NK * sizeof(float4));
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(rc_build_dir_table_kernel, dim3((4 * RC_DIR_NK + 255) / 256), dim3(256), 0, s, tbl);
+            e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dir_table), &tbl, sizeof(tbl), 0, hipMemcpyHostToDevice, s);
+            if (e != hipSuccess) return e;
+        }
+    }
+#endif
     if (li.raycast_variant == 7) {
         const int threads = li.car_threads, per = threads / 64;                     // waves per workgroup
         const long long waves = (long long)p.n_cars * li.car_split;

@@ -20,6 +20,12 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _errtext(stderr):
+    """The ranks' own tracebacks come first, the launcher's summary last: show both ends."""
+    lines = [l for l in stderr.splitlines() if "Traceback" in l or "Error" in l or "error" in l]
+    return "\n".join(lines[:30]) + "\n...\n" + stderr[-1500:]
+
+
 def _json_line(stdout):
     lines = [l for l in stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, stdout[-2000:]
@@ -29,7 +35,7 @@ def _json_line(stdout):
 def test_bench_single_gpu_contract():
     r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--envs", "4096", "--track",
                         "columbia", "--cpu-envs", "4096", "--numpy-envs", "256"], cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
     assert REQUIRED <= set(d) and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 2
     assert d["unit"] == "env-steps/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -63,7 +69,7 @@ def test_bench_starts_its_own_ranks():
     starts its two ranks itself, rank 0's single JSON line comes through, and the communicator's own rank count is in it."""
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "6", "--warmup", "2",
                         "--envs", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["config"]["comm_ranks"] == 2
     assert d["config"]["comm_backend"] == "gloo" and d["config"]["rccl_ranks"] is None      # (RCCL needs a GPU per rank)
@@ -74,7 +80,7 @@ def test_bench_two_ranks_peer_copy_transport():
     """The same two ranks with the gather as direct peer copies (hipIpc works between processes on one device)."""
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--gather-via", "p2p", "--steps", "6",
                         "--warmup", "2", "--envs", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
     assert d["config"]["gather_via"] == "p2p" and "rc_gather_trajectory_p2p" in d["config"]["workload"]
     gm = d["gather_modes"]
@@ -86,7 +92,7 @@ def test_bench_two_ranks_functional():
            "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "6", "--warmup",
            "2", "--envs", "2048", "--backend", "gloo", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["scaling"] == "weak"
     # the headline of an N > 1 run carries the whole record (uint16 LiDAR), and says so; the other payloads are timed beside it
