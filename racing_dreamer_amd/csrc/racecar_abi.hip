@@ -799,7 +799,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
     // symmetric square of variant 5 is limited by the nearest wall in any direction (a wall-grazing ray crawls).
     // Among the free rectangles (width = min over its rows of the free run towards sx) the one with the largest
     // geometric mean of exit distance for rays at 11.25, 33.75, 56.25 and 78.75 degrees inside the quadrant is kept
-    // (tools/analysis/skip_stats9.py: 4 % fewer trips than the arithmetic mean at 22.5 / 67.5 degrees, far fewer than squares
+    // (tools/analysis/skip_stats.py quadrant: 4 % fewer trips than the arithmetic mean at 22.5 / 67.5 degrees, far fewer than squares
     // or maximal area).  The choice only affects speed: any free rectangle gives the same result (see cast_ray_skip).
     // (built on the device by rc_build_quad_kernel after the upload, like the first-trip table: 0.67 -> 0.1 s of
     // rc_load_track for austria, 2.7 -> 0.4 s for gbr)

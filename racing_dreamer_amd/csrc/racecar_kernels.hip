@@ -782,7 +782,7 @@ __device__ __forceinline__ float cast_ray_cells(const uint8_t *cd, const RcTrack
 // certificate is a rectangle with the current cell at its corner (width | height << 8 in a uint16 per cell, one
 // plane per quadrant, chosen once per ray): it reaches as far as the walls ahead allow, where variant 5's
 // symmetric square is limited by the nearest wall in any direction.  Half the trips of variant 5
-// (tools/analysis/skip_stats9.py: 4.1 instead of 8.9 for the slowest ray of a wave on austria); same exit arithmetic.
+// (tools/analysis/skip_stats.py quadrant: 4.1 instead of 8.9 for the slowest ray of a wave on austria); same exit arithmetic.
 __device__ __forceinline__ int floor_to_int(float a) {         // (int)floorf(a) in one instruction
     int r;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(a));
@@ -941,9 +941,9 @@ __device__ __forceinline__ float min_with(float a, float hi) {
 // anywhere in the bin, both widened by a margin far above the traversal's rounding) - its far corners may lie
 // inside walls.  The exit arithmetic is unchanged: a ray of that bin visits only sector cells before it leaves
 // the rectangle, and those are free.  A ray heading down a diagonal straight thus crosses it in one trip where
-// fully free rectangles need one per stair of the wall.  tools/analysis/skip_stats12.py / 13.py: 3.1 trips for the slowest
+// fully free rectangles need one per stair of the wall.  tools/analysis/skip_stats.py firsttrip-slope / sector: 3.1 trips for the slowest
 // ray of a wave on austria against 4.1 with the quadrant planes alone; specialising the later trips as well
-// would need the big table in L2 and gain little more (tools/analysis/skip_stats11.py).
+// would need the big table in L2 and gain little more (tools/analysis/skip_stats.py firsttrip-angle).
 //
 // Bin parameters (set by rck_build_first_table): slope range in the bin's own frame (bins >= RC_FIRST_BINS / 2 are
 // y-dominant and handled with the axes swapped, slope = |dx / dy|) and 1/cos, 1/sin of two sample directions.

@@ -3,7 +3,7 @@ and tiled layouts of the per-quadrant rectangle table (one wave = 64 consecutive
 import sys
 import numpy as np
 sys.path.insert(0, '.'); sys.path.insert(0, 'tools/analysis')
-import skip_stats9 as s9
+import skip_stats as s9
 from oracle import racecar_oracle as ro, c_oracle
 from racing_dreamer_amd.track_assets import load_track
 
