@@ -305,12 +305,19 @@ def main():
     if via == "p2p" and every != 1:
         raise SystemExit("--gather-via p2p sends one record per gather (--gather-every 1)")
 
+    def p2p_close():
+        # exported memory must not be freed while a peer still maps it: everybody unmaps, THEN everybody frees
+        env.p2p_disconnect()
+        dist.barrier()
+        env.p2p_teardown()
+        env._p2p_mode = None
+
     def make_gatherer(mode):
         if mode == "none":
             return None
         if via == "p2p":                        # the peers' buffers depend on the payload: (re)connect per mode
             if getattr(env, "_p2p_mode", None) is not None:
-                env.p2p_teardown()
+                p2p_close()
             blob = env.p2p_setup(mode, rank, world)
             blobs = [None] * world
             dist.all_gather_object(blobs, blob)
@@ -412,8 +419,7 @@ def main():
             if g is not None:
                 g.close()
     if getattr(env, "_p2p_mode", None) is not None:
-        env.p2p_teardown()
-        env._p2p_mode = None
+        p2p_close()
 
     # N > 1: the payload DESIGN.md 6 recommends instead of per-step records - every rank keeps its records in a
     # device-resident ring and what crosses the links is the TRAINING BATCH: ShardedReplay.sample(50 windows x 50 steps)
@@ -433,7 +439,10 @@ def main():
         gen = torch.Generator(device=env.device)
         gen.manual_seed(1234 + rank)
         fields = ("lidar", "action", "reward", "discount")
-        out = rep.sample(batch, length, fields=fields, generator=gen)        # warm-up
+        for k in range(3):                            # warm-up: the sampler's kernels, the collectives' first use per dtype and size
+            ring.step_random(seed=1, step=step_no + k)
+            out = rep.sample(batch, length, fields=fields, generator=gen)
+        step_no += 3
         batch_bytes = sum(int(out[f].numel() * out[f].element_size()) for f in fields) // world
         n_leg = max(args.steps // 4, 5)
         env.sync()

@@ -256,13 +256,17 @@ int rc_gather_wait(rc_env *env, int32_t host_sync);
  *   rc_gather_p2p_wait         orders the handle's stream (host_sync != 0: and the host) behind the arrival of every
  *                   rank's record of the LAST issued gather and returns the slot: rank r's record at r * bytes.  The slot
  *                   stays valid until the call that issues the gather after next; a peer that does not take part within
- *                   RC_P2P_TIMEOUT_S (20 s) makes the host-synchronising wait return RC_ERR_COMM instead of blocking.
+ *                   RC_P2P_TIMEOUT_S (20 s) makes the host-synchronising wait return RC_ERR_COMM instead of blocking;
+ *   rc_p2p_disconnect          waits for this rank's copies and unmaps the peers' buffers; rc_p2p_teardown frees this rank's
+ *                   own.  Exported memory must not be freed while a peer still maps it: EVERY rank disconnects, the caller
+ *                   synchronises the ranks (a barrier of its own), THEN the ranks tear down (rc_destroy tears down too).
  * Every rank must issue the same sequence of gathers.  Ranks may share a GPU (functional tests) or sit on one each. */
 #define RC_P2P_EXPORT_BYTES 256
 int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *export_out, size_t bytes);
 int rc_p2p_connect(rc_env *env, const void *exports_world_x_256, size_t bytes);
 int rc_gather_trajectory_p2p(rc_env *env);
 int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size_t *gathered_bytes);
+int rc_p2p_disconnect(rc_env *env);
 int rc_p2p_teardown(rc_env *env);
 
 /* Re-point the output fields (everything rc_get returns except RC_F_ACTION_IN, which stays where it is) at

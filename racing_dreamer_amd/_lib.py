@@ -83,6 +83,7 @@ SYMBOLS = {
     "rc_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_gather_trajectory_p2p": (C.c_int, [C.c_void_p]),
     "rc_gather_p2p_wait": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
+    "rc_p2p_disconnect": (C.c_int, [C.c_void_p]),
     "rc_p2p_teardown": (C.c_int, [C.c_void_p]),
     "rc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),
     "rc_device_free": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -331,6 +331,11 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_copy_from_device(self._h, ptr, out.ctypes.data, nb))
         return out.reshape(self._p2p_world, -1)
 
+    def p2p_disconnect(self) -> None:
+        """Wait for this rank's copies and unmap the peers' buffers.  Every rank disconnects, the ranks synchronise (the
+        caller's barrier), then they `p2p_teardown()`: exported memory must not be freed while a peer still maps it."""
+        L.check(self._lib.rc_p2p_disconnect(self._h))
+
     def p2p_teardown(self) -> None:
         L.check(self._lib.rc_p2p_teardown(self._h))
 

@@ -1197,14 +1197,21 @@ int rc_gather_wait(rc_env *env, int32_t host_sync) {
 }
 
 // ---- peer-copy all-gather ------------------------------------------------------------------------------------------
-static void p2p_free(rc_env *env) {
+static void p2p_disconnect(rc_env *env) {          // my copies done, the peers' buffers unmapped; mine stay
     P2p *x = env->p2p;
     if (!x) return;
     (void)hipSetDevice(env->cfg.device);
     for (hipStream_t st : x->push) if (st) { (void)hipStreamSynchronize(st); }
     if (x->ctrl) (void)hipStreamSynchronize(x->ctrl);
-    for (char *d : x->peer_dst) if (d) (void)hipIpcCloseMemHandle(d);
-    for (uint32_t *f : x->peer_flags) if (f) (void)hipIpcCloseMemHandle(f);
+    for (char *&d : x->peer_dst) if (d) { (void)hipIpcCloseMemHandle(d); d = nullptr; }
+    for (uint32_t *&f : x->peer_flags) if (f) { (void)hipIpcCloseMemHandle(f); f = nullptr; }
+    x->connected = false;
+}
+
+static void p2p_free(rc_env *env) {
+    P2p *x = env->p2p;
+    if (!x) return;
+    p2p_disconnect(env);
     for (hipStream_t st : x->push) if (st) (void)hipStreamDestroy(st);
     if (x->ctrl) (void)hipStreamDestroy(x->ctrl);
     for (hipEvent_t e : {x->ev_ready, x->ev_go, x->ev_arrived, x->ev_local}) if (e) (void)hipEventDestroy(e);
@@ -1343,6 +1350,12 @@ int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size
     }
     if (gathered_dev) *gathered_dev = x->dst + (size_t)((x->issued - 1u) & 1u) * x->world * x->bytes;
     if (gathered_bytes) *gathered_bytes = (size_t)x->world * x->bytes;
+    return RC_OK;
+}
+
+int rc_p2p_disconnect(rc_env *env) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    p2p_disconnect(env);
     return RC_OK;
 }
 

@@ -220,7 +220,9 @@ def _p2p_rank(rank, world, port, total, steps, repeat, q):
                 else:
                     env.set_arena(arenas[(k + 1) & 1])
             got[mode].append(env.gathered_p2p_host().copy())
-            env.p2p_teardown()
+            env.p2p_disconnect()                # every rank unmaps its peers' buffers ...
+            dist.barrier()
+            env.p2p_teardown()                  # ... before any rank frees its own
             env.close()
             dist.barrier()
         q.put((rank, sh.num_envs, got))
