@@ -315,13 +315,13 @@ def main():
     def make_gatherer(mode):
         if mode == "none":
             return None
-        if via == "p2p":                        # the peers' buffers depend on the payload: (re)connect per mode
-            if getattr(env, "_p2p_mode", None) is not None:
-                p2p_close()
+        if via == "p2p":                        # buffers and mappings are made once; later legs only switch the payload
+            first = getattr(env, "_p2p_mode", None) is None
             blob = env.p2p_setup(mode, rank, world)
-            blobs = [None] * world
-            dist.all_gather_object(blobs, blob)
-            env.p2p_connect(blobs)
+            if first:
+                blobs = [None] * world
+                dist.all_gather_object(blobs, blob)
+                env.p2p_connect(blobs)
         return Gatherer(env, mode, every, via, dist)
 
     gather = make_gatherer(gather_mode)

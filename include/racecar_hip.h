@@ -246,15 +246,19 @@ int rc_gather_wait(rc_env *env, int32_t host_sync);
 /* ---- The same all-gather as DIRECT PEER COPIES (on the xGMI full mesh each rank's record should cross
  * each link once - N - 1 concurrent copies into the peers' buffers - where a ring passes it on N - 1 times).  No RCCL:
  * hipIpc memory handles, one copy stream per peer, sequence flags in uncached device memory.
- *   rc_p2p_setup    allocates this rank's destination (two slots of world x rc_gather_bytes(mode)) and flag block and
+ *   rc_p2p_setup    allocates this rank's destination - two slots of `world` entries, each entry sized for the LARGEST
+ *                   payload (rc_gather_bytes(RC_GATHER_FULL), rounded up to 256: rc_p2p_stride) - and flag block, and
  *                   writes an RC_P2P_EXPORT_BYTES blob; the caller hands every rank's blob to every rank (file, socket,
- *                   MPI, torch.distributed - the library does not care), rank r's at offset r * RC_P2P_EXPORT_BYTES;
- *   rc_p2p_connect  opens the peers' buffers;
+ *                   MPI, torch.distributed - the library does not care), rank r's at offset r * RC_P2P_EXPORT_BYTES.
+ *                   Called again with another mode it only switches the payload (same buffers, same blob, sequence
+ *                   numbers run on; every rank switches at the same gather);
+ *   rc_p2p_connect  opens the peers' buffers (a no-op once connected);
  *   rc_gather_trajectory_p2p   sends the last step's record (the source of `mode`, see rc_gather_trajectory; the caller
  *                   double-buffers it the same way) into slot k & 1 of every rank, k = 0, 1, ... counting the calls:
  *                   queued behind the work on the handle's stream, runs on streams of its own;
  *   rc_gather_p2p_wait         orders the handle's stream (host_sync != 0: and the host) behind the arrival of every
- *                   rank's record of the LAST issued gather and returns the slot: rank r's record at r * bytes.  The slot
+ *                   rank's record of the LAST issued gather and returns the slot (*bytes = world x stride): rank r's record
+ *                   - rc_gather_bytes(mode) bytes of it - at r * stride, stride = *bytes / world.  The slot
  *                   stays valid until the call that issues the gather after next; a peer that does not take part within
  *                   RC_P2P_TIMEOUT_S (20 s) makes the host-synchronising wait return RC_ERR_COMM instead of blocking;
  *   rc_p2p_disconnect          waits for this rank's copies and unmaps the peers' buffers; rc_p2p_teardown frees this rank's
@@ -299,9 +303,7 @@ int rc_scan_kernel_name(rc_env *env, char *out, size_t bytes);
  * max(w, h) * 2^value cells instead of 2^-21 - tests/test_gpu_parity.py narrows it to show that its corner-aimed rays
  * detect a band below the rounding bound.  Takes effect immediately (also after rc_load_track). */
 enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, RC_DBG_BAND_LOG2 = 3,
-       RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiments: bit 1 plain instead of non-temporal stores;
-                                       bit 3 the round-2 kernel (four waves per car), whose bits 0 / 2 pick row-major
-                                       runs / results transposed through LDS */
+       RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiment: bit 1 = plain instead of non-temporal stores */
        RC_DBG_SCAN_BOUNDED = 5,     /* != 0: the scan runs the build whose trip loop carries a trip budget (see below) */
        RC_DBG_COUNT = 6 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);

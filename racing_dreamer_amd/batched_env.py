@@ -300,8 +300,9 @@ class BatchedRaceEnv:
 
     # ---- the same gather as direct peer copies (rc_gather_trajectory_p2p: hipIpc handles, one copy stream per peer) ----
     def p2p_setup(self, mode: str, rank: int, world: int) -> bytes:
-        """Allocate this rank's destination and flags for peer-copy gathers of `mode`; returns the 256-byte blob the other
-        ranks need.  Hand every rank's blob (in rank order) to `p2p_connect` on every rank."""
+        """Allocate this rank's destination and flags for peer-copy gathers (sized for the largest payload) and select
+        `mode`; returns the 256-byte blob the other ranks need.  Hand every rank's blob (in rank order) to `p2p_connect`
+        on every rank.  Called again it only switches the payload: same buffers, same blob."""
         buf = C.create_string_buffer(L.P2P_EXPORT_BYTES)
         L.check(self._lib.rc_p2p_setup(self._h, L.GATHER_MODES[mode], int(rank), int(world), buf, L.P2P_EXPORT_BYTES))
         self._p2p_mode, self._p2p_world = mode, int(world)
@@ -329,7 +330,8 @@ class BatchedRaceEnv:
         ptr, nb = self.gather_p2p_wait(host_sync=True)
         out = np.empty(nb, np.uint8)
         L.check(self._lib.rc_copy_from_device(self._h, ptr, out.ctypes.data, nb))
-        return out.reshape(self._p2p_world, -1)
+        # the slot's entries are sized for the largest payload: the current one fills the head of each
+        return out.reshape(self._p2p_world, -1)[:, :self.gather_bytes(self._p2p_mode)]
 
     def p2p_disconnect(self) -> None:
         """Wait for this rank's copies and unmap the peers' buffers.  Every rank disconnects, the ranks synchronise (the

@@ -162,8 +162,10 @@ static_assert(sizeof(P2pExport) == RC_P2P_EXPORT_BYTES, "export blob size");
 
 struct P2p {
     int rank = 0, world = 0, mode = 0;
-    size_t bytes = 0;              // one rank's record
-    char *dst = nullptr;           // [2][world][bytes], mine
+    size_t bytes = 0;              // one rank's record in the current mode
+    size_t cap = 0;                // ... and in the largest one (RC_GATHER_FULL): what the slots are sized for
+    P2pExport blob{};              // what rc_p2p_setup handed out
+    char *dst = nullptr;           // [2][world][cap], mine
     uint32_t *flags = nullptr;     // arrived[64] | released[64] | timeouts, mine (uncached)
     std::vector<char *> peer_dst;          // peers' destinations, opened (null for me)
     std::vector<uint32_t *> peer_flags;    // peers' flag blocks, opened (null for me)
@@ -282,9 +284,7 @@ void set_launch_geometry(rc_env *env) {
         return (int)std::min<long long>((items + threads - 1) / threads, (long long)li.n_cu * wg_per_cu);
     };
     const long long rays = (long long)env->n_cars * RC_N_BEAMS;
-    const long long quads = (long long)env->n_cars * RC_PATCH * (RC_PATCH / 16);   // 16 pixels per lane
     li.ray_blocks = blocks_for(li.raycast_variant >= 4 ? (size_t)1 : li.raycast_variant == 3 ? li.lds_bytes_packed : (li.raycast_variant != 0 ? li.lds_bytes_skip : li.lds_bytes), rays, li.ray_threads);
-    li.patch_blocks = blocks_for(li.lds_bytes ? li.lds_bytes + RC_PATCH_STAGE_BYTES : 0, quads, li.patch_threads);
     li.patch_variant = env->dbg[RC_DBG_PATCH_VARIANT];
     // tuning knobs for experiments (rc_debug_set; all zero in production): workgroup size / workgroups per CU of the LDS-free scan
     if (li.raycast_variant == 7) {
@@ -688,15 +688,10 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         li.car_threads = 64;
         li.car_split = 1;
         li.ray_threads = 1024;
-        li.patch_threads = 1024;
         env->has_track = true;
         set_launch_geometry(env);
         env->was_reset = false;
     };
-    const bool fits_patch = align_up(nwords * 4 + 4, 64) + RC_PATCH_STAGE_BYTES <= 160 * 1024;
-    if (!fits_patch && env->params.render_patch)
-        return fail(RC_ERR_INVALID, "track bitmap %zu B (+ %d B of staging) does not fit the 160 KiB LDS (needed for obs_type lidar_occupancy)",
-                    align_up(nwords * 4 + 4, 64), RC_PATCH_STAGE_BYTES);
     for (auto it = g_track_cache.begin(); it != g_track_cache.end();)       // entries whose tables are gone
         it = it->second.expired() ? g_track_cache.erase(it) : std::next(it);
     {
@@ -713,7 +708,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
             // (a different track under the same 64-bit key: build its tables; the map keeps the newer one)
         }
     }
-    const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_kernel)
+    const size_t bm_bytes = align_up(nwords * 4 + 4, 64);   // at least one all-zero word behind the bitmap (rc_patch_car_kernel)
     // The lidar_occupancy render and the scan's early forms (variants 0-3) keep the whole bitmap in the 160 KiB LDS;
     // the default scan does not, so a larger map is fine as long as the patch is not asked for.
     const bool fits_lds = bm_bytes <= 160 * 1024;
@@ -858,7 +853,7 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         // small track loaded after a large one would make the large one's launches fail
         static std::map<int, size_t> lds_limit;
         size_t &lim = lds_limit[env->cfg.device];
-        const size_t need = std::min<size_t>(160 * 1024, std::max(std::max(tt->lds_bytes + RC_PATCH_STAGE_BYTES, tt->lds_bytes_skip), tt->lds_bytes_packed));
+        const size_t need = std::min<size_t>(160 * 1024, std::max(std::max(tt->lds_bytes, tt->lds_bytes_skip), tt->lds_bytes_packed));
         if (need > lim || lim == 0) {
             HIP_TRY(rck_set_lds_limits(std::max(need, lim)));
             lim = std::max(need, lim);
@@ -1226,30 +1221,41 @@ int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *e
     if (bytes < RC_P2P_EXPORT_BYTES) return fail(RC_ERR_INVALID, "export buffer must hold %d bytes", RC_P2P_EXPORT_BYTES);
     if (world < 1 || world > RC_P2P_MAX_RANKS || rank < 0 || rank >= world)
         return fail(RC_ERR_INVALID, "rank %d outside world of %d (at most %d ranks)", rank, world, RC_P2P_MAX_RANKS);
-    if (env->p2p) return fail(RC_ERR_INVALID, "the handle already has a peer-copy gather: rc_p2p_teardown first");
     const size_t n = rc_gather_bytes(env, mode);
     if (n == 0) return fail(RC_ERR_INVALID, "unknown gather mode %d", mode);
     HIP_TRY(hipSetDevice(env->cfg.device));
+    if (P2p *x = env->p2p) {
+        // Already set up: only the payload changes.  The buffers, their exports and the peers' mappings stay - they are
+        // sized for the largest payload, and exporting fresh allocations again and again is what the runtime likes least
+        // (a re-export at a recycled address failed with "invalid argument" now and then).  Sequence numbers run on.
+        if (x->rank != rank || x->world != world) return fail(RC_ERR_INVALID, "set up as rank %d of %d: rc_p2p_teardown first", x->rank, x->world);
+        for (hipStream_t st : x->push) HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(x->ctrl));
+        x->mode = mode; x->bytes = n;
+        std::memcpy(export_out, &x->blob, sizeof(x->blob));
+        return RC_OK;
+    }
     P2p *x = new (std::nothrow) P2p();
     if (!x) return fail(RC_ERR_NOMEM, "out of host memory");
     env->p2p = x;
     x->rank = rank; x->world = world; x->mode = mode; x->bytes = n;
+    x->cap = align_up(std::max(n, env->layout.slab_bytes), 256);
     x->peer_dst.assign(world, nullptr);
     x->peer_flags.assign(world, nullptr);
     x->push.assign(world, nullptr);
-#define P2P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { p2p_free(env); return fail(RC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e)); } } while (0)
-    P2P_TRY(hipMalloc((void **)&x->dst, 2 * (size_t)world * n));
+#define P2P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { p2p_free(env); return fail(RC_ERR_HIP, "%s failed: %s (payload %zu B x %d ranks)", #expr, hipGetErrorString(_e), x ? n : n, world); } } while (0)
+    P2P_TRY(hipMalloc((void **)&x->dst, 2 * (size_t)world * x->cap));
     // the flags are written by other GPUs' kernels and polled by this one's: uncached memory, so that a poll sees them
     P2P_TRY(hipExtMallocWithFlags((void **)&x->flags, 4096, hipDeviceMallocUncached));
     P2P_TRY(hipMemset(x->flags, 0, 4096));
     for (int p = 0; p < world; ++p) P2P_TRY(hipStreamCreateWithFlags(&x->push[p], hipStreamNonBlocking));
     P2P_TRY(hipStreamCreateWithFlags(&x->ctrl, hipStreamNonBlocking));
     for (hipEvent_t *e : {&x->ev_ready, &x->ev_go, &x->ev_arrived, &x->ev_local}) P2P_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    P2pExport ex;
+    P2pExport &ex = x->blob;
     std::memset(&ex, 0, sizeof(ex));
     P2P_TRY(hipIpcGetMemHandle(&ex.dst, x->dst));
     P2P_TRY(hipIpcGetMemHandle(&ex.flags, x->flags));
-    ex.bytes = n; ex.rank = rank; ex.world = world; ex.mode = mode; ex.pid = (int32_t)getpid();
+    ex.bytes = x->cap; ex.rank = rank; ex.world = world; ex.mode = 0; ex.pid = (int32_t)getpid();
     P2P_TRY(hipDeviceGetPCIBusId(ex.pci, sizeof(ex.pci), env->cfg.device));
     std::memcpy(export_out, &ex, sizeof(ex));
     return RC_OK;
@@ -1259,15 +1265,15 @@ int rc_p2p_connect(rc_env *env, const void *exports, size_t bytes) {
     if (!env || !exports) return fail(RC_ERR_INVALID, "NULL argument");
     P2p *x = env->p2p;
     if (!x) return fail(RC_ERR_INVALID, "rc_p2p_setup has not been called on this handle");
-    if (x->connected) return fail(RC_ERR_INVALID, "already connected");
+    if (x->connected) return RC_OK;                      // (a mode switch: the peers' buffers are mapped already)
     if (bytes < (size_t)x->world * RC_P2P_EXPORT_BYTES) return fail(RC_ERR_INVALID, "need %d export blobs of %d bytes", x->world, RC_P2P_EXPORT_BYTES);
     HIP_TRY(hipSetDevice(env->cfg.device));
     for (int p = 0; p < x->world; ++p) {
         P2pExport ex;
         std::memcpy(&ex, (const char *)exports + (size_t)p * RC_P2P_EXPORT_BYTES, sizeof(ex));
-        if (ex.rank != p || ex.world != x->world || ex.mode != x->mode || ex.bytes != x->bytes)
-            return fail(RC_ERR_INVALID, "export blob %d does not match (rank %d, world %d, mode %d, %llu bytes)", p, ex.rank, ex.world, ex.mode,
-                        (unsigned long long)ex.bytes);
+        if (ex.rank != p || ex.world != x->world || ex.bytes != x->cap)
+            return fail(RC_ERR_INVALID, "export blob %d does not match (rank %d, world %d, %llu bytes per slot entry; mine %zu)", p, ex.rank, ex.world,
+                        (unsigned long long)ex.bytes, x->cap);
         if (p == x->rank) continue;
         // a peer on another GPU: let this device's copy engines and kernels reach its memory
         int pdev = -1;
@@ -1294,7 +1300,8 @@ int rc_gather_trajectory_p2p(rc_env *env) {
     if (rc) return rc;
     HIP_TRY(hipSetDevice(env->cfg.device));
     const uint32_t k = x->issued, seq = k + 1u;
-    const size_t slot_off = (size_t)(k & 1u) * x->world * n, mine = slot_off + (size_t)x->rank * n;
+    // slot k & 1 of every rank: world entries of `cap` bytes, of which the current payload fills the first n
+    const size_t slot_off = (size_t)(k & 1u) * x->world * x->cap, mine = slot_off + (size_t)x->rank * x->cap;
     // everything below is ordered behind what the env's stream holds now: the step that produced the record, and the
     // caller's use of the slot that gather k overwrites (the buffer of gather k - 2)
     HIP_TRY(hipEventRecord(x->ev_ready, env->stream));
@@ -1348,8 +1355,8 @@ int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size
         HIP_TRY(hipMemcpy(&late, x->timeouts(), sizeof(late), hipMemcpyDeviceToHost));
         if (late != 0) return fail(RC_ERR_COMM, "peer-copy gather: %u flag wait(s) timed out after %.0f s (a peer did not post)", late, (double)RC_P2P_TIMEOUT_S);
     }
-    if (gathered_dev) *gathered_dev = x->dst + (size_t)((x->issued - 1u) & 1u) * x->world * x->bytes;
-    if (gathered_bytes) *gathered_bytes = (size_t)x->world * x->bytes;
+    if (gathered_dev) *gathered_dev = x->dst + (size_t)((x->issued - 1u) & 1u) * x->world * x->cap;
+    if (gathered_bytes) *gathered_bytes = (size_t)x->world * x->cap;
     return RC_OK;
 }
 

@@ -4,7 +4,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define RC_PATCH_STAGE_BYTES 16384              // rc_patch_kernel: 1 024 lanes x 16 bytes of rendered pixels, transposed through LDS
 #define RC_NSTEP_MAX 16                        // longest n_step_progress window (sub-steps)
 #ifndef RC_STAMP_SLOTS
 #define RC_STAMP_SLOTS 32                       // uint64 per wave of the instrumented scan (include/racecar_hip.h)
@@ -90,11 +89,9 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
     int32_t car_threads;         // workgroup size of the one-wave-per-car scan (variant 7): 64 = one wave per workgroup
     int32_t car_split;           // waves sharing one car's 17 rounds of 64 beams (1 for large batches)
     int32_t scan_guarded;        // 1: the scan runs the build whose trip loop is bounded (validation band, RC_DBG_SCAN_BOUNDED)
-    int32_t patch_blocks, patch_threads;
     unsigned long long *scan_stamps;   // rc_debug_scan_stamps: device buffer of the instrumented scan, else null
     int32_t scan_stamp_waves;
-    int32_t patch_variant;       // experiment bits of the lidar_occupancy render (rc_debug_set): 1 row-major runs, 2 plain
-                                 // stores, 4 results transposed through LDS and stored as consecutive bytes
+    int32_t patch_variant;       // experiment bits of the lidar_occupancy render (rc_debug_set): 2 = plain instead of non-temporal stores
     size_t lds_bytes;            // occupancy bitmap (also the patch kernel's drivable bitmap)
     size_t lds_bytes_skip;       // bitmap + free-block table (raycast variants 1, 2); 0 if it does not fit
     size_t lds_bytes_packed;     // packed block table only (raycast variant 3); 0 if it does not fit / blocks are 8x8

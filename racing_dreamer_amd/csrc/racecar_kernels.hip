@@ -11,7 +11,7 @@
 //                       LDS or tables through L1/L2), kept for the parity tests that cross-check them
 //   rc_build_quad_kernel, rc_build_first_kernel  build the quadrant planes and the first-trip table on the device
 //                       at rc_load_track
-//   rc_patch_kernel     lidar_occupancy 64x64 ego patch (H11), drivable bitmap staged in LDS
+//   rc_patch_car_kernel lidar_occupancy 64x64 ego patch (H11), one wave per car, drivable bitmap staged in LDS
 //   rc_reset_kernel     masked reset from the centerline spawn table with Philox4x32-10 (H6)
 //
 // Numerics: fp32, one IEEE operation per written operator (-ffp-contract=off), same order as
@@ -1710,125 +1710,8 @@ __device__ __forceinline__ void patch_run(const __attribute__((address_space(3))
     }
 }
 
-__global__ __launch_bounds__(1024) void rc_patch_kernel(RcParams p, int total_items, int variant) {
-    extern __shared__ uint32_t lds_words[];
-    const RcTrackDev &t = p.trk;
-    const int nwords = t.h * t.pitch;
-    stage_bitmap(lds_words, t.drv_words, nwords + 1);        // + the all-zero word behind the bitmap (rc_load_track)
-    const uint32_t zero_addr = (uint32_t)nwords * 4u;        // where rejected taps read
-    typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-    v4u_t *out128 = reinterpret_cast<v4u_t *>(p.out.patch);
-    const uint32_t pitch_b = (uint32_t)t.pitch * 4u;         // bytes per bitmap row (<= 512)
-    const uint32_t xmax = ((uint32_t)(t.w - 1) << 16) | 0xffffu, ymax = ((uint32_t)(t.h - 1) << 16) | 0xffffu;
-    // The bitmap is the kernel's only LDS object, so it starts at LDS address 0 (checked on the host: rck_set_lds_limits
-    // refuses a build in which the kernel has static LDS) and a tap's byte offset IS its LDS address: indexing a
-    // null-based LDS pointer saves the add of the (zero) base the compiler otherwise emits per tap.
-    typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
-    const lds_u8_ptr lds_bytes = (lds_u8_ptr)(uint32_t)0;
-    // Experiment (patch_variant bit 2): the 16 bytes per lane transposed through LDS before they are stored.  A wave's
-    // runs are 16-byte pieces of many rows (the corner blocks), and pieces of one 64-byte line written by different
-    // waves cost HBM a partial write each (measured: 1.39 x the algorithmic bytes against 1.07 x with row-major runs);
-    // sending the workgroup's 1 024 results through LDS in image order makes them 16 KB of consecutive bytes - and the
-    // two workgroup barriers per iteration that needs, between waves of unequal length, cost more than the partial
-    // writes: 0.1255 ms against 0.1088 (profiles/r02_b_patch_lds_transposition_experiment.txt).  Default: every lane stores its own piece.
-    const uint32_t stage_base = ((uint32_t)(nwords + 1) * 4u + 15u) & ~15u;
-    typedef __attribute__((address_space(3))) v4u_t *lds_v4_ptr;
-    const lds_v4_ptr stage = (lds_v4_ptr)(uintptr_t)stage_base;
-    for (unsigned base = blockIdx.x * blockDim.x; base < (unsigned)total_items; base += gridDim.x * blockDim.x) {
-        const unsigned q = base + threadIdx.x;
-        const bool live = q < (unsigned)total_items;        // (no early exit: every lane meets the barriers below)
-        // 256 runs of 16 pixels per car: a wave's 64 runs belong to ONE car, so its state comes through the scalar
-        // unit (its own counter) - as vector loads they shared the in-order counter with the previous item's store and
-        // every item waited for that store's acknowledgement.
-        // Which runs a wave gets decides how often it needs the tested loop: the pixels the 220-cell window cuts
-        // off lie in the four corners of the patch, at most 15.8 pixels from its edges whatever the heading, so ONE wave
-        // of a car takes the four 16 x 16 corner blocks and is the only one that can need it; the others take the
-        // top / bottom bands between the corners and the 32 middle rows.
-        const unsigned car = __builtin_amdgcn_readfirstlane(q >> 8);
-        // which quarter of the car's patch this wave renders: rotated by the car index, so that the four corner waves of
-        // a workgroup's four cars sit on four different SIMDs (a workgroup's waves go to the SIMDs cyclically: with a
-        // fixed assignment all corner waves - the ones that may need the longer loop - shared ONE SIMD, and the
-        // persistent loop ran at that SIMD's pace)
-        const unsigned wv = __builtin_amdgcn_readfirstlane(((q >> 6) + car) & 3u);
-        const unsigned j = q & 63u;
-        int row, c0;
-        if (variant & 1) {                       // experiment: plain row-major runs (wave w = rows 16 w .. 16 w + 15)
-            row = (int)((wv << 4) | (j >> 2));
-            c0 = (int)(j & 3u) * 16;
-        } else if (wv == 0) {
-            row = (int)(j & 15u) + ((j & 32u) ? 48 : 0);
-            c0 = (j & 16u) ? 48 : 0;
-        } else if (wv == 1) {
-            row = (int)(j & 15u) + ((j & 32u) ? 48 : 0);
-            c0 = (j & 16u) ? 32 : 16;
-        } else {
-            row = 16 + (int)(((wv - 2u) << 4) | (j >> 2));
-            c0 = (int)(j & 3u) * 16;
-        }
-        uint32_t words[4] = {0u, 0u, 0u, 0u};
-        const unsigned scar = live ? car : 0u;                // (a wave is all live or all past the end)
-        int icx, icy;
-        cell_of(t, p.st.x[scar], p.st.y[scar], icx, icy);
-        icx = __builtin_amdgcn_readfirstlane(icx);
-        icy = __builtin_amdgcn_readfirstlane(icy) + 1;
-        // a car tens of thousands of cells away from the grid (a diverged state) sees nothing; it also keeps X, Y in range
-        const bool sane = (unsigned)(icx + 16384) < 32768u && (unsigned)(icy + 16384) < 32768u;
-        if (live && !p.st.fresh[scar] && sane) { // reset observation is all zeros, dreamer/wrappers.py:413
-            const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.ct[scar] * RCS_PATCH_STEP_Q16));
-            const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(p.st.st[scar] * RCS_PATCH_STEP_Q16));
-            // tap of this run's first pixel, in cells << 16, the start cell folded in: (X >> 16, Y >> 16) = (ix, iy)
-            const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;
-            const int X = x00 + c0 * a + row * b, Y = y00 + c0 * b - row * a;
-            // the reference's [-110, 110) crop window around the start cell
-            const int lx = icx - RCS_PATCH_WINDOW_I, ly = icy - RCS_PATCH_WINDOW_I;
-            const uint32_t span = 2 * RCS_PATCH_WINDOW_I - 1;
-            const int Xe = X + 15 * a, Ye = Y + 15 * b;
-            const bool ends_ok = (uint32_t)((X >> 16) - lx) <= span && (uint32_t)((Y >> 16) - ly) <= span &&
-                                 (uint32_t)((Xe >> 16) - lx) <= span && (uint32_t)((Ye >> 16) - ly) <= span;
-            // window inside the grid (wave-uniform: a property of the car)?  then no tap can leave the grid
-            const bool inside = lx >= 0 && ly >= 0 && lx + (int)span <= t.w - 1 && ly + (int)span <= t.h - 1;
-            if (__builtin_amdgcn_ballot_w64(!ends_ok) == 0) {
-                // the two end taps of every run of the wave are inside the window, which is convex: so is every tap
-                if (inside) patch_run<false>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
-                else patch_run<true>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, words);
-            } else {
-                int Xk = X, Yk = Y;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    const unsigned long long ok = cmp_le_u32((uint32_t)((Xk >> 16) - lx), span) & cmp_le_u32((uint32_t)((Yk >> 16) - ly), span);
-                    const uint32_t xc = min_u32((uint32_t)Xk, xmax), yc = min_u32((uint32_t)Yk, ymax);
-                    const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19);
-                    const uint32_t byte = lds_bytes[select_mask(ok, addr, zero_addr)];
-                    const uint32_t bit = bfe_u32(byte, bfe_u32(xc, 16, 3), 1);
-                    words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
-                    Xk += a;
-                    Yk += b;
-                }
-            }
-        }
-        const v4u_t px = {words[0], words[1], words[2], words[3]};
-        const unsigned in_car = (unsigned)row * 4u + ((unsigned)c0 >> 4);              // 16-byte piece of the car's 4 KB patch
-        if (!(variant & 4)) {                     // default: every lane stores its own piece
-            if (live) {
-                v4u_t *dst = out128 + ((size_t)car * 256u + in_car);
-                if (variant & 2) *dst = px;
-                else __builtin_nontemporal_store(px, dst);
-            }
-        } else {
-            stage[(threadIdx.x & ~255u) + in_car] = px;       // experiment: transposed through LDS (see above)
-            __syncthreads();
-            if (live) {
-                const v4u_t lin = stage[threadIdx.x];
-                if (variant & 2) out128[q] = lin;                                      // experiment: plain stores
-                else __builtin_nontemporal_store(lin, out128 + q);
-            }
-            __syncthreads();                      // the next iteration's pieces overwrite the staging area
-        }
-    }
-}
-
-// ---- lidar_occupancy, ONE WAVE PER CAR (default since round 3; rc_patch_kernel above is the round-2 form, kept behind
-// patch_variant bit 3 for A/B runs) ------------------------------------------------------------------------------
+// ---- lidar_occupancy, ONE WAVE PER CAR -----------------------------------------------------------------------------
+// (Round 3.  The round-2 kernel, four waves per car, is in the history: EXPERIMENTS.md I.1 has the A/B.)
 // Same taps, same results; what changed is who renders what.  The round-2 kernel gave a car to four waves of 64 runs
 // (16 pixels each): every wave paid the per-car setup - three dependent global round trips for pose, flag and heading,
 // four 32-bit multiplies, the window tests: a third of its instructions - and the wave that held the four corner blocks
@@ -2538,14 +2421,13 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
     SET((rc_raycast_kernel<2, 6>))
     SET((rc_raycast_kernel<3, 6>))
     SET((rc_raycast_kernel<4, 6>))
-    SET(rc_patch_kernel)
     SET(rc_patch_car_kernel<true>)
     SET(rc_patch_car_kernel<false>)
 #undef SET
-    // rc_patch_kernel and rc_raycast_car_kernel address their dynamic LDS from LDS address 0: true only while they have
+    // rc_patch_car_kernel and rc_raycast_car_kernel address their dynamic LDS from LDS address 0: true only while they have
     // no static LDS
     hipFuncAttributes fa;
-    for (const void *k : {reinterpret_cast<const void *>(rc_patch_kernel), reinterpret_cast<const void *>(rc_patch_car_kernel<true>), reinterpret_cast<const void *>(rc_patch_car_kernel<false>), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel),
+    for (const void *k : {reinterpret_cast<const void *>(rc_patch_car_kernel<true>), reinterpret_cast<const void *>(rc_patch_car_kernel<false>), reinterpret_cast<const void *>(rc_raycast_car_stamps_kernel),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<1, false, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, false, false>),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<3, false, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<4, false, false>),
                           reinterpret_cast<const void *>(rc_raycast_car_kernel<1, true, false>), reinterpret_cast<const void *>(rc_raycast_car_kernel<2, true, false>),
@@ -2624,17 +2506,12 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 }
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
-    const int total = p.n_cars * RC_PATCH * (RC_PATCH / 16);
-    if (li.patch_variant & 8) {           // the round-2 kernel (four waves per car), kept for A/B runs
-        launch(rc_patch_kernel, dim3(li.patch_blocks), dim3(li.patch_threads), li.lds_bytes + RC_PATCH_STAGE_BYTES, s, p, total, li.patch_variant);
-    } else {
-        // persistent 16-wave workgroups, the bitmap staged once per workgroup; as many as stay resident
-        const int per_cu = li.lds_bytes <= 80 * 1024 ? 2 : 1;
-        const long long need = ((long long)p.n_cars + 15) / 16, resident = (long long)li.n_cu * per_cu;
-        const int blocks = (int)(need < resident ? need : resident);
-        if (li.patch_variant & 2) launch(rc_patch_car_kernel<false>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);     // experiment: plain stores
-        else launch(rc_patch_car_kernel<true>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);
-    }
+    // persistent 16-wave workgroups, the bitmap staged once per workgroup; as many as stay resident
+    const int per_cu = li.lds_bytes <= 80 * 1024 ? 2 : 1;
+    const long long need = ((long long)p.n_cars + 15) / 16, resident = (long long)li.n_cu * per_cu;
+    const int blocks = (int)(need < resident ? need : resident);
+    if (li.patch_variant & 2) launch(rc_patch_car_kernel<false>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);     // experiment: plain stores
+    else launch(rc_patch_car_kernel<true>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);
     return hipGetLastError();
 }
 

@@ -182,11 +182,16 @@ def test_two_hip_shards_gather_the_unsharded_oracle_run():
                     assert np.array_equal(q16, ro.quantise_lidar_u16(o["lidar"])), (rank, k)
 
 
+P2P_MODES = ("full-u16", "full", "summary")
+
+
 def _p2p_rank(rank, world, port, total, steps, repeat, q):
-    """One rank of the peer-copy gather: the record of every step sent with rc_gather_trajectory_p2p - hipIpc handles
-    exchanged once (through gloo here: the library does not care how), then per step one copy per peer into the peer's
-    own buffer - all three payloads, the fp32 / summary ones read in place from ALTERNATING arenas (the source of gather
-    k must survive step k + 1: what ADVICE r2 found missing in the abi path of bench.py)."""
+    """One rank of the peer-copy gather: ONE env, one continuous rollout, the record of every step sent with
+    rc_gather_trajectory_p2p - hipIpc handles exchanged once (through gloo here: the library does not care how), then per
+    step one copy per peer into the peer's own buffer - `steps` steps with each payload in turn (the payload is switched
+    in mid-run, as bench.py's legs do: same buffers, same export, sequence numbers run on).  The fp32 / summary payloads are
+    read in place from ALTERNATING arenas: the source of gather k must survive step k + 1 (what ADVICE r2 found missing in
+    the abi path of bench.py), so the result of gather k is read only after step k + 1 has been queued."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -197,34 +202,38 @@ def _p2p_rank(rank, world, port, total, steps, repeat, q):
         from racing_dreamer_amd.batched_env import BatchedRaceEnv
         from racing_dreamer_amd.distributed import shard_envs
         sh = shard_envs(total, rank, world)
-        got = {}
-        for mode in ("full-u16", "full", "summary"):
-            env = BatchedRaceEnv("columbia", sh.num_envs, 1, auto_reset=True, first_env=sh.first_env)
-            blobs = [None] * world
-            dist.all_gather_object(blobs, env.p2p_setup(mode, rank, world))
-            env.p2p_connect(blobs)
-            second = torch.zeros(env.arena_nbytes + 64, dtype=torch.uint8, device=env.device)
-            second = second[(-second.data_ptr()) % 64:][:env.arena_nbytes]
-            arenas = [None, second]
+        env = BatchedRaceEnv("columbia", sh.num_envs, 1, auto_reset=True, first_env=sh.first_env)
+        blobs = [None] * world
+        first = env.p2p_setup(P2P_MODES[0], rank, world)
+        dist.all_gather_object(blobs, first)
+        env.p2p_connect(blobs)
+        second = torch.zeros(env.arena_nbytes + 64, dtype=torch.uint8, device=env.device)
+        second = second[(-second.data_ptr()) % 64:][:env.arena_nbytes]
+        arenas = [None, second]
+        env.reset(mode="random", seed=4)
+        got = {m: [] for m in P2P_MODES}
+        k = 0
+        for mode in P2P_MODES:
+            assert env.p2p_setup(mode, rank, world) == first       # a payload switch: the same export blob
             if mode == "full-u16":
                 env.enable_compact(buffers=2)
-            env.reset(mode="random", seed=4)
-            got[mode] = []
-            for k in range(steps):
-                env.step_random(seed=1, step=k, repeat=repeat)     # writes source buffer k & 1 ...
-                if k > 0:                                          # ... while the gather of record k - 1 may still be
-                    got[mode].append(env.gathered_p2p_host().copy())   # reading the other one: read its result only now
-                env.gather_p2p()                                   # record k: asynchronous, behind step k
+            else:
+                env.disable_compact()
+            for j in range(steps):
+                env.step_random(seed=1, step=k, repeat=repeat)      # writes source buffer k & 1 ...
+                if j > 0:                                           # ... while the gather of record k - 1 may still be
+                    got[mode].append(env.gathered_p2p_host().copy())    # reading the other one: read its result only now
+                env.gather_p2p()                                    # record k: asynchronous, behind step k
+                k += 1
                 if mode == "full-u16":
                     env.rotate_compact()
                 else:
-                    env.set_arena(arenas[(k + 1) & 1])
+                    env.set_arena(arenas[k & 1])
             got[mode].append(env.gathered_p2p_host().copy())
-            env.p2p_disconnect()                # every rank unmaps its peers' buffers ...
-            dist.barrier()
-            env.p2p_teardown()                  # ... before any rank frees its own
-            env.close()
-            dist.barrier()
+        env.p2p_disconnect()                    # every rank unmaps its peers' buffers ...
+        dist.barrier()
+        env.p2p_teardown()                      # ... before any rank frees its own
+        env.close()
         q.put((rank, sh.num_envs, got))
     except Exception as e:          # noqa: BLE001
         import traceback
@@ -251,26 +260,27 @@ def test_two_hip_shards_peer_copy_gather_equals_the_unsharded_oracle_run():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    want = _oracle_rollout("columbia", total, steps, repeat)
+    want = _oracle_rollout("columbia", total, steps * len(P2P_MODES), repeat)
     for rank, n, got in results:
         assert n == total // world, got
         parse = {"full": lambda b: slab_field_views(b, n, False), "full-u16": lambda b: compact_field_views(b, n),
                  "summary": lambda b: summary_field_views(b, n)}
-        for mode, fn in parse.items():
+        for mi, mode in enumerate(P2P_MODES):
+            fn = parse[mode]
             assert len(got[mode]) == steps
-            for k in range(steps):
-                o = want[k]
-                g = torch.from_numpy(got[mode][k])                  # [world, bytes]: rank r's record at row r
+            for j in range(steps):
+                o = want[mi * steps + j]
+                g = torch.from_numpy(got[mode][j])                  # [world, bytes]: rank r's record at row r
                 assert g.shape[0] == world
                 views = [fn(g[r]) for r in range(world)]
                 for name in RECORD:
                     cat = torch.cat([v[name] for v in views]).numpy()
-                    assert np.array_equal(cat, np.asarray(o[name], np.float32).reshape(cat.shape)), (rank, k, mode, name)
+                    assert np.array_equal(cat, np.asarray(o[name], np.float32).reshape(cat.shape)), (rank, mode, j, name)
                 if mode == "full":
-                    assert np.array_equal(torch.cat([v["lidar"] for v in views]).numpy(), o["lidar"]), (rank, k)
+                    assert np.array_equal(torch.cat([v["lidar"] for v in views]).numpy(), o["lidar"]), (rank, j)
                 if mode == "full-u16":
                     q16 = torch.cat([v["lidar_u16"] for v in views]).numpy()
-                    assert np.array_equal(q16, ro.quantise_lidar_u16(o["lidar"])), (rank, k)
+                    assert np.array_equal(q16, ro.quantise_lidar_u16(o["lidar"])), (rank, j)
 
 
 def test_device_memory_helpers_of_the_c_abi():

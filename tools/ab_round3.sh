@@ -1,5 +1,6 @@
 #!/bin/bash
-# Round-3 session A (run on the GPU box): parity of the new default build, the trip-budget termination check, then A/B on
+# Round-3 session A (run on the GPU box; the record is profiles/r03_a_*; needs the builds of that session in
+# racing_dreamer_amd/lib/ab/ and the round-2 render kernel, patch_variant 8, which has been removed since): parity of the new default build, the trip-budget termination check, then A/B on
 # this one box of (a) the scan with and without the in-shadow trip budget, (b) the lidar_occupancy render: round-2 kernel
 # (patch_variant 8), one wave per car with non-temporal (0) and plain (2) stores; then the render's HBM write traffic.
 out=gpurun_out/r3a; mkdir -p $out; export TMPDIR=/tmp
