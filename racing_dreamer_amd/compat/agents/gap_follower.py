@@ -5,8 +5,9 @@ The class the reference imports lives in the external racecar_gym repository (`a
 under /root/reference), so this is the classic follow-the-gap law written from its description: clip far
 ranges, smooth, zero a safety bubble around the closest return, steer at the centre of the widest run of
 beams longer than `gap_range`, slow down when steering hard.  (The reference's own ROS node, ros_agent/agents/follow_the_gap/src/agent.py,
-is a more elaborate disparity-extender + PID variant for the real car.)  Steering is returned normalised to
-[-1, 1] (max 0.42 rad).  The batched device version is BatchedRaceEnv.follow_the_gap().
+is a more elaborate disparity-extender + PID variant for the real car: `ReferenceGapFollower` below restates THAT law
+and is pinned to the node's own outputs.)  Steering is returned normalised to [-1, 1] (max 0.42 rad).  The batched device
+versions are BatchedRaceEnv.follow_the_gap() and .follow_the_gap_reference().
 """
 import numpy as np
 
@@ -38,3 +39,66 @@ class GapFollower:
         steering = float(np.clip(angle / self.max_steering, -1.0, 1.0))
         motor = self.corners_speed if abs(steering) > 0.35 else self.straights_speed
         return motor, steering
+
+
+class ReferenceGapFollower:
+    """The law of the reference's own follow-the-gap node (ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a host
+    agent with the same `action(obs) -> (motor, steering)` interface - for the single-env shim; the batched device form
+    is `BatchedRaceEnv.follow_the_gap_reference()`.  Forward arc of +-90 deg clipped at the look-ahead distance,
+    disparities (maximum of their 10-degree window, > 9 window medians, > 0.2 m) extended by the vehicle's half-width, heading
+    = mean angle of the beams at or above the 83.3rd percentile, steering = 1.4 heading - 0.1 d(heading)/dt within +-24
+    deg, the node's speed law.  `dt` = seconds between calls (0.01 s x action_repeat); `reset()` at an episode start drops
+    the derivative term's memory.  tests/test_golden_ftg.py checks it against the node's own outputs (golden G9)."""
+    LOOKAHEAD = 2.0 * (7.0 ** 2 / (2.0 * 8.26))
+    WIDTH = 0.3302 * 1.2
+    MAX_STEER = np.deg2rad(24.0)
+
+    def __init__(self, dt: float = 0.04, max_steering: float = 0.42, max_velocity: float = 5.0, range_max: float = 15.0):
+        self.dt, self.max_steering, self.max_velocity, self.range_max = dt, max_steering, max_velocity, range_max
+        self.previous = None
+        self.last = {}
+
+    def reset(self):
+        self.previous = None
+
+    @staticmethod
+    def _filtered(x, width, pad_mode, reducer):
+        half = width // 2
+        win = np.lib.stride_tricks.sliding_window_view(np.pad(x, (half, width - 1 - half), mode=pad_mode), width)
+        return reducer(win)
+
+    def heading(self, lidar):
+        """lidar: 1080 ranges in the env's order (beam 0 at +135 deg, clockwise).  Returns (heading, free distance)."""
+        ros = np.asarray(lidar, np.float64).reshape(-1)[-1080:][::-1]          # ROS order: from -135 deg, counter-clockwise
+        inc, amin = 1.5 * np.pi / 1079, -0.75 * np.pi
+        first, last = int((-np.pi / 2 - amin) / inc), int((np.pi / 2 - amin) / inc)
+        angles = np.arange(first, last + 1) * inc + amin
+        r = np.clip(ros[first:last + 1], 0.0, self.LOOKAHEAD)
+        jump = np.abs(np.diff(r))
+        width = int(np.deg2rad(10.0) / inc)
+        peak = self._filtered(jump, width, "symmetric", lambda w: w.max(axis=1))
+        med = self._filtered(jump, width, "edge", lambda w: np.sort(w, axis=1)[:, width // 2])
+        adjusted = r.copy()
+        for i in np.nonzero((jump == peak) & (jump > 9.0 * med) & (jump > 0.2))[0]:
+            near = r[i - 1:i + 2].min()
+            c = (2.0 * near * near - self.WIDTH ** 2) / (2.0 * near * near) if near > 0 else np.nan
+            if not -1.0 <= c <= 1.0:
+                a = b = 0                                       # the car is wider than twice the range: beam 0 only
+            else:
+                half = np.arccos(c)
+                a, b = (int(np.clip(int((angles[i] + s * half - angles[0]) / inc), 0, len(r) - 1)) for s in (-1.0, 1.0))
+            adjusted[a:b + 1] = np.minimum(adjusted[a:b + 1], near)
+        chosen = (adjusted >= np.percentile(adjusted, 100 * (1.0 - np.deg2rad(30.0) / np.pi))) & (adjusted < self.range_max)
+        return float(angles[chosen].mean()), float(r[chosen].mean())
+
+    def action(self, obs):
+        h, dist = self.heading(obs["lidar"])
+        d_term = 0.0 if self.previous is None else 0.1 * (self.previous - h) / self.dt
+        self.previous = h
+        steer = float(np.clip(1.4 * h - d_term, -self.MAX_STEER, self.MAX_STEER))
+        speed = 6.0 - (abs(steer) / self.MAX_STEER) * 1.8 if abs(steer) > np.deg2rad(5.0) else 6.0
+        if dist < 5:
+            speed = min(speed, dist / 5 * 4)
+        speed = max(speed, 1.5)
+        self.last = dict(heading=h, heading_distance=dist, steering_angle=steer, speed=speed)
+        return float(np.clip(speed / self.max_velocity, -1.0, 1.0)), float(np.clip(steer / self.max_steering, -1.0, 1.0))
