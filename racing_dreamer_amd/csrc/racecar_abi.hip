@@ -1243,7 +1243,7 @@ int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *e
     x->peer_dst.assign(world, nullptr);
     x->peer_flags.assign(world, nullptr);
     x->push.assign(world, nullptr);
-#define P2P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { p2p_free(env); return fail(RC_ERR_HIP, "%s failed: %s (payload %zu B x %d ranks)", #expr, hipGetErrorString(_e), x ? n : n, world); } } while (0)
+#define P2P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { p2p_free(env); return fail(RC_ERR_HIP, "%s failed: %s (payload %zu B x %d ranks)", #expr, hipGetErrorString(_e), n, world); } } while (0)
     P2P_TRY(hipMalloc((void **)&x->dst, 2 * (size_t)world * x->cap));
     // the flags are written by other GPUs' kernels and polled by this one's: uncached memory, so that a poll sees them
     P2P_TRY(hipExtMallocWithFlags((void **)&x->flags, 4096, hipDeviceMallocUncached));
