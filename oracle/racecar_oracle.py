@@ -273,7 +273,10 @@ def follow_the_gap_reference(lidar, prev_heading, dt, max_steering=None, max_vel
     max_velocity = MAX_VEL if max_velocity is None else f32(max_velocity)
     ang = ftgr_angles()
     # arc element a = ROS beam 179 + a = env beam 900 - a
-    r = np.minimum(np.maximum(lidar[:, 900 - np.arange(FTGR_N)], f32(0.0)), FTGR_LOOKAHEAD).astype(f32)
+    arc = lidar[:, 900 - np.arange(FTGR_N)]
+    with np.errstate(invalid="ignore"):
+        r = np.where(arc > f32(0.0), arc, f32(0.0))                               # (a NaN range counts as 0, like a negative one)
+        r = np.where(r < FTGR_LOOKAHEAD, r, FTGR_LOOKAHEAD).astype(f32)
     jump = np.abs(r[:, 1:] - r[:, :-1]).astype(f32)                               # [n, 720]
     half_w = FTGR_WIDTH // 2
     peak_pad = np.pad(jump, ((0, 0), (half_w, half_w)), mode="symmetric")

@@ -741,6 +741,73 @@ def test_reference_follow_the_gap_law_on_the_device():
         env.close()
 
 
+def test_reference_follow_the_gap_law_on_adversarial_scans():
+    """The same kernel on scans no track produces, written straight into the env's LiDAR rows: a sawtooth in which every
+    other beam is a disparity (hundreds of extensions per scan), plateaus of equal ranges around the percentile (NumPy's
+    2^-43 interpolation decides whether a whole plateau counts), all-zero / all-max / constant rows, ranges shorter than half
+    the vehicle's width (arccos of a number below -1), NaNs and negatives, single spikes at the arc's ends."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    rng = np.random.default_rng(3)
+    n = 512
+    rows = np.empty((n, 1080), np.float32)
+    ang = np.linspace(2.356, -2.356, 1080)
+    for i in range(n):
+        kind = i % 16
+        if kind == 0:
+            r = np.where(np.arange(1080) % 2 == 0, rng.uniform(0.5, 2.0), rng.uniform(2.5, 5.0))
+        elif kind == 1:
+            r = np.full(1080, 0.0)
+        elif kind == 2:
+            r = np.full(1080, 15.0)
+        elif kind == 3:
+            r = np.full(1080, rng.uniform(0.05, 8.0))
+        elif kind == 4:
+            r = np.round(rng.uniform(1.0, 6.5, 1080) * 4) / 4                  # plateaus of equal values, many exact ties
+        elif kind == 5:
+            r = np.full(1080, 3.0); r[rng.integers(180, 900, 6)] = 0.1          # spikes nearer than half the car's width
+        elif kind == 6:
+            r = rng.uniform(0.0, 0.3, 1080)                                     # everything closer than the car is wide
+        elif kind == 7:
+            r = 4.0 + np.cumsum(rng.normal(0, 0.05, 1080)); r[rng.integers(0, 1080, 30)] = np.nan
+        elif kind == 8:
+            r = rng.uniform(-1.0, 7.0, 1080)                                    # noise, negatives included
+        elif kind == 9:
+            r = np.full(1080, 2.0); r[180:185] = 6.0; r[896:901] = 6.0          # gaps at the very ends of the arc
+        elif kind == 10:
+            r = np.full(1080, 5.0); r[(ang > -0.2) & (ang < 0.1)] = 1.0         # a box dead ahead
+        elif kind == 11:
+            r = np.clip(3.0 + 2.5 * np.sin(8 * ang + rng.uniform(0, 6)), 0, 15) # smooth: no disparity at all
+        elif kind == 12:
+            r = np.where(np.arange(1080) % 40 < 20, 1.0, 1.0 + 0.2000001)       # jumps just above the 0.2 m threshold ...
+        elif kind == 13:
+            r = np.where(np.arange(1080) % 40 < 20, 1.0, 1.2)                   # ... and on it
+        elif kind == 14:
+            r = np.full(1080, 5.932203); r[400:700] = 5.9322033                 # values around the look-ahead clip
+        else:
+            r = rng.uniform(0.2, 12.0) * np.abs(np.sin(rng.uniform(1, 20) * ang)) + rng.uniform(0, 1)
+        rows[i] = r
+    env = BatchedRaceEnv("columbia", n, 1, auto_reset=False)
+    env.reset(mode="grid", seed=0)
+    env.step(torch.zeros((n, 1, 2), device="cuda"))                          # (past the reset observation: fresh = 0)
+    env.sync()
+    env.views["lidar"].copy_(torch.from_numpy(rows).view(n, 1, 1080))
+    prev = np.full(n, np.nan, np.float32)
+    for it in range(2):                                                         # the second pass has a derivative term
+        act, det = env.follow_the_gap_reference(dt=0.04, detail=True)
+        torch.cuda.synchronize()
+        want = ro.follow_the_gap_reference(rows, prev, 0.04)
+        d = det.cpu().numpy()
+        for j, name in enumerate(("heading", "heading_distance", "steering_angle", "speed")):
+            same = (d[:, j] == want[name]) | (np.isnan(d[:, j]) & np.isnan(want[name]))
+            assert same.all(), (it, name, np.nonzero(~same)[0][:8], d[~same, j][:4], want[name][~same][:4])
+        assert np.array_equal(act.cpu().numpy().reshape(n, 2), want["action"], equal_nan=True)
+        prev = want["heading"]
+        rows = np.roll(rows, 7, axis=1)                                         # another scan, so the heading moves
+        env.views["lidar"].copy_(torch.from_numpy(rows).view(n, 1, 1080))
+    env.close()
+
+
 def test_full_size_two_cars_32768_envs_match_oracle():
     """BASELINE.json configs[3] size: 32 768 envs x 2 cars, treitlstrasse_v2, random_ball resets, inter-car
     raycast + collision, against the C oracle."""
