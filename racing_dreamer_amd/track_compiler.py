@@ -237,6 +237,29 @@ def compile_track(name: str, maps_dir: str, world_start=(0.0, 0.0)) -> CompiledT
                          np.array([r0, c0, fh, fw], np.int32), np.array([sc, sr], np.int32), cl)
 
 
+def export_scene(name: str, maps_dir: str, out_dir: str, world_start=(0.0, 0.0)) -> str:
+    """Write a racecar_gym-style scene directory for a track - `<out_dir>/<name>/<name>.yml` with the keys
+    `SceneConfig.load` consumers read (dreamer/plotting/plot_trajectories.py:17-37: sdf, map.maps, map.starting_grid,
+    map.origin, map.resolution), `maps/maps.npz` (export_maps_npz) and `maps/starting_grid.npz` (the grid-mode start poses
+    of this build: x, y, yaw per slot).  Returns the yml path."""
+    import yaml
+    from .track_assets import load_track
+    scene = os.path.join(out_dir, name)
+    os.makedirs(os.path.join(scene, "maps"), exist_ok=True)
+    export_maps_npz(name, maps_dir, os.path.join(scene, "maps", "maps.npz"), world_start)
+    map_name, props, res, gray, free, sc, sr = _load_map(name, maps_dir, world_start)
+    t = load_track(name)
+    cl = np.asarray(t.centerline, np.float64)
+    slots = [(8 + 12 * k) % len(cl) for k in range(4)]                  # grid mode: 0.8 m after the line, 1.2 m apart
+    np.savez(os.path.join(scene, "maps", "starting_grid.npz"), data=cl[slots][:, :3])
+    path = os.path.join(scene, f"{name}.yml")
+    with open(path, "w") as f:
+        yaml.safe_dump({"name": name, "sdf": f"{name}.sdf",
+                        "map": {"maps": "maps/maps.npz", "starting_grid": "maps/starting_grid.npz",
+                                "resolution": float(res), "origin": [float(v) for v in props["origin"]]}}, f)
+    return path
+
+
 def export_maps_npz(name: str, maps_dir: str, out_path: str, world_start=(0.0, 0.0)) -> dict:
     """Write the racecar_gym-style `maps.npz` of a track: the keys and value conventions of the reference's costmap
     generator (generate-costmap.py:410-425), full source-image frame, row 0 = top of the image - what

@@ -204,3 +204,32 @@ def test_vector_env_is_one_batched_handle_per_track(ref_wrappers, monkeypatch):
     frames = vec.render(mode="birds_eye")
     assert len(frames) == 5 and frames[0].shape == frames[1].shape and frames[0].ndim == 3
     vec.close()
+
+
+def test_host_progress_task_equals_the_device_task(ref_wrappers, monkeypatch):
+    """racecar_gym.tasks.progress_based.MaximizeProgressTask (ros_agent/helpers/wrappers.py:17-20) evaluated on the state dicts
+    the shim returns == the reward and done flag the backend computed itself, step for step, over episodes that end in walls."""
+    from racecar_gym import SingleAgentScenario
+    from racecar_gym.envs import SingleAgentRaceEnv
+    from racecar_gym.tasks.progress_based import MaximizeProgressTask
+    monkeypatch.chdir(os.path.join(REF, "dreamer"))
+    scen = SingleAgentScenario.from_spec("scenarios/max_progress/columbia.yml", rendering=False)
+    p = scen.agent.task_params
+    env = SingleAgentRaceEnv(scen)
+    task = MaximizeProgressTask(**p)
+    rng = np.random.default_rng(1)
+    ended = 0
+    for episode in range(4):
+        env.reset(mode="random" if episode else "grid")
+        task.reset()
+        for k in range(400):
+            a = {"motor": np.array([rng.uniform(0.2, 1.0)]), "steering": np.array([rng.uniform(-1, 1)])}
+            obs, rew, done, info = env.step(a)
+            state = {scen.agent.id: info}
+            assert task.reward(scen.agent.id, state, a) == pytest.approx(rew, abs=2e-4), (episode, k)
+            assert task.done(scen.agent.id, state) == done
+            if done:
+                ended += 1
+                break
+    assert ended >= 2 and float(p["collision_reward"]) != 0.0
+    env.close()
