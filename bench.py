@@ -247,6 +247,46 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
     return out
 
 
+def time_mixed_tracks(names, envs, steps, warmup):
+    """BASELINE.json configs[4]'s track mix inside ONE batch on the current device (not the 8-GPU run): `envs` envs in equal
+    blocks on `names`, one handle per track filling one arena (MixedTrackEnv), random-action rollouts."""
+    import torch
+    from racing_dreamer_amd.batched_env import MixedTrackEnv
+    per = [envs // len(names) + (1 if i < envs % len(names) else 0) for i in range(len(names))]
+    env = MixedTrackEnv(list(names), per, auto_reset=True)
+    env.reset(mode="random", seed=0)
+    torch.cuda.set_stream(env.stream)
+    for k in range(warmup):
+        env.step_random(seed=1, step=k)
+    env.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        env.step_random(seed=1, step=warmup + k)
+    env.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    for p in env.parts:
+        p.reset_kernel_times()
+        p.set_profiling(True)
+    for k in range(min(steps, 40)):
+        env.step_random(seed=1, step=warmup + steps + k)
+    env.sync()
+    scans = {}
+    for nm, p in zip(names, env.parts):
+        p.set_profiling(False)
+        scans[nm] = round(p.kernel_times()["rc_raycast_kernel"]["avg_ms"], 4)
+    env.close()
+    ms = dt / steps * 1e3
+    step_bytes = STEP_BYTES_PER_CAR * envs
+    return {"workload": f"configs[4]'s track mix on ONE GPU: {envs} envs in {len(names)} blocks ({', '.join(names)}), one handle per "
+                        f"track filling one arena (MixedTrackEnv); the 8-GPU run itself is `--gpus 8 --mixed-tracks`",
+            "envs": envs, "cars_per_env": 1, "track": "mixed: " + " / ".join(names), "obs_type": "lidar", "steps": steps,
+            "ms_per_step": ms, "env_steps_per_s": envs * steps / dt, "kernels_ms": {"rc_raycast_kernel_by_track": scans},
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "step_bytes": step_bytes,
+                         "step_achieved": step_bytes / (ms * 1e-3) / 1e9, "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -607,6 +647,7 @@ def main():
                     ("configs[3]: 32 768 envs x 2 cars, treitlstrasse_v2, inter-car raycast + collision",
                      "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
             out["configs"] = [time_config(*c) for c in cfgs]
+            out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10))
         if not args.no_cpu_baseline and world == 1:
             from oracle import cpu_baseline as cb
             out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)

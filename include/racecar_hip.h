@@ -132,13 +132,23 @@ typedef struct rc_config {
     void    *stream;               /* optional hipStream_t to run on; NULL = library creates one */
     int32_t  car_task[RC_MAX_CARS];/* task of car slot a (agents A, B, C, D of a scenario yml); -1 = `task`          */
     int32_t  n_steps;              /* RC_TASK_N_STEP_PROGRESS window in sub-steps, 1..RC_NSTEP_MAX (yml n_steps: 10) */
+    /* Several handles filling ONE arena - one handle per track, so that a batch can mix tracks by blocks of envs (SURVEY.md
+     * 8e "per-env track"; BASELINE configs[4] on one GPU): the arena (external_arena) is laid out for arena_total_cars cars
+     * and this handle's cars are cars arena_first_car ... of it; every output section then holds the cars of all handles in
+     * order.  0 / 0 = the arena is this handle's alone.  rc_trajectory_slab, the compact record and the gathers belong to the
+     * arena's owner then, not to a slice handle.  Give each handle first_env = the global index of its first env. */
+    int32_t  arena_total_cars;
+    int32_t  arena_first_car;
 } rc_config;
 
 /* Fill `cfg` with the defaults of the reference's max_progress scenario. */
 void rc_default_config(rc_config *cfg);
 
-/* Bytes of device memory the output arena needs for this configuration. */
+/* Bytes of device memory the output arena needs for this configuration (for arena_total_cars cars if that is set). */
 size_t rc_arena_bytes(const rc_config *cfg);
+/* Where a field's section starts in that arena and how many bytes a car takes in it (0 if the field is not enabled):
+ * car c's data at section_offset + c * bytes_per_car. */
+int rc_field_layout(const rc_config *cfg, int32_t field, size_t *section_offset, size_t *bytes_per_car);
 
 int rc_create(const rc_config *cfg, rc_env **out);
 void rc_destroy(rc_env *env);

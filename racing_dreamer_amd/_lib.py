@@ -45,6 +45,7 @@ class RcConfig(C.Structure):
         ("external_arena", C.c_void_p),
         ("external_arena_bytes", C.c_size_t), ("stream", C.c_void_p),
         ("car_task", C.c_int32 * 4), ("n_steps", C.c_int32),
+        ("arena_total_cars", C.c_int32), ("arena_first_car", C.c_int32),
     ]
 
 
@@ -53,6 +54,7 @@ _P = C.POINTER
 SYMBOLS = {
     "rc_default_config": (None, [_P(RcConfig)]),
     "rc_arena_bytes": (C.c_size_t, [_P(RcConfig)]),
+    "rc_field_layout": (C.c_int, [_P(RcConfig), C.c_int32, _P(C.c_size_t), _P(C.c_size_t)]),
     "rc_create": (C.c_int, [_P(RcConfig), _P(C.c_void_p)]),
     "rc_destroy": (None, [C.c_void_p]),
     "rc_load_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,

@@ -64,10 +64,14 @@ class BatchedRaceEnv:
                  terminate_on_collision: bool = True, collision_reward: float = -1.0,
                  remap_actions: bool = False, action_low=spec.ACTION_LOW, action_high=spec.ACTION_HIGH,
                  time_limit_steps: int = 0, auto_reset: bool = False, profiling: bool = False,
-                 lidar_transform: str = "metres", car_tasks=None, n_steps: int = 10):
+                 lidar_transform: str = "metres", car_tasks=None, n_steps: int = 10,
+                 shared_arena: Optional[torch.Tensor] = None, arena_total_cars: int = 0, arena_first_car: int = 0,
+                 stream: Optional[torch.cuda.Stream] = None):
         """car_tasks: optional task name per car slot (agents A, B, ... of a scenario yml; None entries = `task`), e.g.
         ["maximize_progress", "n_step_progress", ...] for baselines/scenarios/max_progress/columbia.yml; n_steps: the
-        window of `n_step_progress` in sub-steps."""
+        window of `n_step_progress` in sub-steps.  shared_arena / arena_total_cars / arena_first_car / stream: this env
+        fills cars [arena_first_car, ...) of an arena laid out for arena_total_cars cars and runs on the given stream -
+        how `MixedTrackEnv` puts one handle per track behind one set of output tensors."""
         if obs_type not in OBS_TYPES:
             raise ValueError(f"obs_type must be one of {sorted(OBS_TYPES)}, got {obs_type!r}")
         if task not in TASKS:
@@ -100,12 +104,19 @@ class BatchedRaceEnv:
         if lidar_transform not in LIDAR_TRANSFORMS:
             raise ValueError(f"lidar_transform must be one of {sorted(LIDAR_TRANSFORMS)}, got {lidar_transform!r}")
         cfg.lidar_transform = LIDAR_TRANSFORMS[lidar_transform]
+        cfg.arena_total_cars, cfg.arena_first_car = int(arena_total_cars), int(arena_first_car)
         nbytes = self._lib.rc_arena_bytes(C.byref(cfg))
-        with torch.cuda.device(self.device):
-            self.arena = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
-            self.stream = torch.cuda.Stream(device=self.device)
-        pad = (-self.arena.data_ptr()) % 64
-        self._arena_view = self.arena[pad:pad + nbytes]
+        if shared_arena is not None:
+            if shared_arena.dtype != torch.uint8 or shared_arena.numel() < nbytes or shared_arena.data_ptr() % 64:
+                raise ValueError(f"shared_arena must be a 64-byte aligned uint8 tensor of at least {nbytes} bytes")
+            self.arena, self._arena_view = shared_arena, shared_arena[:nbytes]
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        else:
+            with torch.cuda.device(self.device):
+                self.arena = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
+                self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+            pad = (-self.arena.data_ptr()) % 64
+            self._arena_view = self.arena[pad:pad + nbytes]
         cfg.external_arena = self._arena_view.data_ptr()
         cfg.external_arena_bytes = nbytes
         cfg.stream = self.stream.cuda_stream
@@ -125,14 +136,16 @@ class BatchedRaceEnv:
             t = self._arena_view[off:off + nb.value].view(dtype)
             self.views[name] = t.view(self.num_envs, self.cars_per_env, *tail)
             self._host_layout[name] = (off, nb.value, str(dtype).replace("torch.", ""), tail)
-        ptr, nb = C.c_void_p(), C.c_size_t()
-        L.check(self._lib.rc_trajectory_slab(self._h, C.byref(ptr), C.byref(nb)))
-        self.slab = self._arena_view[ptr.value - base:ptr.value - base + nb.value]
-        # the record without the bulky observations: pose .. time (76 B per car), contiguous in the arena
-        p0, n0, p1, n1 = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
-        L.check(self._lib.rc_get(self._h, L.F_POSE, C.byref(p0), C.byref(n0)))
-        L.check(self._lib.rc_get(self._h, L.F_TIME, C.byref(p1), C.byref(n1)))
-        self.summary_slab = self._arena_view[p0.value - base:p1.value - base + n1.value]
+        self.slab = self.summary_slab = None
+        if not (arena_total_cars and arena_total_cars != self.n_cars):     # (a slice of a shared arena has no slab of its own)
+            ptr, nb = C.c_void_p(), C.c_size_t()
+            L.check(self._lib.rc_trajectory_slab(self._h, C.byref(ptr), C.byref(nb)))
+            self.slab = self._arena_view[ptr.value - base:ptr.value - base + nb.value]
+            # the record without the bulky observations: pose .. time (76 B per car), contiguous in the arena
+            p0, n0, p1, n1 = C.c_void_p(), C.c_size_t(), C.c_void_p(), C.c_size_t()
+            L.check(self._lib.rc_get(self._h, L.F_POSE, C.byref(p0), C.byref(n0)))
+            L.check(self._lib.rc_get(self._h, L.F_TIME, C.byref(p1), C.byref(n1)))
+            self.summary_slab = self._arena_view[p0.value - base:p1.value - base + n1.value]
         self._own_views = self.views
         if profiling:
             self.set_profiling(True)
@@ -460,3 +473,97 @@ class BatchedRaceEnv:
         """Synchronised host copy of one output field."""
         self.sync()
         return self.views[name].cpu().numpy()
+
+
+class MixedTrackEnv:
+    """A batch that mixes tracks by blocks of envs (SURVEY.md 8e "per-env track"; BASELINE configs[4]'s track mix on ONE GPU):
+    one `BatchedRaceEnv` handle per track, all of them filling their slice of ONE output arena, so the caller
+    sees a single set of tensors `[total_envs, cars_per_env, ...]` and `track_id[total_envs]` (each handle on a stream of its own,
+    forked from / joined to the caller's current stream around every call).  Env e of the batch is env e
+    of the job: its reset stream is keyed by `first_env + e` whatever block it lies in, so a block of track T behaves
+    exactly like the same envs in a single-track batch.  A step is one (dynamics, scan[, render]) launch set per track.
+
+        env = MixedTrackEnv(["columbia", "austria", "barcelona"], [21846, 21845, 21845], auto_reset=True)
+        out = env.reset(mode="random", seed=0); out = env.step(actions)       # actions float32 [65536, 1, 2] on the device
+    """
+
+    def __init__(self, tracks, envs_per_track, cars_per_env: int = 1, obs_type: str = "lidar", device: int = 0,
+                 first_env: int = 0, **kw):
+        if len(tracks) != len(envs_per_track) or not tracks:
+            raise ValueError("one env count per track")
+        self._lib = L.load_library()
+        if not torch.cuda.is_available():
+            raise L.RacecarHipError("no HIP device visible to torch; MixedTrackEnv has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.num_envs, self.cars_per_env = int(sum(envs_per_track)), int(cars_per_env)
+        self.n_cars = self.num_envs * self.cars_per_env
+        cfg = L.RcConfig()
+        self._lib.rc_default_config(C.byref(cfg))
+        cfg.num_envs, cfg.cars_per_env, cfg.obs_type = self.num_envs, self.cars_per_env, OBS_TYPES[obs_type]
+        nbytes = self._lib.rc_arena_bytes(C.byref(cfg))
+        with torch.cuda.device(self.device):
+            raw = torch.zeros(nbytes + 64, dtype=torch.uint8, device=self.device)
+            self.stream = torch.cuda.Stream(device=self.device)      # a stream for callers that want one (bench.py works on it)
+        pad = (-raw.data_ptr()) % 64
+        self._raw, self.arena = raw, raw[pad:pad + nbytes]
+        self.parts, self.blocks = [], []
+        e0 = 0
+        for track, n in zip(tracks, envs_per_track):
+            self.parts.append(BatchedRaceEnv(track, int(n), cars_per_env, obs_type=obs_type, device=device, first_env=first_env + e0,
+                                             shared_arena=self.arena, arena_total_cars=self.n_cars,
+                                             arena_first_car=e0 * self.cars_per_env, **kw))
+            self.blocks.append((e0, e0 + int(n)))
+            e0 += int(n)
+        self.track_id = torch.cat([torch.full((b - a,), i, dtype=torch.int32) for i, (a, b) in enumerate(self.blocks)]).to(self.device)
+        self.views: Dict[str, torch.Tensor] = {}
+        off, per = C.c_size_t(), C.c_size_t()
+        for name, (fid, dtype, tail) in _FIELD_VIEWS.items():
+            L.check(self._lib.rc_field_layout(C.byref(cfg), fid, C.byref(off), C.byref(per)))
+            if per.value == 0:
+                continue
+            t = self.arena[off.value:off.value + per.value * self.n_cars].view(dtype)
+            self.views[name] = t.view(self.num_envs, self.cars_per_env, *tail)
+
+    # Every block runs on a stream of its own, forked from and joined to the caller's current stream around each call: the
+    # blocks' kernels overlap (a block of a third of the batch leaves the tail of its scan half empty; the next block's
+    # waves fill it), and the caller sees one stream-ordered operation.
+    def _fork_join(self, call):
+        cur = torch.cuda.current_stream(self.device)
+        for p in self.parts:
+            p.stream.wait_stream(cur)
+        for p, blk in zip(self.parts, self.blocks):
+            L.check(call(p, blk))
+        for p in self.parts:
+            cur.wait_stream(p.stream)
+        return self.views
+
+    def reset(self, mode: str = "grid", seed: Optional[int] = None):
+        if mode not in spec.RESET_MODES:
+            raise ValueError(f"reset mode must be one of {sorted(spec.RESET_MODES)}, got {mode!r}")
+        for p in self.parts:
+            if seed is not None:
+                p.seed = int(seed)
+        return self._fork_join(lambda p, blk: p._lib.rc_reset(p._h, None, spec.RESET_MODES[mode], C.c_uint64(p.seed)))
+
+    def step(self, actions: Optional[torch.Tensor] = None, repeat: Optional[int] = None):
+        """actions: float32 [total_envs, cars_per_env, 2] on the device (None: each block's `action_in`)."""
+        if actions is not None:
+            actions = actions.to(self.device, torch.float32).reshape(self.num_envs, self.cars_per_env, 2).contiguous()
+        return self._fork_join(lambda p, blk: p._lib.rc_step(
+            p._h, None if actions is None else actions[blk[0]:blk[1]].data_ptr(), p.action_repeat if repeat is None else int(repeat)))
+
+    def step_random(self, seed: int, step: int, repeat: Optional[int] = None):
+        return self._fork_join(lambda p, blk: p._lib.rc_step_random(p._h, C.c_uint64(seed), C.c_uint32(step),
+                                                                    p.action_repeat if repeat is None else int(repeat)))
+
+    def follow_the_gap_reference(self, dt: Optional[float] = None):
+        self._fork_join(lambda p, blk: p._lib.rc_follow_the_gap_reference(p._h, 0.01 * p.action_repeat if dt is None else float(dt), None))
+        return self.views["action_in"]
+
+    def sync(self):
+        for p in self.parts:
+            p.sync()
+
+    def close(self):
+        for p in self.parts:
+            p.close()

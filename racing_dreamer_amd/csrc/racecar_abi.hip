@@ -60,16 +60,19 @@ struct Layout {
     size_t total;
 };
 
-Layout make_layout(int n_cars, bool occupancy) {
+// The arena holds `n_cars` cars; a handle that owns only cars [first_car, first_car + n_own) of it (rc_config::arena_total_cars:
+// several handles - one per track - fill ONE set of output arrays) gets the offsets and sizes of ITS slice of every section.
+Layout make_layout(int n_cars, bool occupancy, int first_car = 0, int n_own = -1) {
     Layout l{};
+    if (n_own < 0) n_own = n_cars;
     size_t off = 0;
     for (int f = 0; f < RC_F_COUNT; ++f) {
         size_t b = kFieldBytes[f] * (size_t)n_cars;
         if (f == RC_F_OCCUPANCY && !occupancy) b = 0;
-        l.offset[f] = off;
-        l.bytes[f] = b;
+        l.offset[f] = off + (b ? kFieldBytes[f] * (size_t)first_car : 0);
+        l.bytes[f] = b ? kFieldBytes[f] * (size_t)n_own : 0;
+        if (f == (occupancy ? RC_F_OCCUPANCY : RC_F_TIME)) l.slab_bytes = off + b;
         off = align_up(off + b, 64);
-        if (f == (occupancy ? RC_F_OCCUPANCY : RC_F_TIME)) l.slab_bytes = l.offset[f] + b;
     }
     l.total = off;
     return l;
@@ -189,6 +192,7 @@ struct rc_env {
     // device memory
     void *arena = nullptr;
     bool own_arena = false;
+    bool shared_arena = false;     // this handle fills a slice of a larger arena (rc_config::arena_total_cars)
     Layout layout{};
     void *state_mem = nullptr;
     std::shared_ptr<TrackTables> track;   // shared with the other handles that loaded the same track on this device
@@ -415,10 +419,12 @@ int load_rccl() {
 int gather_source(rc_env *env, int mode, const void **src, size_t *bytes) {
     switch (mode) {
     case RC_GATHER_FULL:
+        if (env->shared_arena) return fail(RC_ERR_INVALID, "this handle fills a slice of a shared arena: gather the arena itself");
         *src = env->out_arena;
         *bytes = env->layout.slab_bytes;
         return RC_OK;
     case RC_GATHER_SUMMARY:
+        if (env->shared_arena) return fail(RC_ERR_INVALID, "this handle fills a slice of a shared arena: gather the arena itself");
         *src = (const char *)env->out_arena + env->compact.summary_src_off;
         *bytes = env->compact.summary_bytes;
         return RC_OK;
@@ -440,6 +446,15 @@ int check_cfg(const rc_config *cfg) {
         return fail(RC_ERR_INVALID, "cars_per_env must be in 1..%d (got %d)", RC_MAX_CARS, cfg->cars_per_env);
     if ((int64_t)cfg->num_envs * cfg->cars_per_env * RC_N_BEAMS > 0x7fffffffLL)
         return fail(RC_ERR_INVALID, "num_envs * cars_per_env * 1080 must fit int32");
+    if (cfg->arena_total_cars != 0) {
+        const int64_t own = (int64_t)cfg->num_envs * cfg->cars_per_env;
+        if (cfg->arena_first_car < 0 || cfg->arena_total_cars < 0 || cfg->arena_first_car + own > cfg->arena_total_cars)
+            return fail(RC_ERR_INVALID, "cars [%d, %lld) do not lie inside an arena of %d cars", cfg->arena_first_car,
+                        (long long)(cfg->arena_first_car + own), cfg->arena_total_cars);
+        if (!cfg->external_arena) return fail(RC_ERR_INVALID, "arena_total_cars needs the caller's arena (external_arena)");
+    } else if (cfg->arena_first_car != 0) {
+        return fail(RC_ERR_INVALID, "arena_first_car without arena_total_cars");
+    }
     if (cfg->obs_type != RC_OBS_LIDAR && cfg->obs_type != RC_OBS_LIDAR_OCCUPANCY)
         return fail(RC_ERR_INVALID, "unknown obs_type %d", cfg->obs_type);
     if (cfg->lidar_transform < RC_LIDAR_METRES || cfg->lidar_transform > RC_LIDAR_UNIT)
@@ -523,11 +538,25 @@ void rc_default_config(rc_config *cfg) {
     cfg->action_high[1] = 1.0f;
     for (int a = 0; a < RC_MAX_CARS; ++a) cfg->car_task[a] = -1;      // every car runs `task`
     cfg->n_steps = 10;                   // baselines/scenarios/max_progress/columbia.yml:18
+    cfg->arena_total_cars = 0;           // the arena is this handle's alone
+    cfg->arena_first_car = 0;
 }
 
 size_t rc_arena_bytes(const rc_config *cfg) {
     if (!cfg || cfg->num_envs < 1 || cfg->cars_per_env < 1) return 0;
-    return make_layout(cfg->num_envs * cfg->cars_per_env, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY).total;
+    const int n = cfg->arena_total_cars > 0 ? cfg->arena_total_cars : cfg->num_envs * cfg->cars_per_env;
+    return make_layout(n, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY).total;
+}
+
+int rc_field_layout(const rc_config *cfg, int32_t field, size_t *section_offset, size_t *bytes_per_car) {
+    if (!cfg || !section_offset || !bytes_per_car) return fail(RC_ERR_INVALID, "NULL argument");
+    if (field < 0 || field >= RC_F_COUNT) return fail(RC_ERR_INVALID, "unknown field %d", field);
+    if (cfg->num_envs < 1 || cfg->cars_per_env < 1) return fail(RC_ERR_INVALID, "num_envs and cars_per_env must be >= 1");
+    const int n = cfg->arena_total_cars > 0 ? cfg->arena_total_cars : cfg->num_envs * cfg->cars_per_env;
+    const Layout l = make_layout(n, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY);
+    *section_offset = l.offset[field];
+    *bytes_per_car = l.bytes[field] ? kFieldBytes[field] : 0;
+    return RC_OK;
 }
 
 int rc_create(const rc_config *cfg, rc_env **out) {
@@ -545,7 +574,8 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     env->cfg = *cfg;
     const int n = env->n_cars = cfg->num_envs * cfg->cars_per_env;
     const bool occ = cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY;
-    env->layout = make_layout(n, occ);
+    env->shared_arena = cfg->arena_total_cars > 0 && cfg->arena_total_cars != n;
+    env->layout = cfg->arena_total_cars > 0 ? make_layout(cfg->arena_total_cars, occ, cfg->arena_first_car, n) : make_layout(n, occ);
     env->compact = make_compact(env->layout, n);
 #define FAIL_FREE(code_expr) do { int _c = (code_expr); rc_destroy(env); return _c; } while (0)
 #define HIP_TRY_FREE(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) FAIL_FREE(fail(RC_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(_e))); } while (0)
@@ -565,7 +595,13 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         HIP_TRY_FREE(hipMalloc(&env->arena, env->layout.total));
         env->own_arena = true;
     }
-    HIP_TRY_FREE(hipMemsetAsync(env->arena, 0, env->layout.total, env->stream));
+    if (!env->shared_arena) {
+        HIP_TRY_FREE(hipMemsetAsync(env->arena, 0, env->layout.total, env->stream));
+    } else {
+        for (int f = 0; f < RC_F_COUNT; ++f)          // this handle's slices only: the rest belongs to other handles
+            if (env->layout.bytes[f])
+                HIP_TRY_FREE(hipMemsetAsync((char *)env->arena + env->layout.offset[f], 0, env->layout.bytes[f], env->stream));
+    }
 
     // simulator state: packed scan pose, 10 float + 2 int + 6 byte arrays per car, 2 int + 1 uint per env
     const size_t nc = (size_t)align_up(n, 64), ne = (size_t)align_up(cfg->num_envs, 64);
@@ -1000,6 +1036,7 @@ int rc_copy_out(rc_env *env, int32_t field, void *host_dst, size_t bytes) {
 
 int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes) {
     if (!env || !dev_ptr || !bytes) return fail(RC_ERR_INVALID, "NULL argument");
+    if (env->shared_arena) return fail(RC_ERR_INVALID, "this handle fills a slice of a shared arena: the slab is the head of the arena itself");
     *dev_ptr = env->out_arena;
     *bytes = env->layout.slab_bytes;
     return RC_OK;
@@ -1087,6 +1124,7 @@ size_t rc_compact_bytes(const rc_config *cfg) {
 int rc_set_compact_slab(rc_env *env, void *slab, size_t bytes) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (slab) {
+        if (env->shared_arena) return fail(RC_ERR_INVALID, "the compact record is not available on a handle that fills a slice of a shared arena");
         if (bytes < env->compact.total) return fail(RC_ERR_INVALID, "compact slab too small: %zu < %zu", bytes, env->compact.total);
         if ((uintptr_t)slab % 64) return fail(RC_ERR_INVALID, "compact slab must be 64-byte aligned");
         if (env->has_track && env->launch.raycast_variant != 7)

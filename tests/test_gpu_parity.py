@@ -892,6 +892,46 @@ def test_mixed_track_shards_like_config_4():
         env.close()
 
 
+def test_mixed_track_env_blocks_equal_their_oracles():
+    """MixedTrackEnv: one handle per track filling ONE arena (rc_config.arena_total_cars / arena_first_car) - the track mix of
+    BASELINE configs[4] inside one batch.  Every block of the common output tensors equals the oracle of its own track with
+    the same global env offset (occupancy patches included), `track_id` says which; and two blocks of the SAME track are,
+    bit for bit, the single-track batch of all their envs."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv, MixedTrackEnv
+    from racing_dreamer_amd.track_assets import load_track
+    from racing_dreamer_amd import spec
+    names, sizes = ["columbia", "austria", "barcelona", "columbia"], [100, 60, 37, 40]
+    env = MixedTrackEnv(names, sizes, cars_per_env=2, obs_type="lidar_occupancy", auto_reset=True)
+    assert env.track_id.tolist() == sum(([i] * n for i, n in enumerate(sizes)), []) and env.views["lidar"].shape == (237, 2, 1080)
+    oras = [make_oracle(load_track(nm), num_envs=n, cars_per_env=2, auto_reset=True, render_occupancy=True, first_env=a)
+            for nm, n, (a, b) in zip(names, sizes, env.blocks)]
+    dv = env.reset(mode="random_ball", seed=13)
+    ovs = [o.reset(mode=spec.RESET_RANDOM_BALL, seed=13) for o in oras]
+    for k in range(12):
+        act = ro.random_actions(5, k, 237 * 2)
+        act[:, 0] = np.abs(act[:, 0])
+        dv = env.step(torch.from_numpy(act).cuda().view(237, 2, 2), repeat=2)
+        ovs = [o.step(act[2 * a:2 * b], repeat=2) for o, (a, b) in zip(oras, env.blocks)]
+        for (a, b), ov, nm in zip(env.blocks, ovs, names):
+            compare_outputs({k2: v[a:b] for k2, v in dv.items()}, ov, b - a, 2, f"step {k}, block [{a}, {b}) on {nm}")
+    assert sum(int(np.asarray(ov["done"]).sum()) for ov in ovs) >= 0
+    env.close()
+    # the same track in two blocks == one batch
+    two = MixedTrackEnv(["columbia", "columbia"], [70, 58], auto_reset=True)
+    one = BatchedRaceEnv("columbia", 128, 1, auto_reset=True)
+    a, b = two.reset(mode="random", seed=2), one.reset(mode="random", seed=2)
+    for k in range(25):
+        a, b = two.step_random(seed=9, step=k, repeat=3), one.step_random(seed=9, step=k, repeat=3)
+    torch.cuda.synchronize()
+    for name in ("lidar", "pose", "reward", "done", "progress", "time", "fresh", "action"):
+        assert torch.equal(a[name], b[name]), name
+    with pytest.raises(Exception, match="shared arena"):
+        two.parts[0].enable_compact()
+    two.close()
+    one.close()
+
+
 def test_every_compiled_map_steps_like_the_oracle():
     """all 29 compiled maps of docs/maps/maps run on the device (any grid up to 4096 cells per side:
     columbia_simple is 1083 x 1489, f1_mco 937 x 1072) - reset, three agent steps and the scan against the C oracle."""
