@@ -75,6 +75,79 @@ def check_resource_usage(remarks: str) -> None:
         raise RuntimeError("build refused (see racing_dreamer_amd/build.py, NO_SPILL_KERNELS):\n  " + "\n  ".join(problems))
 
 
+def check_async_load_registers(asm_text: str, kernels=("rc_raycast_car_kernel", "rc_raycast_car_stamps_kernel", "rc_raycast_kernel")) -> int:
+    """The scan requests a table entry with an inline-assembly `global_load_ushort` and waits for it in a LATER statement
+    (`s_waitcnt vmcnt(0)`): until then the destination register is not the compiler's to read, copy or overwrite, and
+    nothing tells it so.  This walks the generated assembly of the scan kernels and raises if any instruction between such
+    a load and the next wait for it (in layout order) touches the destination register.  Returns the number of loads
+    checked."""
+    import re
+    checked, problems = 0, []
+    kernel, pending, in_asm = None, None, False
+    for raw in asm_text.splitlines():
+        line = raw.strip()
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            kernel = m.group(1) if any(k in m.group(1) for k in kernels) else None
+            pending = None
+            continue
+        if kernel is None or not line or line.startswith((";", ".", "//")) and "#ASM" not in line:
+            if ";;#ASMSTART" in line:
+                in_asm = True
+            elif ";;#ASMEND" in line:
+                in_asm = False
+            continue
+        if ";;#ASMSTART" in line:
+            in_asm = True
+            continue
+        if ";;#ASMEND" in line:
+            in_asm = False
+            continue
+        if "s_endpgm" in line:
+            kernel, pending = None, None
+            continue
+        code = line.split(";")[0].strip()
+        if not code or code.endswith(":"):
+            continue
+        if pending is not None:
+            if code.startswith("s_waitcnt") and "vmcnt(0)" in code:
+                pending = None
+            else:
+                regs = set(int(r) for r in re.findall(r"\bv(\d+)\b", code))
+                for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code):
+                    regs.update(range(int(a), int(b) + 1))
+                if pending[0] in regs:
+                    problems.append(f"{kernel}: `{code}` touches v{pending[0]} while `{pending[1]}` is in flight")
+                    pending = None
+        m = re.match(r"^global_load_ushort v(\d+),", code)
+        if m and in_asm:
+            pending = (int(m.group(1)), code)
+            checked += 1
+    if problems:
+        raise RuntimeError("build refused: a register with an asynchronous load in flight is used before its wait\n  " + "\n  ".join(problems[:8]))
+    if checked == 0:
+        raise RuntimeError("no inline-assembly table request found in the scan kernels: the check does not see what it should")
+    return checked
+
+
+def verify_scan_assembly(verbose: bool = True) -> int:
+    """Compile the kernels to assembly once more (device only) and run check_async_load_registers on it."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "kernels.s")
+        flags = [f for f in FLAGS if f not in ("-fPIC", "-shared")]
+        cmd = [find_hipcc(), *flags, "-S", "--cuda-device-only", os.path.join(CSRC, SOURCES[0]), "-o", out]
+        r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stderr[-4000:])
+            raise subprocess.CalledProcessError(r.returncode, cmd)
+        with open(out) as f:
+            n = check_async_load_registers(f.read())
+    if verbose:
+        print(f"[racing_dreamer_amd.build] scan assembly: {n} in-flight table requests, none touched before its wait", flush=True)
+    return n
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB_PATH
@@ -92,6 +165,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print("\n".join(other), file=sys.stderr)
     try:
         check_resource_usage(r.stderr)
+        verify_scan_assembly(verbose)
     except RuntimeError:
         os.remove(tmp)
         raise

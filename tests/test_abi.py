@@ -126,3 +126,35 @@ def test_build_refuses_a_scan_kernel_that_spills():
     other = ok + ("k.hip:9:1: remark: Function Name: _ZN12_GLOBAL__N_118rc_dynamics_kernelILi4EEEv8RcParamsPfijjj [-Rpass-analysis=kernel-resource-usage]\n"
                   "k.hip:9:1: remark:     VGPRs Spill: 12 [-Rpass-analysis=kernel-resource-usage]\n")
     build.check_resource_usage(other)           # kernels without such loads may spill
+
+
+def test_build_refuses_a_copy_of_a_register_with_a_load_in_flight():
+    """The other half of the same hazard: no spill, but an instruction that reads (or overwrites) the destination of the scan's
+    inline-assembly table request before the `s_waitcnt vmcnt(0)` that belongs to it.  The build walks the kernels' assembly."""
+    import pytest
+    from racing_dreamer_amd import build
+    ok = """
+_ZN12_GLOBAL__N_121rc_raycast_car_kernelILi1ELb0ELb0EEEv8RcParamsi:
+	v_mad_u32_u24 v49, v48, s36, v49
+	;;#ASMSTART
+	global_load_ushort v49, v49, s[16:17]
+	;;#ASMEND
+	v_cndmask_b32_e64 v55, v50, v54, s[2:3]
+	v_add_f32_e32 v55, 0.5, v55
+	s_and_saveexec_b64 s[28:29], vcc
+	;;#ASMSTART
+	s_waitcnt vmcnt(0)
+	;;#ASMEND
+	v_mov_b32_e32 v51, v49
+	s_endpgm
+"""
+    assert build.check_async_load_registers(ok) == 1
+    with pytest.raises(RuntimeError, match="touches v49"):
+        build.check_async_load_registers(ok.replace("v_add_f32_e32 v55, 0.5, v55", "v_mov_b32_e32 v51, v49"))
+    with pytest.raises(RuntimeError, match="touches v49"):
+        build.check_async_load_registers(ok.replace("v_cndmask_b32_e64 v55, v50, v54, s[2:3]", "v_fma_f32 v[48:49], v1, v2, v3"))
+    with pytest.raises(RuntimeError, match="does not see"):
+        build.check_async_load_registers(ok.replace("global_load_ushort", "global_load_dword"))
+    # the same instructions in another kernel are nobody's business
+    other = ok.replace("rc_raycast_car_kernel", "rc_dynamics_kernel").replace("v_add_f32_e32 v55, 0.5, v55", "v_mov_b32_e32 v51, v49")
+    assert build.check_async_load_registers(ok + other) == 1
