@@ -13,3 +13,4 @@ for f in ('bench_default', 'bench_driver_flags'):
     print(f, 'value', round(d['value']/1e6, 1), 'M  ms/step', round(d['ms_per_step'], 4), d['kernels_ms'], d['roofline']['kernel'], round(d['roofline']['frac'], 4), 'cpu x', round(d['cpu_baseline']['speedup_all_over_one_thread'], 2), 'on', d['cpu_baseline']['cores_effective'])
 "
 bash tools/bench_one_rank_rccl.sh | tee $out/bench_one_rank_rccl.txt
+python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -2
