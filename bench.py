@@ -506,16 +506,16 @@ def main():
         mean_range_random = float(env.views["lidar"].float().mean().item())
         env.reset(mode="random", seed=0)
         for k in range(150):                      # let the cars settle on the racing line
-            env.follow_the_gap()
+            env.follow_the_gap_reference()
             env.step(None)
         env.sync()
         env.reset_kernel_times()
-        env.set_profiling(True, kernels=[L.K_RAYCAST])
+        env.set_profiling(True, kernels=[L.K_RAYCAST, L.K_FTG])
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         n_ftg = max(args.steps // 4, 5)
         for k in range(n_ftg):
-            env.follow_the_gap()
+            env.follow_the_gap_reference()
             env.step(None)
         env.sync()
         torch.cuda.synchronize()
@@ -524,10 +524,13 @@ def main():
         kt = env.kernel_times()
         ftg = {"env_steps_per_s": args.envs * n_ftg * args.repeat / dtf, "steps": n_ftg,
                "raycast_ms": round(kt["rc_raycast_kernel"]["avg_ms"], 4),
+               "agent_kernel_ms": round(kt["rc_ftg_kernel"]["avg_ms"], 4),
                "mean_range_m": float(env.views["lidar"].float().mean().item()),
+               "mean_speed_m_s": float(env.views["speed"].float().mean().item()),
                "mean_range_m_random_actions": mean_range_random,
-               "note": "same envs driven by the device follow-the-gap agent after 150 settling steps (cars on the racing "
-                       "line, long rays) instead of random actions; includes the agent's kernel"}
+               "note": "same envs driven by rc_follow_the_gap_reference - the law of the reference's own follow-the-gap node "
+                       "(ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent - after 150 settling steps "
+                       "(cars on the racing line, long rays) instead of random actions; includes the agent's kernel"}
 
     if distributed:
         times = [dt, dt4] + [v[0] for v in mode_legs.values()] + ([batch_leg[0]] if batch_leg else [])
