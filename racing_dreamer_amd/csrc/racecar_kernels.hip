@@ -2048,8 +2048,9 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
     const int lane = threadIdx.x & 63;
     const int car = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (car >= p.n_cars) return;
-    __shared__ float lds_r[4][FR_PER_LANE * 64 + 2], lds_j[4][FR_PER_LANE * 64];
+    __shared__ float lds_r[4][FR_PER_LANE * 64 + 2], lds_j[4][FR_PER_LANE * 64], lds_p[4][2][FR_PER_LANE * 64 + 64];
     float *r = lds_r[threadIdx.x >> 6], *jump = lds_j[threadIdx.x >> 6];
+    float *pa = lds_p[threadIdx.x >> 6][0], *pb = lds_p[threadIdx.x >> 6][1];
     const float *scan = p.out.lidar + (size_t)car * RC_N_BEAMS;
     // the arc, clipped at the look-ahead distance (agent.py:141-146); consecutive lanes read consecutive beams
     float rv[FR_PER_LANE];
@@ -2075,23 +2076,45 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
         jump[a] = jv[k];
     }
     __builtin_amdgcn_wave_barrier();
-    // disparities (agent.py:150-159): a jump that is the maximum of its 39-beam window (mirrored at the ends), exceeds 0.2 m
-    // and nine times the window's median (ends repeated) - the median only where the first two tests pass
+    // The maximum of every 39-beam window (agent.py:154, scipy's 'reflect' border) by doubling: the jumps padded with their
+    // mirror image (19 each side) in LDS, then windows of 2, 4, 8, 16, 32 - each pass one neighbour read and one maximum
+    // per element - and 39 = 32 and 32 seven further on.  Element i of the padded array is jump[i - 19]; the window of
+    // beam a is padded [a, a + 38].
+    constexpr int kPad = 2 * FR_HALF, kPadded = FR_N - 1 + kPad;      // 758 values
+    float w[FR_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        const int i = lane + 64 * k;
+        int a = i - FR_HALF;
+        a = a < 0 ? -a - 1 : (a >= FR_N - 1 ? 2 * (FR_N - 1) - a - 1 : a);
+        w[k] = i < kPadded ? jump[a] : 0.0f;
+        pa[i] = w[k];
+    }
+    if (lane < 64) pa[FR_PER_LANE * 64 + lane] = 0.0f, pb[FR_PER_LANE * 64 + lane] = 0.0f;       // (reads beyond the array: zeros)
+    float *src = pa, *dst = pb;
+#pragma unroll
+    for (int sft = 1; sft <= 16; sft <<= 1) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FR_PER_LANE; ++k) {
+            const int i = lane + 64 * k;
+            const float o = src[i + sft];
+            w[k] = o > w[k] ? o : w[k];
+            dst[i] = w[k];
+        }
+        float *t2 = src; src = dst; dst = t2;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // disparities (agent.py:150-159): a jump that is the maximum of its window, exceeds 0.2 m and nine times the window's
+    // median (ends repeated) - the median only where the first two tests pass
     float adj[FR_PER_LANE];
     bool cand[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
         const int a = lane + 64 * k;
         adj[k] = a < FR_N ? rv[k] : INFINITY;                         // (slots beyond the arc: above every rank)
-        float peak = 0.0f;
-        if (a < FR_N - 1) {
-            for (int w = -FR_HALF; w <= FR_HALF; ++w) {
-                int i = a + w;
-                i = i < 0 ? -i - 1 : (i >= FR_N - 1 ? 2 * (FR_N - 1) - i - 1 : i);
-                const float v = jump[i];
-                peak = v > peak ? v : peak;
-            }
-        }
+        const float o = src[a + 7];
+        const float peak = o > w[k] ? o : w[k];                       // windows [a, a + 31] and [a + 7, a + 38] of the padded array
         cand[k] = a < FR_N - 1 && jv[k] == peak && jv[k] > 0.2f;
     }
 #pragma unroll
