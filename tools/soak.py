@@ -1,5 +1,6 @@
 """Soak run (GPU box): long random-action rollouts on every track, every output finite, ranges within [0, 15], and a
-spot check of the last scan against the CPU oracle.  Also prints the time rc_load_track takes per track."""
+spot check of the last scan - and, where the track's bitmap fits the LDS, the last lidar_occupancy patches - against the CPU
+oracle.  Also prints the time rc_load_track takes per track (table builds + the bounded validation scan from every free cell)."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
@@ -16,7 +17,12 @@ if len(sys.argv) > 2 and sys.argv[2] == "all":           # python tools/soak.py 
 for name in names:
     t = load_track(name)
     t0 = time.perf_counter()
-    env = BatchedRaceEnv(t, 16384, 1, auto_reset=True)
+    try:
+        env = BatchedRaceEnv(t, 16384, 1, auto_reset=True, obs_type="lidar_occupancy")
+        occ = True
+    except Exception:                                   # the render needs the bitmap in the 160 KB LDS
+        env = BatchedRaceEnv(t, 16384, 1, auto_reset=True)
+        occ = False
     env.sync()
     t_load = time.perf_counter() - t0
     env.reset(mode="random", seed=1)
@@ -35,9 +41,13 @@ for name in names:
     o.reset()
     o.arr["x"][:], o.arr["y"][:], o.arr["theta"][:] = pose[:n, 0], pose[:n, 1], pose[:n, 5]
     o.arr["st"][:], o.arr["ct"][:] = ro.sincos32(pose[:n, 5].astype(np.float32))
+    o.arr["fresh"][:] = out["fresh"].reshape(-1)[:n].cpu().numpy()
+    o.cfg.render_occupancy = occ
     o._observe()
     same = np.array_equal(o.lidar, lid[:n].cpu().numpy())
-    print(f"{name:18s} load {t_load:5.2f} s  {steps} steps in {dt:5.2f} s  finite/in-range {ok}  last scan == oracle {same}", flush=True)
-    assert ok and same
+    same_patch = (not occ) or np.array_equal(o.patch, out["lidar_occupancy"].reshape(-1, 64, 64)[:n].cpu().numpy())
+    print(f"{name:18s} load {t_load:5.2f} s  {steps} steps in {dt:5.2f} s  finite/in-range {ok}  last scan == oracle {same}  "
+          f"{'last patches == oracle ' + str(same_patch) if occ else '(bitmap too large for the render)'}  overruns {env.scan_overruns()}", flush=True)
+    assert ok and same and same_patch
     env.close()
 print("soak ok")
