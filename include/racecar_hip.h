@@ -290,6 +290,15 @@ int rc_p2p_teardown(rc_env *env);
  * (dreamer/wrappers.py:213-219, dreamer/tools.py:235-264): one arena per time slot, rotate before each step. */
 int rc_set_arena(rc_env *env, void *arena, size_t bytes);
 
+/* Rows out of a ring of arenas - the window gather of a replay sampler (the reference reads fixed-length windows out of
+ * episode files: dreamer/tools.py:235-264).  ring_base + k * slot_bytes is arena k of a ring filled through rc_set_arena;
+ * output row r takes the record of car car_idx[r] in slot slot_idx[r] (device int32 arrays), for every field of
+ * field_mask (bit f = rc_field f): section f of the output holds n_rows records of that field back to back, sections in
+ * field order, each starting on a 64-byte boundary (rc_gather_rows_bytes = the total).  Queued on the handle's stream. */
+size_t rc_gather_rows_bytes(rc_env *env, uint32_t field_mask, int32_t n_rows);
+int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const int32_t *slot_idx_dev, const int32_t *car_idx_dev,
+                   int32_t n_rows, uint32_t field_mask, void *out_dev, size_t out_bytes);
+
 int rc_sync(rc_env *env);
 void *rc_stream(rc_env *env);      /* the hipStream_t the handle launches on */
 

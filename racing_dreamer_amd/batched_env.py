@@ -459,6 +459,31 @@ class BatchedRaceEnv:
         new["action_in"] = self._own_views["action_in"]
         self.views = new
 
+    def gather_rows(self, ring: torch.Tensor, slot_bytes: int, slots: torch.Tensor, cars: torch.Tensor, names) -> Dict[str, torch.Tensor]:
+        """`rc_gather_rows`: for every row r the record of car `cars[r]` in ring slot `slots[r]` (int32 device tensors),
+        the fields `names`, as one launch.  Returns name -> tensor [rows, ...] (views of one fresh buffer)."""
+        names = [n for n in names if n in _FIELD_VIEWS and n != "action_in" and n in self._host_layout]
+        order = sorted(names, key=lambda n: _FIELD_VIEWS[n][0])
+        mask = 0
+        for n in order:
+            mask |= 1 << _FIELD_VIEWS[n][0]
+        rows = int(slots.numel())
+        nbytes = int(self._lib.rc_gather_rows_bytes(self._h, mask, rows))
+        out = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        slots = slots.to(torch.int32).contiguous()
+        cars = cars.to(torch.int32).contiguous()
+        self._enter()
+        L.check(self._lib.rc_gather_rows(self._h, ring.data_ptr(), int(slot_bytes), slots.data_ptr(), cars.data_ptr(), rows, mask,
+                                         out.data_ptr(), nbytes))
+        self._exit()
+        res, off = {}, 0
+        for n in order:
+            fid, dtype, tail = _FIELD_VIEWS[n]
+            per = self._host_layout[n][1] // self.n_cars
+            res[n] = out[off:off + per * rows].view(dtype).view(rows, *tail)
+            off = (off + per * rows + 63) // 64 * 64
+        return res
+
     def host_snapshot(self) -> Dict[str, np.ndarray]:
         """Every output field on the host from ONE device-to-host copy of the arena (for small batches, e.g. the
         single-env shim): dict of NumPy views [num_envs, cars_per_env, ...] into one host buffer."""

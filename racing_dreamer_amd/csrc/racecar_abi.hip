@@ -1042,6 +1042,37 @@ int rc_trajectory_slab(rc_env *env, void **dev_ptr, size_t *bytes) {
     return RC_OK;
 }
 
+size_t rc_gather_rows_bytes(rc_env *env, uint32_t field_mask, int32_t n_rows) {
+    if (!env || n_rows < 1) return 0;
+    size_t off = 0;
+    for (int f = 0; f < RC_F_COUNT; ++f)
+        if (((field_mask >> f) & 1u) && env->layout.bytes[f]) off = align_up(off + kFieldBytes[f] * (size_t)n_rows, 64);
+    return off;
+}
+
+int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const int32_t *slot_idx_dev, const int32_t *car_idx_dev,
+                   int32_t n_rows, uint32_t field_mask, void *out_dev, size_t out_bytes) {
+    if (!env || !ring_base || !slot_idx_dev || !car_idx_dev || !out_dev) return fail(RC_ERR_INVALID, "NULL argument");
+    if (n_rows < 1) return fail(RC_ERR_INVALID, "n_rows must be >= 1");
+    if (slot_bytes < env->layout.total) return fail(RC_ERR_INVALID, "slot_bytes %zu is smaller than an arena (%zu)", slot_bytes, env->layout.total);
+    if (env->shared_arena) return fail(RC_ERR_INVALID, "rc_gather_rows works on whole arenas, not on a slice handle");
+    size_t src[RC_GATHER_MAX_FIELDS], dst[RC_GATHER_MAX_FIELDS], off = 0;
+    uint32_t bpc[RC_GATHER_MAX_FIELDS];
+    int n = 0;
+    for (int f = 0; f < RC_F_COUNT; ++f) {
+        if (!((field_mask >> f) & 1u)) continue;
+        if (f == RC_F_ACTION_IN || !env->layout.bytes[f]) return fail(RC_ERR_INVALID, "field %d is not part of a recorded arena in this configuration", f);
+        src[n] = env->layout.offset[f]; dst[n] = off; bpc[n] = (uint32_t)kFieldBytes[f];
+        off = align_up(off + kFieldBytes[f] * (size_t)n_rows, 64);
+        ++n;
+    }
+    if (n == 0) return fail(RC_ERR_INVALID, "empty field mask");
+    if (out_bytes < off) return fail(RC_ERR_INVALID, "output too small: %zu < %zu", out_bytes, off);
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(rck_gather_rows(ring_base, slot_bytes, slot_idx_dev, car_idx_dev, n_rows, src, dst, bpc, n, out_dev, env->stream));
+    return RC_OK;
+}
+
 int rc_sync(rc_env *env) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     HIP_TRY(hipSetDevice(env->cfg.device));

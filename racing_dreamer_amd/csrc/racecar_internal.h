@@ -101,6 +101,9 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
                                  // (identical results)
 };
 
+#define RC_GATHER_MAX_FIELDS 24
+hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *slot_idx, const int32_t *car_idx, int n_rows,
+                           const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s);
 #define RC_P2P_MAX_RANKS 64
 #define RC_P2P_TIMEOUT_S 20.0                   // bound of a flag poll (a peer that never posts: an error, not a hung queue)
 struct RcP2pPost {               // one store per lane: flag[p] = value (null entries skipped)

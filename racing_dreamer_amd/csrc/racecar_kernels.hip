@@ -2376,6 +2376,46 @@ hipError_t rck_validate_tables(const RcTrackDev &t, float band, hipStream_t s, u
     return e;
 }
 
+// ---- rows out of a ring of arenas (rc_gather_rows: the window gather of replay.TrajectoryRing.sample) --------------------
+// One wave per output row r: the record of car car_idx[r] in ring slot slot_idx[r], field by field, into the field's section
+// of the output (row r of section f at out + sec[f] + r * bpc[f]).  The LiDAR row goes as 270 16-byte vectors, the small
+// fields as words / bytes.
+struct RcGatherRows {
+    size_t src_off[RC_GATHER_MAX_FIELDS], dst_off[RC_GATHER_MAX_FIELDS];
+    uint32_t bpc[RC_GATHER_MAX_FIELDS];
+    int32_t n_fields;
+};
+__global__ __launch_bounds__(256) void rc_gather_rows_kernel(const char *__restrict__ ring, size_t slot_bytes, const int32_t *__restrict__ slot_idx,
+                                                             const int32_t *__restrict__ car_idx, int n_rows, RcGatherRows g, char *__restrict__ out) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const unsigned lane = threadIdx.x & 63u;
+    const size_t slot = (size_t)slot_idx[row] * slot_bytes;
+    const size_t car = (size_t)car_idx[row];
+    for (int f = 0; f < g.n_fields; ++f) {
+        const uint32_t n = g.bpc[f];
+        const char *src = ring + slot + g.src_off[f] + car * n;
+        char *dst = out + g.dst_off[f] + (size_t)row * n;
+        if ((n & 15u) == 0u) {                                   // (sections are 64-byte aligned and n is a multiple of 16: aligned vectors)
+            for (uint32_t o = lane * 16u; o < n; o += 64u * 16u) *reinterpret_cast<v4u *>(dst + o) = *reinterpret_cast<const v4u *>(src + o);
+        } else if ((n & 3u) == 0u) {
+            for (uint32_t o = lane * 4u; o < n; o += 64u * 4u) *reinterpret_cast<uint32_t *>(dst + o) = *reinterpret_cast<const uint32_t *>(src + o);
+        } else {
+            for (uint32_t o = lane; o < n; o += 64u) dst[o] = src[o];
+        }
+    }
+}
+
+hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *slot_idx, const int32_t *car_idx, int n_rows,
+                           const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s) {
+    RcGatherRows g{};
+    g.n_fields = n_fields;
+    for (int f = 0; f < n_fields; ++f) { g.src_off[f] = src_off[f]; g.dst_off[f] = dst_off[f]; g.bpc[f] = bpc[f]; }
+    hipLaunchKernelGGL(rc_gather_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, (const char *)ring, slot_bytes, slot_idx, car_idx,
+                       n_rows, g, (char *)out);
+    return hipGetLastError();
+}
+
 // ---- flags of the peer-copy all-gather (rc_gather_trajectory_p2p): sequence numbers in uncached device memory that a
 // PEER's kernel writes (over xGMI) and the owner's kernel polls.  Both kernels are one wave; the poll is bounded (wall
 // clock) and reports a time-out instead of hanging the queue.

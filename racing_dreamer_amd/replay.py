@@ -139,13 +139,31 @@ class TrajectoryRing:
             raise RuntimeError(f"could not find {batch} windows of {length} records without an episode boundary")
         t0 = torch.cat(keep_t)[:batch]; e = torch.cat(keep_e)[:batch]; c = torch.cat(keep_c)[:batch]
         slots = (oldest + t0[:, None] + ar[None, :]) % self.capacity
-        out = {name: self.fields[name][slots, e[:, None], c[:, None]] for name in names}
         terminal = torch.zeros(batch, dtype=torch.bool, device=dev)
         if length > 1:
             terminal = (fresh[slots[:, -1], e, c] != 0) & (done[slots[:, -1], e, c] != 0)
-            for name in OBSERVATION_FIELDS:                   # the new episode's observation is not this episode's
-                if name in out:
-                    out[name][terminal, -1] = out[name][terminal, -2]
+        if hasattr(self.env, "gather_rows") and self.buffer.is_cuda:
+            # one launch per group of fields (rc_gather_rows: a wave per row) instead of one indexing kernel chain per field.
+            # A terminal row takes its observation from the record before it (the new episode's observation is not this
+            # episode's): for the observation fields that row simply reads the previous slot.
+            cars = (e * self.env.cars_per_env + c)[:, None].expand(batch, length).reshape(-1)
+            slots_obs = slots.clone()
+            if length > 1:
+                slots_obs[:, -1] = torch.where(terminal, slots[:, -2], slots[:, -1])
+            obs_names = [n for n in names if n in OBSERVATION_FIELDS]
+            rest = [n for n in names if n not in OBSERVATION_FIELDS]
+            rows = {}
+            if obs_names:
+                rows.update(self.env.gather_rows(self.buffer, self.slot_bytes, slots_obs.reshape(-1), cars, obs_names))
+            if rest:
+                rows.update(self.env.gather_rows(self.buffer, self.slot_bytes, slots.reshape(-1), cars, rest))
+            out = {n: v.view(batch, length, *v.shape[1:]) for n, v in rows.items()}
+        else:
+            out = {name: self.fields[name][slots, e[:, None], c[:, None]] for name in names}
+            if length > 1:
+                for name in OBSERVATION_FIELDS:               # the new episode's observation is not this episode's
+                    if name in out:
+                        out[name][terminal, -1] = out[name][terminal, -2]
         if reset_rows:
             first = self.fields["fresh"][slots[:, 0], e, c] != 0               # window starts an episode
             if "action" in out:

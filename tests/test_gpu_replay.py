@@ -137,3 +137,44 @@ def test_set_arena_rejects_bad_buffers():
     env.set_arena(None)
     env.reset()
     env.close()
+
+
+def test_native_window_gather_equals_tensor_indexing():
+    """rc_gather_rows (one wave per row, every field of the mask in one launch) against plain advanced indexing on the ring's
+    strided views - the LiDAR rows as 16-byte vectors, 24-byte poses, single-byte flags, the 4 KB patches - and through
+    TrajectoryRing.sample: the terminal rows' observations come from the record before them."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.replay import OBSERVATION_FIELDS, TrajectoryRing
+    env = BatchedRaceEnv("columbia", 96, 2, obs_type="lidar_occupancy", auto_reset=True, action_repeat=4)
+    ring = TrajectoryRing(env, capacity=12)
+    ring.reset(mode="random_ball", seed=1)
+    for k in range(60):
+        ring.step_random(seed=2, step=k)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rows = 500
+    slots = torch.randint(0, 12, (rows,), device="cuda", generator=g)
+    e = torch.randint(0, 96, (rows,), device="cuda", generator=g)
+    c = torch.randint(0, 2, (rows,), device="cuda", generator=g)
+    names = ["lidar", "pose", "velocity", "speed", "action", "reward", "discount", "progress_total", "time", "lidar_occupancy",
+             "progress", "lap", "done", "fresh", "wall_collision", "steering_angle"]
+    got = env.gather_rows(ring.buffer, ring.slot_bytes, slots, e * 2 + c, names)
+    torch.cuda.synchronize()
+    for n in names:
+        assert torch.equal(got[n], ring.fields[n][slots, e, c]), n
+    with pytest.raises(Exception, match="NULL argument|empty field mask"):
+        env.gather_rows(ring.buffer, ring.slot_bytes, slots, e * 2 + c, [])
+    # through the sampler: identical to the indexing form of the same draw
+    g1, g2 = torch.Generator(device="cuda").manual_seed(9), torch.Generator(device="cuda").manual_seed(9)
+    fields = ("lidar", "lidar_occupancy", "action", "reward", "discount", "time", "speed", "done", "fresh")
+    a = ring.sample(768, 3, fields=fields, generator=g1)
+    native = env.gather_rows
+    try:
+        del BatchedRaceEnv.gather_rows                  # the indexing path of the same sampler
+        b = ring.sample(768, 3, fields=fields, generator=g2)
+    finally:
+        BatchedRaceEnv.gather_rows = native.__func__
+    assert set(a) == set(b) and bool(a["terminal"].any())
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
+    env.close()
