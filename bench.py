@@ -65,6 +65,8 @@ def parse_args():
                          "or rc_gather_trajectory_p2p (direct peer copies over hipIpc handles, one copy stream per peer)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-gather-modes", action="store_true", help="N>1: skip the short legs that time the other gather modes")
+    ap.add_argument("--no-gather-check", action="store_true",
+                    help="N>1: skip the self-check of every gathered payload (each rank's shard against the sender's checksum)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -144,7 +146,7 @@ class Gatherer:
         elif getattr(env, "compact", None) is not None:
             env.disable_compact()               # this leg's scan does not write the uint16 rows, its step does not copy the summary
         self.in_place = every == 1 or via != "torch"
-        self.arenas, self._k = None, 0
+        self.arenas, self._k, self._sent, self._last_dst = None, 0, 0, None
         if self.in_place and mode in ("full", "summary"):
             second = torch.zeros(env.arena_nbytes + 64, dtype=torch.uint8, device=env.device)
             pad = (-second.data_ptr()) % 64
@@ -177,7 +179,9 @@ class Gatherer:
         if self.via == "abi":
             # the collective before last wrote dst[k]: order this one behind it, then send the record just produced
             env.gather_wait(host_sync=False)
-            env.gather(self.mode, self.dst[self._k & 1])
+            self._last_dst = self.dst[self._sent & 1]
+            env.gather(self.mode, self._last_dst)
+            self._sent += 1
         elif self.via == "p2p":
             env.gather_p2p(self.mode)
         else:
@@ -195,6 +199,48 @@ class Gatherer:
             self.env.gather_p2p_wait(host_sync=True)
         else:
             self.tg.wait()
+
+    @staticmethod
+    def _checksum(t):
+        """Two sums over the record's 32-bit words (plain, and weighted by position), in wrapping int64."""
+        import torch
+        w = t.contiguous().view(torch.int32).to(torch.int64)
+        pos = torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 65521 + 1
+        return [int(w.sum().item()), int((w * pos).sum().item())]
+
+    def check(self, step, k0, dist_mod):
+        """Self-check of the collective on whatever hardware this run is on: three steps in the timed loop's own rhythm (each
+        followed by its collective, the next step launched behind it into the other buffer of the pair), one more step to
+        overwrite what a late read would see, then every rank compares EVERY rank's shard of the last gathered record with the
+        checksum that rank took of the record before it was sent.  Returns {"ok", "ranks", ...}; the same on all ranks."""
+        import torch
+        if not self.in_place:
+            return {"ok": None, "skipped": "staged batches (--gather-every > 1)"}
+        mine = None
+        for j in range(3):
+            step(k0 + j)
+            mine = self._checksum(self._source())
+            if j == 2 and os.environ.get("RC_BENCH_CORRUPT_GATHER") == str(dist_mod.get_rank()):
+                self._source()[5] ^= 1           # tests: this check must see a single flipped bit in one rank's record
+            self.after_step()
+        step(k0 + 3)
+        self.wait()
+        self.env.sync()
+        if self.via == "abi":
+            got = self._last_dst.view(self.world, -1)
+        elif self.via == "p2p":
+            got = torch.from_numpy(self.env.gathered_p2p_host())
+        else:
+            got = self.tg.wait()
+        sums = [None] * self.world
+        dist_mod.all_gather_object(sums, mine)
+        bad = [r for r in range(self.world) if self._checksum(got[r]) != sums[r]]
+        oks = [None] * self.world
+        dist_mod.all_gather_object(oks, not bad)
+        out = {"ok": all(oks), "ranks": self.world, "records_in_flight": 3, "bytes_per_rank": self.bytes, "via": self.via}
+        if bad:
+            out["bad_shards_seen_by_this_rank"] = bad
+        return out
 
     def close(self):
         """Leave the env as it was found: outputs in its own arena."""
@@ -429,7 +475,11 @@ def main():
     step_no += r4_steps
     headline_bytes = gather.bytes if gather is not None else 0
     headline_in_place = gather.in_place if gather is not None else True
+    gather_checks = {}
     if gather is not None:
+        if not args.no_gather_check:
+            gather_checks[gather_mode] = gather.check(lambda k: env.step_random(seed=1, step=k), step_no, dist)
+            step_no += 4
         gather.close()
 
     # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
@@ -457,6 +507,9 @@ def main():
             mode_legs[m] = [time.perf_counter() - t1, n_leg]
             step_no += 3 + n_leg
             if g is not None:
+                if not args.no_gather_check:
+                    gather_checks[m] = g.check(lambda k: env.step_random(seed=1, step=k), step_no, dist)
+                    step_no += 4
                 g.close()
     if getattr(env, "_p2p_mode", None) is not None:
         p2p_close()
@@ -637,6 +690,10 @@ def main():
                                   f"rejection loop synchronises the host once per sample")
                 table["batch"] = e
             out["gather_modes"] = table
+        if gather_checks:
+            # every payload's collective checked on THIS hardware: each rank's shard of the last of three in-flight records
+            # equals the checksum its sender took before sending (Gatherer.check)
+            out["gather_check"] = dict(ok=all(c["ok"] is not False for c in gather_checks.values()), payloads=gather_checks)
         if ftg is not None:
             out["follow_the_gap"] = ftg
     env.close()
@@ -661,6 +718,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if any(c["ok"] is False for c in gather_checks.values()):
+        print(f"bench.py: rank {rank}: a gathered record differs from what its sender sent: {gather_checks}", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -76,6 +76,23 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["config"]["comm_ranks"] == 2
     assert d["config"]["comm_backend"] == "gloo" and d["config"]["rccl_ranks"] is None      # (RCCL needs a GPU per rank)
     assert set(d["gather_modes"]) == {"full-u16", "full", "summary", "none", "batch"}
+    # every payload's collective checked by the run itself: both ranks' shards of the gathered record against the senders' checksums
+    gc = d["gather_check"]
+    assert gc["ok"] is True and set(gc["payloads"]) == {"full-u16", "full", "summary"}
+    assert all(c["ok"] is True and c["ranks"] == 2 and c["via"] == "torch" for c in gc["payloads"].values())
+
+
+def test_bench_sees_one_flipped_bit_in_a_gathered_record():
+    """The self-check is live: one bit flipped in rank 1's record after its checksum was taken, before the collective -
+    the line says so and the run fails (each rank exits 4; the launcher reports the failure)."""
+    import os
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1",
+                        "--envs", "1024", "--no-gather-modes"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RC_BENCH_CORRUPT_GATHER="1"))
+    assert r.returncode != 0, _errtext(r.stderr)
+    d = _json_line(r.stdout)
+    assert d["gather_check"]["ok"] is False and d["gather_check"]["payloads"]["full-u16"]["ok"] is False
+    assert "differs from what its sender sent" in r.stderr
 
 
 def test_bench_two_ranks_peer_copy_transport():
@@ -87,6 +104,9 @@ def test_bench_two_ranks_peer_copy_transport():
     assert d["config"]["gather_via"] == "p2p" and "rc_gather_trajectory_p2p" in d["config"]["workload"]
     gm = d["gather_modes"]
     assert all(gm[m]["ms_per_step"] > 0 for m in ("full-u16", "full", "summary", "none", "batch"))
+    gc = d["gather_check"]
+    assert gc["ok"] is True and all(gc["payloads"][m]["ok"] is True and gc["payloads"][m]["via"] == "p2p"
+                                    for m in ("full-u16", "full", "summary"))
 
 
 def test_bench_two_ranks_functional():
