@@ -549,6 +549,32 @@ class MixedTrackEnv:
             t = self.arena[off.value:off.value + per.value * self.n_cars].view(dtype)
             self.views[name] = t.view(self.num_envs, self.cars_per_env, *tail)
 
+    @classmethod
+    def from_track_ids(cls, tracks, track_id, **kw):
+        """An ARBITRARY per-env track assignment (`track_id[e]` indexes `tracks`): the envs are laid out in the arena sorted by
+        track (stable), because a workgroup of the render shares one bitmap in LDS and a wave's table lines should be its
+        neighbours'; `row_of_env[e]` is the arena row of the caller's env e, `env_of_row` its inverse, and `to_rows` /
+        `to_envs` reorder a leading-axis tensor between the two orders (one indexed copy).  Row r draws from reset stream
+        `first_env + r`."""
+        ids = torch.as_tensor(track_id, dtype=torch.int64).cpu().reshape(-1)
+        if ids.numel() == 0 or int(ids.min()) < 0 or int(ids.max()) >= len(tracks):
+            raise ValueError("track_id must index tracks")
+        used = [i for i in range(len(tracks)) if bool((ids == i).any())]
+        env = cls([tracks[i] for i in used], [int((ids == i).sum()) for i in used], **kw)
+        env.env_of_row = torch.argsort(ids, stable=True).to(env.device)
+        env.row_of_env = torch.empty_like(env.env_of_row)
+        env.row_of_env[env.env_of_row] = torch.arange(ids.numel(), device=env.device)
+        env.track_id = torch.as_tensor(used, dtype=torch.int32, device=env.device)[env.track_id.long()]   # ids as the caller numbered them
+        return env
+
+    def to_rows(self, x: torch.Tensor) -> torch.Tensor:
+        """Caller order [num_envs, ...] -> arena order (e.g. actions before `step`)."""
+        return x.to(self.device)[self.env_of_row]
+
+    def to_envs(self, x: torch.Tensor) -> torch.Tensor:
+        """Arena order -> caller order (e.g. `to_envs(out["lidar"])`)."""
+        return x[self.row_of_env]
+
     # Every block runs on a stream of its own, forked from and joined to the caller's current stream around each call: the
     # blocks' kernels overlap (a block of a third of the batch leaves the tail of its scan half empty; the next block's
     # waves fill it), and the caller sees one stream-ordered operation.

@@ -932,6 +932,39 @@ def test_mixed_track_env_blocks_equal_their_oracles():
     one.close()
 
 
+def test_mixed_track_env_from_an_arbitrary_per_env_track_assignment():
+    """`MixedTrackEnv.from_track_ids`: any per-env track list (here interleaved, one track of the list unused); the arena is
+    sorted by track, `to_rows` / `to_envs` translate between the caller's env order and the arena's, and in the caller's
+    order every env equals the oracle of ITS track."""
+    import torch
+    from racing_dreamer_amd.batched_env import MixedTrackEnv
+    from racing_dreamer_amd.track_assets import load_track
+    from racing_dreamer_amd import spec
+    names = ["austria", "gbr", "columbia", "barcelona"]
+    ids = np.array([(3, 0, 2, 0, 3, 3, 2)[e % 7] for e in range(90)])          # "gbr" never drawn
+    env = MixedTrackEnv.from_track_ids(names, ids, auto_reset=True)
+    assert len(env.parts) == 3 and env.num_envs == 90
+    assert torch.equal(env.to_envs(env.track_id).cpu(), torch.from_numpy(ids).int())
+    assert torch.equal(env.to_envs(env.to_rows(torch.arange(90))).cpu(), torch.arange(90))
+    oras = [make_oracle(load_track(names[int(env.track_id[a])]), num_envs=b - a, auto_reset=True, first_env=a) for a, b in env.blocks]
+    env.reset(mode="random", seed=4)
+    for o in oras:
+        o.reset(mode=spec.RESET_RANDOM, seed=4)
+    rows = env.env_of_row.cpu().numpy()
+    for k in range(10):
+        act = ro.random_actions(3, k, 90)                                      # in the CALLER's env order
+        act[:, 0] = np.abs(act[:, 0])
+        dv = env.step(env.to_rows(torch.from_numpy(act).view(90, 1, 2)), repeat=2)
+        lidar_user = env.to_envs(dv["lidar"]).cpu().numpy()
+        for (a, b), o in zip(env.blocks, oras):
+            ov = o.step(act[rows[a:b]], repeat=2)
+            compare_outputs({k2: v[a:b] for k2, v in dv.items()}, ov, b - a, 1, f"step {k}, rows [{a}, {b})")
+            assert np.array_equal(lidar_user[rows[a:b], 0], np.asarray(ov["lidar"]).reshape(b - a, 1080))
+    env.close()
+    with pytest.raises(ValueError, match="index tracks"):
+        MixedTrackEnv.from_track_ids(names, [0, 4])
+
+
 def test_every_compiled_map_steps_like_the_oracle():
     """all 29 compiled maps of docs/maps/maps run on the device (any grid up to 4096 cells per side:
     columbia_simple is 1083 x 1489, f1_mco 937 x 1072) - reset, three agent steps and the scan against the C oracle."""
