@@ -2048,9 +2048,12 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
     const int lane = threadIdx.x & 63;
     const int car = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (car >= p.n_cars) return;
-    __shared__ float lds_r[4][FR_PER_LANE * 64 + 2], lds_j[4][FR_PER_LANE * 64], lds_p[4][2][FR_PER_LANE * 64 + 64];
-    float *r = lds_r[threadIdx.x >> 6], *jump = lds_j[threadIdx.x >> 6];
-    float *pa = lds_p[threadIdx.x >> 6][0], *pb = lds_p[threadIdx.x >> 6][1];
+    // Two arrays of 832 floats per wave (6.6 KB: six waves per SIMD).  `ra`: the clipped arc r[a] - overwritten by the window
+    // maxima while they are built, written again from registers afterwards; `jp`: the jumps with 19 mirrored values on each
+    // side (jp[i] = jump[i - 19]), kept to the end.  Both end in zeros (reads beyond the data).
+    constexpr int kBuf = FR_PER_LANE * 64 + 64;
+    __shared__ float lds_a[4][kBuf], lds_b[4][kBuf];
+    float *ra = lds_a[threadIdx.x >> 6], *jp = lds_b[threadIdx.x >> 6];
     const float *scan = p.out.lidar + (size_t)car * RC_N_BEAMS;
     // the arc, clipped at the look-ahead distance (agent.py:141-146); consecutive lanes read consecutive beams
     float rv[FR_PER_LANE];
@@ -2064,99 +2067,103 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
             v = v < kFrLookahead ? v : kFrLookahead;
         }
         rv[k] = v;
-        r[a] = v;
+        ra[a] = v;
     }
-    if (lane < 2) r[FR_PER_LANE * 64 + lane] = 0.0f;
+    ra[FR_PER_LANE * 64 + lane] = 0.0f;
+    jp[kBuf - 128 + lane] = 0.0f;                                    // [704, 768) - the jumps below overwrite what they own -
+    jp[kBuf - 64 + lane] = 0.0f;                                     // and [768, 832)
     __builtin_amdgcn_wave_barrier();
+    constexpr int kPad = 2 * FR_HALF, kPadded = FR_N - 1 + kPad;      // 758 padded values
     float jv[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
         const int a = lane + 64 * k;
-        jv[k] = a < FR_N - 1 ? fabsf(r[a + 1] - rv[k]) : 0.0f;      // agent.py:148
-        jump[a] = jv[k];
+        jv[k] = a < FR_N - 1 ? fabsf(ra[a + 1] - rv[k]) : 0.0f;     // agent.py:148
     }
     __builtin_amdgcn_wave_barrier();
-    // The maximum of every 39-beam window (agent.py:154, scipy's 'reflect' border) by doubling: the jumps padded with their
-    // mirror image (19 each side) in LDS, then windows of 2, 4, 8, 16, 32 - each pass one neighbour read and one maximum
-    // per element - and 39 = 32 and 32 seven further on.  Element i of the padded array is jump[i - 19]; the window of
-    // beam a is padded [a, a + 38].
-    constexpr int kPad = 2 * FR_HALF, kPadded = FR_N - 1 + kPad;      // 758 values
-    float w[FR_PER_LANE];
-#pragma unroll
-    for (int k = 0; k < FR_PER_LANE; ++k) {
-        const int i = lane + 64 * k;
-        int a = i - FR_HALF;
-        a = a < 0 ? -a - 1 : (a >= FR_N - 1 ? 2 * (FR_N - 1) - a - 1 : a);
-        w[k] = i < kPadded ? jump[a] : 0.0f;
-        pa[i] = w[k];
-    }
-    if (lane < 64) pa[FR_PER_LANE * 64 + lane] = 0.0f, pb[FR_PER_LANE * 64 + lane] = 0.0f;       // (reads beyond the array: zeros)
-    float *src = pa, *dst = pb;
-#pragma unroll
-    for (int sft = 1; sft <= 16; sft <<= 1) {
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < FR_PER_LANE; ++k) {
-            const int i = lane + 64 * k;
-            const float o = src[i + sft];
-            w[k] = o > w[k] ? o : w[k];
-            dst[i] = w[k];
-        }
-        float *t2 = src; src = dst; dst = t2;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // disparities (agent.py:150-159): a jump that is the maximum of its window, exceeds 0.2 m and nine times the window's
-    // median (ends repeated) - the median only where the first two tests pass
-    float adj[FR_PER_LANE];
-    bool cand[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
         const int a = lane + 64 * k;
-        adj[k] = a < FR_N ? rv[k] : INFINITY;                         // (slots beyond the arc: above every rank)
-        const float o = src[a + 7];
-        const float peak = o > w[k] ? o : w[k];                       // windows [a, a + 31] and [a + 7, a + 38] of the padded array
-        cand[k] = a < FR_N - 1 && jv[k] == peak && jv[k] > 0.2f;
+        if (a < FR_N - 1) jp[a + FR_HALF] = jv[k];
+        if (k == 0 && a < FR_HALF) jp[FR_HALF - 1 - a] = jv[k];                                  // scipy's 'reflect' border
+        if (k >= 10 && a >= FR_N - 1 - FR_HALF && a < FR_N - 1) jp[2 * (FR_N - 1) - 1 - a + FR_HALF] = jv[k];
     }
+    __builtin_amdgcn_wave_barrier();
+    // The maximum of every 39-beam window (agent.py:154) by doubling: windows of 2, 4, 8, 16, 32 - each pass one neighbour read
+    // and one maximum per element, in place in `ra` (all reads of a pass before its writes) - and 39 = 32 and 32 seven further
+    // on.  The window of beam a is padded [a, a + 38].
+    float w[FR_PER_LANE], o[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
-        unsigned long long todo = __builtin_amdgcn_ballot_w64(cand[k]);
-        while (todo != 0) {
-            const int l = __builtin_ctzll(todo);
-            todo &= todo - 1;
-            const int ac = l + 64 * k;                                // wave-uniform
-            // median of the window: lane m < 39 holds sample m; its rank = samples below it (ties by position)
-            int i = ac - FR_HALF + lane;
-            i = i < 0 ? 0 : (i > FR_N - 2 ? FR_N - 2 : i);
-            const float mine = jump[i];
-            int rank = 0;
+        const int i = lane + 64 * k;
+        const float x = jp[i], y = jp[i + 1];
+        w[k] = y > x ? y : x;
+    }
 #pragma unroll
-            for (int m = 0; m < 2 * FR_HALF + 1; ++m) {
-                const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), m));
-                rank += (o < mine || (o == mine && m < lane)) ? 1 : 0;
-            }
-            const unsigned long long is_med = __builtin_amdgcn_ballot_w64(lane <= 2 * FR_HALF && rank == FR_HALF);
-            const float med = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), __builtin_ctzll(is_med)));
-            const float jc = jump[ac];
-            if (!(jc > med * 9.0f)) continue;
-            // extend the nearer side by the half-width of the vehicle as seen at that range (agent.py:165-176)
-            const float near = fminf(fminf(r[ac > 0 ? ac - 1 : 0], r[ac]), r[ac + 1]);
-            const float two = 2.0f * (near * near);
-            const float half = fr_acos((two - kFrW2) / two);
-            int ia = 0, ib = 0;
-            if (half == half) {
-                const float a0 = fr_angle(0), at = fr_angle(ac);
-                const float lo = ((at - half) - a0) / kFrInc, hi = ((at + half) - a0) / kFrInc;
-                ia = (int)lo; ib = (int)hi;
-                ia = ia < 0 ? 0 : (ia > FR_N - 1 ? FR_N - 1 : ia);
-                ib = ib < 0 ? 0 : (ib > FR_N - 1 ? FR_N - 1 : ib);
-            }
+    for (int k = 0; k < FR_PER_LANE; ++k) ra[lane + 64 * k] = w[k];
 #pragma unroll
-            for (int e = 0; e < FR_PER_LANE; ++e) {
-                const int a = lane + 64 * e;
-                if (a >= ia && a <= ib) adj[e] = adj[e] < near ? adj[e] : near;
-            }
+    for (int sft = 2; sft <= 16; sft <<= 1) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FR_PER_LANE; ++k) o[k] = ra[lane + 64 * k + sft];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < FR_PER_LANE; ++k) {
+            w[k] = o[k] > w[k] ? o[k] : w[k];
+            ra[lane + 64 * k] = w[k];
         }
     }
+    __builtin_amdgcn_wave_barrier();
+    // candidates (agent.py:150-156): a jump that is the maximum of its window and exceeds 0.2 m; bit k of `cbits` = this
+    // lane's element k is one
+    uint32_t cbits = 0u;
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) {
+        const int a = lane + 64 * k;
+        const float x = ra[a + 7];
+        const float peak = x > w[k] ? x : w[k];                       // windows [a, a + 31] and [a + 7, a + 38] of the padded array
+        if (a < FR_N - 1 && jv[k] == peak && jv[k] > 0.2f) cbits |= 1u << k;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) ra[lane + 64 * k] = rv[k];  // the arc again (rv[] becomes the adjusted arc below)
+    __builtin_amdgcn_wave_barrier();
+    // One candidate at a time, the wave together (their order does not matter: the extension is a minimum).  A candidate is a
+    // disparity if it exceeds nine times the MEDIAN of its window (agent.py:157-159, ends repeated) - and since x -> fl(9 x) is
+    // monotone, "jump > 9 median" holds exactly when at least 20 of the 39 samples satisfy "jump > 9 sample": no sorting.
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(cbits != 0u);
+    while (todo != 0) {
+        const int l = __builtin_ctzll(todo);
+        const uint32_t bits = (uint32_t)__builtin_amdgcn_readlane((int)cbits, l);
+        const int ac = l + 64 * __builtin_ctz(bits);                  // wave-uniform
+        if (lane == l) cbits &= cbits - 1u;
+        if ((bits & (bits - 1u)) == 0u) todo &= todo - 1;
+        int i = ac - FR_HALF + lane;
+        i = i < 0 ? 0 : (i > FR_N - 2 ? FR_N - 2 : i);
+        const float mine = jp[i + FR_HALF];
+        const float jc = jp[ac + FR_HALF];
+        if (wave_count(lane <= 2 * FR_HALF && jc > mine * 9.0f) <= FR_HALF) continue;
+        // extend the nearer side by the half-width of the vehicle as seen at that range (agent.py:165-176)
+        const float near = fminf(fminf(ra[ac > 0 ? ac - 1 : 0], ra[ac]), ra[ac + 1]);
+        const float two = 2.0f * (near * near);
+        const float half = fr_acos((two - kFrW2) / two);
+        int ia = 0, ib = 0;
+        if (half == half) {
+            const float a0 = fr_angle(0), at = fr_angle(ac);
+            const float lo = ((at - half) - a0) / kFrInc, hi = ((at + half) - a0) / kFrInc;
+            ia = (int)lo; ib = (int)hi;
+            ia = ia < 0 ? 0 : (ia > FR_N - 1 ? FR_N - 1 : ia);
+            ib = ib < 0 ? 0 : (ib > FR_N - 1 ? FR_N - 1 : ib);
+        }
+#pragma unroll
+        for (int e = 0; e < FR_PER_LANE; ++e) {
+            const int a = lane + 64 * e;
+            if (a >= ia && a <= ib) rv[e] = rv[e] < near ? rv[e] : near;
+        }
+    }
+    float adj[FR_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < FR_PER_LANE; ++k) adj[k] = lane + 64 * k < FR_N ? rv[k] : INFINITY;   // (slots beyond the arc: above every rank)
     // the 601st and 602nd smallest adjusted range (agent.py:183, np.percentile at q = 83.3): ranges are >= 0, so their
     // bit patterns order like the values; binary search on the pattern, counts by ballot
     uint32_t key[FR_PER_LANE];
@@ -2195,7 +2202,7 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
         count += wave_count(chosen);
         if (chosen) {
             sum_k += a;
-            sum_q += (uint32_t)__builtin_rintf(rv[k] * 524288.0f);
+            sum_q += (uint32_t)__builtin_rintf(ra[a] * 524288.0f);
         }
     }
 #pragma unroll
