@@ -1340,20 +1340,29 @@ int rc_p2p_connect(rc_env *env, const void *exports, size_t bytes) {
     for (int p = 0; p < x->world; ++p) {
         P2pExport ex;
         std::memcpy(&ex, (const char *)exports + (size_t)p * RC_P2P_EXPORT_BYTES, sizeof(ex));
-        if (ex.rank != p || ex.world != x->world || ex.bytes != x->cap)
+        if (ex.rank != p || ex.world != x->world || ex.bytes != x->cap) {
+            p2p_disconnect(env);
             return fail(RC_ERR_INVALID, "export blob %d does not match (rank %d, world %d, %llu bytes per slot entry; mine %zu)", p, ex.rank, ex.world,
                         (unsigned long long)ex.bytes, x->cap);
+        }
         if (p == x->rank) continue;
         // a peer on another GPU: let this device's copy engines and kernels reach its memory
         int pdev = -1;
         if (hipDeviceGetByPCIBusId(&pdev, ex.pci) == hipSuccess && pdev >= 0 && pdev != env->cfg.device) {
             hipError_t pe = hipDeviceEnablePeerAccess(pdev, 0);
-            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+            if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
+                p2p_disconnect(env);
                 return fail(RC_ERR_HIP, "hipDeviceEnablePeerAccess(%d) failed: %s", pdev, hipGetErrorString(pe));
+            }
             (void)hipGetLastError();
         }
-        HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_dst[p], ex.dst, hipIpcMemLazyEnablePeerAccess));
-        HIP_TRY(hipIpcOpenMemHandle((void **)&x->peer_flags[p], ex.flags, hipIpcMemLazyEnablePeerAccess));
+        // (a failure half way leaves nothing mapped: the call can be repeated)
+        hipError_t oe = hipIpcOpenMemHandle((void **)&x->peer_dst[p], ex.dst, hipIpcMemLazyEnablePeerAccess);
+        if (oe == hipSuccess) oe = hipIpcOpenMemHandle((void **)&x->peer_flags[p], ex.flags, hipIpcMemLazyEnablePeerAccess);
+        if (oe != hipSuccess) {
+            p2p_disconnect(env);
+            return fail(RC_ERR_HIP, "hipIpcOpenMemHandle of rank %d's buffers failed: %s", p, hipGetErrorString(oe));
+        }
     }
     x->connected = true;
     return RC_OK;

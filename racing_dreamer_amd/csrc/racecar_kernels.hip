@@ -2073,7 +2073,7 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
     jp[kBuf - 128 + lane] = 0.0f;                                    // [704, 768) - the jumps below overwrite what they own -
     jp[kBuf - 64 + lane] = 0.0f;                                     // and [768, 832)
     __builtin_amdgcn_wave_barrier();
-    constexpr int kPad = 2 * FR_HALF, kPadded = FR_N - 1 + kPad;      // 758 padded values
+    // (758 padded values: 720 jumps + 2 x 19)
     float jv[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
