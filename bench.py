@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=150,
+                    help="untimed steps between reset and the warm-up in which the random-action rollout spreads from the "
+                         "spawn poses (part of preparing the synthetic data; reported as config.settle_steps)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--cars", type=int, default=1)
     ap.add_argument("--track", default="austria")
@@ -250,7 +253,7 @@ class Gatherer:
             self._k = 0
 
 
-def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="random"):
+def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="random", settle=150):
     """One of BASELINE.json's other single-GPU configurations on the current device: ms per step, per-kernel times
     from launch-attached HIP events, whole-step and per-kernel HBM-roofline fractions."""
     import torch
@@ -258,6 +261,8 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
     env = BatchedRaceEnv(track_name, envs, cars, obs_type=obs_type, auto_reset=True)
     env.reset(mode=mode, seed=0)
     torch.cuda.set_stream(env.stream)
+    for k in range(settle):
+        env.step_random(seed=2, step=k)
     for k in range(warmup):
         env.step_random(seed=1, step=k)
     env.sync()
@@ -293,7 +298,7 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
     return out
 
 
-def time_mixed_tracks(names, envs, steps, warmup):
+def time_mixed_tracks(names, envs, steps, warmup, settle=150):
     """BASELINE.json configs[4]'s track mix inside ONE batch on the current device (not the 8-GPU run): `envs` envs in equal
     blocks on `names`, one handle per track filling one arena (MixedTrackEnv), random-action rollouts."""
     import torch
@@ -302,6 +307,8 @@ def time_mixed_tracks(names, envs, steps, warmup):
     env = MixedTrackEnv(list(names), per, auto_reset=True)
     env.reset(mode="random", seed=0)
     torch.cuda.set_stream(env.stream)
+    for k in range(settle):
+        env.step_random(seed=2, step=k)
     for k in range(warmup):
         env.step_random(seed=1, step=k)
     env.sync()
@@ -376,6 +383,11 @@ def main():
         name, _, val = kv.partition("=")
         env.debug_set(name, int(val))
     env.reset(mode="random", seed=0)
+    # the synthetic data is a random-action rollout that HAS SETTLED: right after a reset every car stands on the centre line
+    # looking along the track (longer rays, a scan 5 % slower than in the spread of poses a long run is made of)
+    for k in range(args.settle):
+        env.step_random(seed=2, step=k)
+    env.sync()
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     via = args.gather_via
     abi_ranks = None
@@ -551,9 +563,8 @@ def main():
         ring.detach()
         del rep, ring
 
-    # secondary figure: the long-ray case of SURVEY.md 8d - cars driven along the track by the follow-the-gap agent
-    # (the reference's other prefill policy, dreamer/dream.py:211-216) instead of crashing into walls with random
-    # actions: rank 0 only, single-GPU runs only (it is a property of the scan, not of the scaling)
+    # secondary figure: cars driven along the track at speed by the reference's follow-the-gap law (its other prefill
+    # policy, dreamer/dream.py:211-216) instead of crawling under random actions: rank 0 only, single-GPU runs only
     ftg = None
     if world == 1 and not args.no_cpu_baseline_ftg:
         mean_range_random = float(env.views["lidar"].float().mean().item())
@@ -583,7 +594,7 @@ def main():
                "mean_range_m_random_actions": mean_range_random,
                "note": "same envs driven by rc_follow_the_gap_reference - the law of the reference's own follow-the-gap node "
                        "(ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent - after 150 settling steps "
-                       "(cars on the racing line, long rays) instead of random actions; includes the agent's kernel"}
+                       "(cars lapping at speed, no crashes) instead of random actions; includes the agent's kernel"}
 
     if distributed:
         times = [dt, dt4] + [v[0] for v in mode_legs.values()] + ([batch_leg[0]] if batch_leg else [])
@@ -633,7 +644,8 @@ def main():
             "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic (random-action rollout, {args.settle} untimed settling steps after reset, then the warm-up)",
             "config": {
                 "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
                             f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
@@ -641,7 +653,7 @@ def main():
                             f"auto-reset, action_repeat {args.repeat}; {gather_txt}",
                 "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
                 "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
-                "obs_type": args.obs_type, "action_repeat": args.repeat,
+                "obs_type": args.obs_type, "action_repeat": args.repeat, "settle_steps": args.settle,
                 "parallelism": f"env-sharded x{world}", "gather": gather_mode, "gather_via": via if distributed else None,
                 # the size of the job as the communicator reports it (sum over ranks of 1 through the backend's own
                 # all-reduce; ncclCommCount of the C-ABI's communicator when that transport is used)
@@ -706,8 +718,8 @@ def main():
                      "lidar_occupancy", 100, 10, "random"),
                     ("configs[3]: 32 768 envs x 2 cars, treitlstrasse_v2, inter-car raycast + collision",
                      "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
-            out["configs"] = [time_config(*c) for c in cfgs]
-            out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10))
+            out["configs"] = [time_config(*c, settle=args.settle) for c in cfgs]
+            out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10, settle=args.settle))
         if not args.no_cpu_baseline and world == 1:
             from oracle import cpu_baseline as cb
             out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
