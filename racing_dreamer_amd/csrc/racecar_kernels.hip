@@ -2042,6 +2042,25 @@ __device__ __forceinline__ float fr_acos(float x) {                  // racecar_
 }
 __device__ __forceinline__ float fr_angle(int a) { return (float)(FR_FIRST + a) * kFrInc + kFrAmin; }
 __device__ __forceinline__ int wave_count(bool c) { return __builtin_popcountll(__builtin_amdgcn_ballot_w64(c)); }
+// Reductions over the 64 lanes on the DPP paths of the vector unit (one instruction per step, no LDS crossbar): within rows of
+// 16 by quad permutes and mirrors, then lane 15 of a row into the next (row_bcast:15, rows 1 and 3) and lane 31 into the upper
+// half (row_bcast:31); lane 63 holds the result.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_pull(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROWS, 0xF, false); }
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_reduce(uint32_t v, Op op) {
+    v = op(v, dpp_pull<0xB1, 0xF>(v));       // quad_perm:[1,0,3,2]
+    v = op(v, dpp_pull<0x4E, 0xF>(v));       // quad_perm:[2,3,0,1]
+    v = op(v, dpp_pull<0x141, 0xF>(v));      // row_half_mirror
+    v = op(v, dpp_pull<0x140, 0xF>(v));      // row_mirror: every lane of a row holds the row's result
+    const uint32_t r1 = dpp_pull<0x142, 0xA>(v);     // (rows not named keep their own value: see the selects)
+    v = (__lane_id() & 16) ? op(v, r1) : v;
+    const uint32_t r2 = dpp_pull<0x143, 0xC>(v);
+    v = (__lane_id() & 32) ? op(v, r2) : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_reduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return wave_reduce(v, [](uint32_t a, uint32_t b) { return a + b; }); }
 
 __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float *__restrict__ actions, float *__restrict__ prev_heading,
                                                                float dt, float *__restrict__ detail) {
@@ -2092,25 +2111,29 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
     // The maximum of every 39-beam window (agent.py:154) by doubling: windows of 2, 4, 8, 16, 32 - each pass one neighbour read
     // and one maximum per element, in place in `ra` (all reads of a pass before its writes) - and 39 = 32 and 32 seven further
     // on.  The window of beam a is padded [a, a + 38].
-    float w[FR_PER_LANE], o[FR_PER_LANE];
+    // (jumps are >= +0 and never NaN: their bit patterns order like the values, and an integer maximum is ONE instruction
+    // where the floating-point select is a compare and a move)
+    uint32_t *rau = reinterpret_cast<uint32_t *>(ra);
+    const uint32_t *jpu = reinterpret_cast<const uint32_t *>(jp);
+    uint32_t w[FR_PER_LANE], o[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
         const int i = lane + 64 * k;
-        const float x = jp[i], y = jp[i + 1];
+        const uint32_t x = jpu[i], y = jpu[i + 1];
         w[k] = y > x ? y : x;
     }
 #pragma unroll
-    for (int k = 0; k < FR_PER_LANE; ++k) ra[lane + 64 * k] = w[k];
+    for (int k = 0; k < FR_PER_LANE; ++k) rau[lane + 64 * k] = w[k];
 #pragma unroll
     for (int sft = 2; sft <= 16; sft <<= 1) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < FR_PER_LANE; ++k) o[k] = ra[lane + 64 * k + sft];
+        for (int k = 0; k < FR_PER_LANE; ++k) o[k] = rau[lane + 64 * k + sft];
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int k = 0; k < FR_PER_LANE; ++k) {
             w[k] = o[k] > w[k] ? o[k] : w[k];
-            ra[lane + 64 * k] = w[k];
+            rau[lane + 64 * k] = w[k];
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -2120,9 +2143,9 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
         const int a = lane + 64 * k;
-        const float x = ra[a + 7];
-        const float peak = x > w[k] ? x : w[k];                       // windows [a, a + 31] and [a + 7, a + 38] of the padded array
-        if (a < FR_N - 1 && jv[k] == peak && jv[k] > 0.2f) cbits |= 1u << k;
+        const uint32_t x = rau[a + 7];
+        const uint32_t peak = x > w[k] ? x : w[k];                    // windows [a, a + 31] and [a + 7, a + 38] of the padded array
+        if (a < FR_N - 1 && __float_as_uint(jv[k]) == peak && jv[k] > 0.2f) cbits |= 1u << k;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2158,24 +2181,34 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
 #pragma unroll
         for (int e = 0; e < FR_PER_LANE; ++e) {
             const int a = lane + 64 * e;
-            if (a >= ia && a <= ib) rv[e] = rv[e] < near ? rv[e] : near;
+            if (a >= ia && a <= ib) rv[e] = __uint_as_float(min(__float_as_uint(rv[e]), __float_as_uint(near)));      // (both >= +0)
         }
     }
     float adj[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) adj[k] = lane + 64 * k < FR_N ? rv[k] : INFINITY;   // (slots beyond the arc: above every rank)
     // the 601st and 602nd smallest adjusted range (agent.py:183, np.percentile at q = 83.3): ranges are >= 0, so their
-    // bit patterns order like the values; binary search on the pattern, counts by ballot
+    // bit patterns order like the values; binary search on the pattern, counts by ballot.  [lo, lo + 2^bit) always holds
+    // the wanted key (c_lo keys below it, c_hi below its end, c_lo <= 600 < c_hi): once it holds ONE key the search is
+    // over - about half way for a scan's spread of ranges; ties run to the last bit.
     uint32_t key[FR_PER_LANE];
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) key[k] = __float_as_uint(adj[k]);
     uint32_t x600 = 0u;
-    for (int bit = 30; bit >= 0; --bit) {
+    int c_lo = 0, c_hi = FR_PER_LANE * 64, bit = 30;
+    for (; bit >= 0; --bit) {
         const uint32_t trial = x600 | (1u << bit);
         int below = 0;
 #pragma unroll
         for (int k = 0; k < FR_PER_LANE; ++k) below += wave_count(key[k] < trial);
-        if (below <= 600) x600 = trial;
+        if (below <= 600) { x600 = trial; c_lo = below; } else c_hi = below;
+        if (c_hi - c_lo == 1) break;
+    }
+    if (bit >= 0) {                                                   // the one key at or above the bucket's start
+        uint32_t only = 0xffffffffu;
+#pragma unroll
+        for (int k = 0; k < FR_PER_LANE; ++k) only = key[k] >= x600 && key[k] < only ? key[k] : only;
+        x600 = wave_min_u32(only);
     }
     int not_above = 0;
     uint32_t next = 0x7f800000u;
@@ -2184,35 +2217,28 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
         not_above += wave_count(key[k] <= x600);
         if (key[k] > x600 && key[k] < next) next = key[k];
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)next, off);
-        next = o < next ? o : next;
-    }
-    const uint32_t x601 = not_above >= 602 ? x600 : next;
-    // NumPy's linear interpolation at virtual index 600.0000000000001: a + (b - a) * 2^-43 in binary64
+    const uint32_t x601 = not_above >= 602 ? x600 : wave_min_u32(next);
+    // NumPy's linear interpolation at virtual index 600.0000000000001: a + (b - a) * 2^-43 in binary64; a binary32 range is
+    // at or above that threshold exactly when it is at or above the threshold rounded UP to binary32
     const double a64 = (double)__uint_as_float(x600), b64 = (double)__uint_as_float(x601);
     const double thr = a64 + (b64 - a64) * 1.1368683772161603e-13;
-    int count = 0, sum_k = 0;
-    uint32_t sum_q = 0u;
+    float thr32 = (float)thr;
+    if ((double)thr32 < thr) thr32 = __uint_as_float(__float_as_uint(thr32) + 1u);      // (thr >= 0 and finite)
+    int count = 0;
+    uint32_t sum_k = 0u, sum_q = 0u;
 #pragma unroll
     for (int k = 0; k < FR_PER_LANE; ++k) {
         const int a = lane + 64 * k;
-        const bool chosen = a < FR_N && (double)adj[k] >= thr && adj[k] < RCS_MAX_RANGE;      // np.digitize(...) == 2
+        const bool chosen = a < FR_N && adj[k] >= thr32 && adj[k] < RCS_MAX_RANGE;           // np.digitize(...) == 2
         count += wave_count(chosen);
-        if (chosen) {
-            sum_k += a;
-            sum_q += (uint32_t)__builtin_rintf(ra[a] * 524288.0f);
-        }
+        sum_k += chosen ? (uint32_t)a : 0u;
+        sum_q += chosen ? (uint32_t)__builtin_rintf(ra[a] * 524288.0f) : 0u;
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        sum_k += __shfl_xor(sum_k, off);
-        sum_q += (uint32_t)__shfl_xor((int)sum_q, off);
-    }
+    sum_k = wave_sum_u32(sum_k);
+    sum_q = wave_sum_u32(sum_q);
     if (lane == 0) {
         const float cnt = (float)count;
-        const float heading = (((float)sum_k / cnt) + (float)FR_FIRST) * kFrInc + kFrAmin;          // agent.py:184
+        const float heading = (((float)(int)sum_k / cnt) + (float)FR_FIRST) * kFrInc + kFrAmin;          // agent.py:184
         const float hd = ((float)sum_q / cnt) * (1.0f / 524288.0f);                                 // agent.py:185
         // agent.py:200-234 with PID.calculate (kp 1.4, kd 0.1): no derivative term on an episode's first command
         const float prev = p.st.fresh[car] ? __builtin_nanf("") : prev_heading[car];
