@@ -594,7 +594,7 @@ def main():
                "mean_range_m_random_actions": mean_range_random,
                "note": "same envs driven by rc_follow_the_gap_reference - the law of the reference's own follow-the-gap node "
                        "(ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent - after 150 settling steps "
-                       "(cars lapping at speed, no crashes) instead of random actions; includes the agent's kernel"}
+                       "(cars at 4 m/s instead of crawling under random actions); includes the agent's kernel"}
 
     if distributed:
         times = [dt, dt4] + [v[0] for v in mode_legs.values()] + ([batch_leg[0]] if batch_leg else [])

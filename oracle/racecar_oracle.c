@@ -33,6 +33,8 @@
 #define LIDAR_X 0.25f
 #define WHEELBASE 0.3302f
 #define MAX_STEER 0.42f
+#define WHEEL_MAX 0.19f      /* front-wheel angle at full command; +1 = right: racecar_oracle.py, STEER_GAIN */
+#define STEER_GAIN -0.19f
 #define MAX_VEL 5.0f
 #define ACCEL_MAX 4.0f
 #define DRAG 0.8f
@@ -274,7 +276,7 @@ void oc_step_range(const oc_track *t, const oc_cfg *c, oc_state *s, const float 
                     const float force = fabsf(m) * ACCEL_MAX;
                     const float acc = (m >= 0.0f ? force : -force) - DRAG * s->v[i];
                     const float v = clampf(s->v[i] + acc * DT, 0.0f, MAX_VEL);
-                    const float dd = clampf(steer[a] * MAX_STEER - s->delta[i], -STEER_STEP, STEER_STEP);
+                    const float dd = clampf(steer[a] * STEER_GAIN - s->delta[i], -STEER_STEP, STEER_STEP);
                     const float dl = s->delta[i] + dd;
                     float sd, cd;
                     sincos32(dl, &sd, &cd);

@@ -28,8 +28,12 @@ env spec whose *interface* is pinned by the reference's call sit
 
 What IS pinned against the reference: the wrapper-layer semantics and the patch
 geometry, through tests/golden/*.npz captured from the importable reference wrappers
-(tests/golden/make_golden.py), and the Philox4x32-10 generator through the published
-Random123 known-answer vectors.
+(tests/golden/make_golden.py); the Philox4x32-10 generator through the published
+Random123 known-answer vectors; and - behaviourally - the core's handedness (a positive
+steering command turns towards higher beam indices = right) and steering lock (0.19 rad)
+through the reference's own trained Dreamer agents, which lap in this env and crash within
+seconds in its mirror image or with another lock (tests/test_golden_policy.py,
+oracle/dreamer_policy_port.py).
 
 Numerics contract: every float operation below is a single correctly-rounded IEEE
 binary32 operation (+, -, *, /, compare, floor, rint) applied in the written order - no
@@ -59,6 +63,15 @@ MAX_VEL = f32(5.0)
 ACCEL_MAX = f32(4.0)             # max_force 0.5 * 8.0
 DRAG = f32(0.8)                  # 1/s: ACCEL_MAX / MAX_VEL, so full throttle settles at max_velocity
 STEER_STEP = f32(0.032)          # 3.2 rad/s * dt
+# The steering command: +1 = full lock to the RIGHT (clockwise), front wheels at WHEEL_MAX.  Both are pinned by the
+# reference's own trained agents (ros_agent/checkpoints, tests/test_golden_policy.py): beams run left -> right
+# (dreamer/tools.py:84-86 draws index 0 on the left), and the Dreamer policies trained in the reference's simulator steer
+# towards HIGHER beam indices with POSITIVE commands - they lap in this env and crash within seconds in its mirror image -
+# and they lap only while full lock is 0.17-0.20 rad (0.12: understeer into the outer wall, 0.21: the inner one): the
+# simulated car turns less than half as sharply as the 0.42 rad the action space is nominally scaled to
+# (racing_dreamer.py:14).
+WHEEL_MAX = f32(0.19)
+STEER_GAIN = f32(-0.19)          # command -> wheel angle in the vehicle frame (counter-clockwise positive)
 INV_DT = f32(100.0)
 X_REAR, X_FRONT, HALF_W = -0.10, 0.45, 0.15
 BOX_CX = f32(0.175)              # (X_FRONT + X_REAR) / 2
@@ -194,13 +207,13 @@ def follow_the_gap(lidar, motor_straight=0.6, motor_corner=0.3):
     agents.gap_follower.GapFollower used by dreamer/dream.py:211-216): float32 [n, 2] = (motor, steering)."""
     lidar = np.asarray(lidar, f32).reshape(-1, N_BEAMS)
     lo, n, bubble = 135, 810, 60
-    r = np.where(lidar[:, lo:lo + n] > f32(3.0), f32(3.0), lidar[:, lo:lo + n]).astype(f32)
+    r = np.where(lidar[:, lo:lo + n] > f32(6.0), f32(6.0), lidar[:, lo:lo + n]).astype(f32)
     pad = np.zeros((len(r), n + 4), f32)
     pad[:, 2:-2] = r
     sm = ((((pad[:, 0:n] + pad[:, 1:n + 1]) + pad[:, 2:n + 2]) + pad[:, 3:n + 3]) + pad[:, 4:n + 4]) * f32(0.2)
     closest = sm.argmin(axis=1)                              # first minimum
     idx = np.arange(n)[None, :]
-    gap = (sm > f32(1.0)) & ((idx < closest[:, None] - bubble) | (idx > closest[:, None] + bubble))
+    gap = (sm > f32(2.0)) & ((idx < closest[:, None] - bubble) | (idx > closest[:, None] + bubble))
     out = np.zeros((len(r), 2), f32)
     for c in range(len(r)):
         g = np.concatenate([[0], gap[c].astype(np.int8), [0]])
@@ -211,7 +224,7 @@ def follow_the_gap(lidar, motor_straight=0.6, motor_corner=0.3):
         k = int((ends - starts).argmax())                    # first longest run
         centre = f32(lo) + f32(2 * starts[k] + (ends[k] - starts[k]) - 1) * f32(0.5)
         angle = f32(2.35619449019234492885) - centre * f32(0.00436737625568553)
-        steering = clamp32(angle / MAX_STEER, f32(-1.0), f32(1.0))
+        steering = clamp32(angle / STEER_GAIN, f32(-1.0), f32(1.0))         # the command that points the wheels at the gap
         out[c, 0] = motor_corner if abs(steering) > f32(0.35) else motor_straight
         out[c, 1] = steering
     return out
@@ -263,13 +276,14 @@ def ftgr_angles():
     return (np.arange(FTGR_FIRST, FTGR_FIRST + FTGR_N).astype(f32) * FTGR_INC + FTGR_AMIN).astype(f32)
 
 
-def follow_the_gap_reference(lidar, prev_heading, dt, max_steering=None, max_velocity=None):
+def follow_the_gap_reference(lidar, prev_heading, dt, wheel_max=None, max_velocity=None):
     """lidar float32 [n, 1080] in metres (the env's beam order), prev_heading float32 [n] (NaN = none yet), dt seconds per
     agent step.  Returns dict: action float32 [n, 2] = (motor, steering) in [-1, 1] - the node's speed over the car's top
-    speed, its steering angle over the car's steering limit -, heading, heading_distance, steering_angle, speed [n]."""
+    speed, and the command that puts the front wheels at the node's steering angle (positive command = right, the node's
+    angle is positive to the left; full lock beyond the car's WHEEL_MAX) -, heading, heading_distance, steering_angle, speed [n]."""
     lidar = np.asarray(lidar, f32).reshape(-1, N_BEAMS)
     n = len(lidar)
-    max_steering = MAX_STEER if max_steering is None else f32(max_steering)
+    steer_gain = STEER_GAIN if wheel_max is None else -f32(wheel_max)
     max_velocity = MAX_VEL if max_velocity is None else f32(max_velocity)
     ang = ftgr_angles()
     # arc element a = ROS beam 179 + a = env beam 900 - a
@@ -318,7 +332,7 @@ def follow_the_gap_reference(lidar, prev_heading, dt, max_steering=None, max_vel
     speed = np.where(np.abs(steer) > FTGR_DEG5, f32(6.0) - (np.abs(steer) / FTGR_MAX_STEER) * f32(1.8), f32(6.0)).astype(f32)
     speed = np.where(hd < f32(5.0), np.minimum(speed, (hd / f32(5.0)) * f32(4.0)), speed).astype(f32)
     speed = np.maximum(speed, f32(1.5)).astype(f32)
-    action = np.stack([clamp32(speed / max_velocity, f32(-1.0), f32(1.0)), clamp32(steer / max_steering, f32(-1.0), f32(1.0))], 1).astype(f32)
+    action = np.stack([clamp32(speed / max_velocity, f32(-1.0), f32(1.0)), clamp32(steer / steer_gain, f32(-1.0), f32(1.0))], 1).astype(f32)
     return dict(action=action, heading=heading, heading_distance=hd, steering_angle=steer, speed=speed)
 
 
@@ -451,7 +465,7 @@ class OracleRaceEnv:
             force = np.abs(m) * ACCEL_MAX
             acc = np.where(m >= f32(0.0), force, -force) - DRAG * v
             v = clamp32(v + acc * DT, f32(0.0), MAX_VEL)
-            dd = clamp32(s * MAX_STEER - delta, -STEER_STEP, STEER_STEP)
+            dd = clamp32(s * STEER_GAIN - delta, -STEER_STEP, STEER_STEP)
             delta = delta + dd
             sd, cd = sincos32(delta)
             omega = (v / WHEELBASE) * (sd / cd)

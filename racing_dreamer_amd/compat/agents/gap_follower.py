@@ -13,12 +13,12 @@ import numpy as np
 
 
 class GapFollower:
-    def __init__(self, max_range: float = 3.0, bubble_radius: int = 60, smooth: int = 5, gap_range: float = 1.0,
+    def __init__(self, max_range: float = 6.0, bubble_radius: int = 60, smooth: int = 5, gap_range: float = 2.0,
                  fov_deg: float = 270.0,
-                 max_steering: float = 0.42, straights_speed: float = 0.6, corners_speed: float = 0.3):
+                 wheel_max: float = 0.19, straights_speed: float = 0.6, corners_speed: float = 0.3):
         self.max_range, self.bubble, self.smooth, self.gap_range = max_range, bubble_radius, smooth, gap_range
         self.fov = np.radians(fov_deg)
-        self.max_steering = max_steering
+        self.wheel_max = wheel_max             # front-wheel angle at full command; a positive command steers right (spec.STEER_GAIN)
         self.straights_speed, self.corners_speed = straights_speed, corners_speed
 
     def action(self, obs):
@@ -36,7 +36,7 @@ class GapFollower:
         k = int((ends - starts).argmax())
         best = lo + (starts[k] + ends[k] - 1) / 2.0
         angle = self.fov / 2.0 - best * self.fov / (n - 1)          # beam 0 is at +135 deg, sweep is clockwise
-        steering = float(np.clip(angle / self.max_steering, -1.0, 1.0))
+        steering = float(np.clip(-angle / self.wheel_max, -1.0, 1.0))
         motor = self.corners_speed if abs(steering) > 0.35 else self.straights_speed
         return motor, steering
 
@@ -53,8 +53,8 @@ class ReferenceGapFollower:
     WIDTH = 0.3302 * 1.2
     MAX_STEER = np.deg2rad(24.0)
 
-    def __init__(self, dt: float = 0.04, max_steering: float = 0.42, max_velocity: float = 5.0, range_max: float = 15.0):
-        self.dt, self.max_steering, self.max_velocity, self.range_max = dt, max_steering, max_velocity, range_max
+    def __init__(self, dt: float = 0.04, wheel_max: float = 0.19, max_velocity: float = 5.0, range_max: float = 15.0):
+        self.dt, self.wheel_max, self.max_velocity, self.range_max = dt, wheel_max, max_velocity, range_max
         self.previous = None
         self.last = {}
 
@@ -101,4 +101,4 @@ class ReferenceGapFollower:
             speed = min(speed, dist / 5 * 4)
         speed = max(speed, 1.5)
         self.last = dict(heading=h, heading_distance=dist, steering_angle=steer, speed=speed)
-        return float(np.clip(speed / self.max_velocity, -1.0, 1.0)), float(np.clip(steer / self.max_steering, -1.0, 1.0))
+        return float(np.clip(speed / self.max_velocity, -1.0, 1.0)), float(np.clip(-steer / self.wheel_max, -1.0, 1.0))

@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
                 const float force = fabsf(m) * RCS_ACCEL_MAX;
                 const float acc = (m >= 0.0f ? force : -force) - RCS_DRAG * c.v;
                 c.v = clampf(c.v + acc * RCS_DT, 0.0f, RCS_MAX_VEL);
-                const float dd = clampf(steer[a] * RCS_MAX_STEER - c.dl, -RCS_STEER_STEP, RCS_STEER_STEP);
+                const float dd = clampf(steer[a] * RCS_STEER_GAIN - c.dl, -RCS_STEER_STEP, RCS_STEER_STEP);
                 c.dl = c.dl + dd;
                 float sd, cd;
                 sincos32(c.dl, sd, cd);
@@ -1899,7 +1899,8 @@ __global__ __launch_bounds__(1024) void rc_patch_car_kernel(RcParams p) {
 #define FTG_N 810
 #define FTG_PER_LANE 13
 #define FTG_BUBBLE 60
-#define FTG_GAP_RANGE 1.0f      // a beam belongs to a gap if its smoothed range exceeds this [m]
+#define FTG_GAP_RANGE 2.0f      // a beam belongs to a gap if its smoothed range exceeds this [m]
+#define FTG_CLIP 6.0f           // ranges are clipped here first (with the 0.19 rad lock the car must see a corner early)
 
 struct RunSummary { int len, pre, suf, best, bstart, all; };
 
@@ -1935,7 +1936,7 @@ __global__ __launch_bounds__(256) void rc_ftg_kernel(RcParams p, float *__restri
         float v = 0.0f;
         if (e < FTG_N) {
             v = scan[FTG_LO + e];
-            v = v > 3.0f ? 3.0f : v;
+            v = v > FTG_CLIP ? FTG_CLIP : v;
         }
         row[e] = v;
     }
@@ -2001,7 +2002,7 @@ __global__ __launch_bounds__(256) void rc_ftg_kernel(RcParams p, float *__restri
         if (s.best > 0) {
             const float centre = (float)FTG_LO + ((float)(2 * s.bstart + s.best - 1)) * 0.5f;
             const float angle = 2.35619449019234492885f - centre * 0.00436737625568553f;   // 135 deg - i * 270/1079 deg
-            steering = clampf(angle / RCS_MAX_STEER, -1.0f, 1.0f);
+            steering = clampf(angle / RCS_STEER_GAIN, -1.0f, 1.0f);          // the command that points the wheels at the gap (+ = right)
             motor = fabsf(steering) > 0.35f ? motor_corner : motor_straight;
         }
         actions[2 * car] = motor;
@@ -2251,7 +2252,7 @@ __global__ __launch_bounds__(256) void rc_ftg_reference_kernel(RcParams p, float
         speed = speed > 1.5f ? speed : 1.5f;
         prev_heading[car] = heading;
         // the car's actuators: target speed over its top speed, steering angle over its steering limit
-        float motor = clampf(speed / RCS_MAX_VEL, -1.0f, 1.0f), steering = clampf(steer / RCS_MAX_STEER, -1.0f, 1.0f);
+        float motor = clampf(speed / RCS_MAX_VEL, -1.0f, 1.0f), steering = clampf(steer / RCS_STEER_GAIN, -1.0f, 1.0f);
         if (p.remap_actions) {                 // the caller's convention is ReduceActionSpace's (wrappers.py:128-130): invert it
             motor = ((motor - p.act_lo0) * 2.0f) / (p.act_hi0 - p.act_lo0) - 1.0f;
             steering = ((steering - p.act_lo1) * 2.0f) / (p.act_hi1 - p.act_lo1) - 1.0f;

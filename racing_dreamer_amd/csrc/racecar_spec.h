@@ -7,7 +7,9 @@
 #define RCS_MAX_RANGE 15.0f       // dreamer/tools.py:274
 #define RCS_LIDAR_X 0.25f
 #define RCS_WHEELBASE 0.3302f     // ros_agent/agents/follow_the_gap/src/agent.py:78
-#define RCS_MAX_STEER 0.42f       // ros_agent/models/dreamer/racing_dreamer.py:14
+#define RCS_MAX_STEER 0.42f       // ros_agent/models/dreamer/racing_dreamer.py:14 (the nominal scale of the steering action)
+#define RCS_WHEEL_MAX 0.19f       // front-wheel angle at full command - and +1 steers RIGHT: both pinned by the reference's trained
+#define RCS_STEER_GAIN -0.19f     // agents (tests/test_golden_policy.py): command -> wheel angle, counter-clockwise positive
 #define RCS_MAX_VEL 5.0f          // ros_agent/models/dreamer/racing_dreamer.py:16
 #define RCS_ACCEL_MAX 4.0f        // max_force 0.5 (racing_dreamer.py:15) * 8 m/s^2 per unit force
 #define RCS_DRAG 0.8f             // 1/s = ACCEL_MAX / MAX_VEL: full throttle settles at max_velocity

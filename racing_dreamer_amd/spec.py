@@ -21,7 +21,9 @@ LIDAR_X = 0.25                # sensor origin ahead of the rear axle [m]        
 
 # --- vehicle ----------------------------------------------------------------------
 WHEELBASE = 0.3302            # ros_agent/agents/follow_the_gap/src/agent.py:78
-MAX_STEER = 0.42              # ros_agent/models/dreamer/racing_dreamer.py:14
+MAX_STEER = 0.42              # ros_agent/models/dreamer/racing_dreamer.py:14 (nominal scale of the steering action)
+WHEEL_MAX = 0.19              # front-wheel angle at full command [rad]; a POSITIVE command steers RIGHT (clockwise): both
+STEER_GAIN = -WHEEL_MAX       # pinned by the reference's trained agents (tests/test_golden_policy.py)
 MAX_FORCE = 0.5               # ros_agent/models/dreamer/racing_dreamer.py:15
 MAX_VEL = 5.0                 # ros_agent/models/dreamer/racing_dreamer.py:16
 FORCE_TO_ACCEL = 8.0          # m/s^2 per unit motor force                          (free)

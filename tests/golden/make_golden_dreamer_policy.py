@@ -1,0 +1,58 @@
+"""Fixture generator (run in the BUILD container, where /root/reference exists; the outputs are committed, this script never runs
+on the GPU box): the weights of the reference's own trained Dreamer agents - ros_agent/checkpoints/<name>/{rssm,actor}.pkl, the
+checkpoints its ROS node deploys (ros_agent/models/dreamer/racing_dreamer.py:30-36) - as plain float32 arrays.
+
+    python tests/golden/make_golden_dreamer_policy.py     ->  tests/golden/dreamer_policy_{austria,treitlstrasse}.npz
+
+The pickles are read with an allow-list unpickler: nothing but NumPy array reconstruction may be named in them (they are
+`pickle.dump(tf.Module.variables as numpy)`, dreamer/tools.py:26-33).  Array order = `tf.Module.variables` order, identified
+by shape: GRU cell (kernel, recurrent kernel, bias [2, 600] = reset_after), Dense img1, img2, img3, obs1 (1 280 = deter 200 +
+the 1 080-beam scan: the deployed agent has no encoder, encoder.pkl is empty), obs2; actor h0..h3, hout.
+"""
+import hashlib
+import os
+import pickle
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.dreamer_policy_port import ACTOR_KEYS, RSSM_KEYS   # noqa: E402
+
+CHECKPOINTS = "/root/reference/ros_agent/checkpoints"
+RSSM_SHAPES = [(200, 600), (200, 600), (2, 600), (32, 200), (200,), (200, 200), (200,), (200, 60), (60,), (1280, 200), (200,), (200, 60), (60,)]
+ACTOR_SHAPES = [(230, 400), (400,), (400, 400), (400,), (400, 400), (400,), (400, 400), (400,), (400, 4), (4,)]
+
+
+class ArraysOnly(pickle.Unpickler):
+    ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"), ("numpy", "dtype")}
+
+    def find_class(self, module, name):
+        if (module, name) in self.ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"refused to load {module}.{name}: the checkpoint may only hold NumPy arrays")
+
+
+def read(path, shapes):
+    with open(path, "rb") as f:
+        raw = f.read()
+    arrays = ArraysOnly(__import__("io").BytesIO(raw)).load()
+    assert [a.shape for a in arrays] == shapes and all(a.dtype == np.float32 for a in arrays), path
+    return list(arrays), hashlib.sha256(raw).hexdigest()
+
+
+def main():
+    for name, directory in (("austria", "austria_dreamer"), ("treitlstrasse", "treitlstrasse_dreamer")):
+        rssm, h1 = read(os.path.join(CHECKPOINTS, directory, "rssm.pkl"), RSSM_SHAPES)
+        actor, h2 = read(os.path.join(CHECKPOINTS, directory, "actor.pkl"), ACTOR_SHAPES)
+        out = dict(zip(RSSM_KEYS, rssm))
+        out.update(zip(ACTOR_KEYS, actor))
+        out["source"] = np.array(f"ros_agent/checkpoints/{directory}/rssm.pkl sha256 {h1}; actor.pkl sha256 {h2}")
+        path = os.path.join(ROOT, "tests", "golden", f"dreamer_policy_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

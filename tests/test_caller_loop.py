@@ -32,7 +32,7 @@ class ScriptedPolicy:
         self.calls.append(({k: np.asarray(v).shape for k, v in obs.items()}, np.asarray(done).copy(), state))
         scan = obs["lidar"][0]
         steer = float(np.clip((scan[700:900].mean() - scan[180:380].mean()) * 0.4, -1, 1))   # towards the open side
-        return np.array([[self.motor, -steer]]), (0 if state is None else state + 1)
+        return np.array([[self.motor, steer]]), (0 if state is None else state + 1)      # (+ = right)
 
 
 def _dreamer_env(W, episodes, duration=25):

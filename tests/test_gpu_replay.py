@@ -146,11 +146,14 @@ def test_native_window_gather_equals_tensor_indexing():
     import torch
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
     from racing_dreamer_amd.replay import OBSERVATION_FIELDS, TrajectoryRing
+    from oracle import racecar_oracle as ro
     env = BatchedRaceEnv("columbia", 96, 2, obs_type="lidar_occupancy", auto_reset=True, action_repeat=4)
     ring = TrajectoryRing(env, capacity=12)
     ring.reset(mode="random_ball", seed=1)
     for k in range(60):
-        ring.step_random(seed=2, step=k)
+        act = ro.random_actions(2, k, 192)
+        act[:, 0] = 1.0                                     # full throttle, random steering: episodes end within a second or two
+        ring.step(torch.from_numpy(act).cuda().view(96, 2, 2))
     g = torch.Generator(device="cuda").manual_seed(3)
     rows = 500
     slots = torch.randint(0, 12, (rows,), device="cuda", generator=g)

@@ -159,7 +159,7 @@ def test_caller_loop_on_the_hip_shim(tmp_path, monkeypatch):
         scan = obs["lidar"][0]
         steer = float(np.clip((scan[700:900].mean() - scan[180:380].mean()) * 0.4, -1, 1))
         k = 0 if state is None else state + 1
-        return np.array([[0.3 + 0.1 * (k % 3), -steer]]), k
+        return np.array([[0.3 + 0.1 * (k % 3), steer]]), k                     # (+ = right)
 
     path = _scenario(tmp_path, "columbia")
     runs = []

@@ -72,15 +72,16 @@ def test_raycast_max_range_and_start_inside_wall():
 
 
 def test_bicycle_known_answer_circle_arc():
-    """Constant speed and steering -> circle of radius L / tan(delta) (explicit Euler, dt = 0.01)."""
+    """Constant speed and steering -> circle of radius L / tan(delta) (explicit Euler, dt = 0.01); a NEGATIVE command
+    turns the wheels to the left (counter-clockwise, delta > 0): delta = command x STEER_GAIN."""
     env = _box_env(size=600)
     env.centerline[0, :2] = 15.0
     env.reset()
     env.v[:] = 2.0
-    env.delta[:] = 0.3
-    act = np.array([[0.4, 0.3 / 0.42]], np.float32)      # throttle 0.4 holds 2 m/s, steering holds delta
+    env.delta[:] = 0.15
+    act = np.array([[0.4, -0.15 / 0.19]], np.float32)    # throttle 0.4 holds 2 m/s, steering holds delta
     env.v[:] = 2.0
-    r = 0.3302 / np.tan(0.3)
+    r = 0.3302 / np.tan(0.15)
     x0, y0, th0 = float(env.x[0]), float(env.y[0]), float(env.theta[0])
     n = 200
     for _ in range(n):

@@ -27,6 +27,7 @@ def test_constants_agree():
         ("LIDAR_X", spec.LIDAR_X, ro.LIDAR_X, c["LIDAR_X"]), ("WHEELBASE", spec.WHEELBASE, ro.WHEELBASE, c["WHEELBASE"]),
         ("MAX_STEER", spec.MAX_STEER, ro.MAX_STEER, c["MAX_STEER"]), ("MAX_VEL", spec.MAX_VEL, ro.MAX_VEL, c["MAX_VEL"]),
         ("ACCEL_MAX", spec.ACCEL_MAX, ro.ACCEL_MAX, c["ACCEL_MAX"]), ("DRAG", spec.DRAG, ro.DRAG, c["DRAG"]),
+        ("WHEEL_MAX", spec.WHEEL_MAX, ro.WHEEL_MAX, c["WHEEL_MAX"]), ("STEER_GAIN", spec.STEER_GAIN, ro.STEER_GAIN, c["STEER_GAIN"]),
         ("STEER_STEP", spec.STEER_RATE * spec.DT, ro.STEER_STEP, c["STEER_STEP"]),
         ("BOX_CX", (spec.X_FRONT + spec.X_REAR) / 2, ro.BOX_CX, c["BOX_CX"]),
         ("BOX_HL", (spec.X_FRONT - spec.X_REAR) / 2, ro.BOX_HL, c["BOX_HL"]),
