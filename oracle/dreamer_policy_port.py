@@ -11,7 +11,7 @@ What it follows (reference files, read as text; nothing is imported from them - 
     tanh-transformed normal wrapped in SampleDist.
   * dreamer/tools.py:318-321                            SampleDist.mode: the one of 100 samples with the highest log-probability.
   * tf.keras.layers.GRUCell (TF 2 defaults: reset_after=True - the checkpoint's (2, 600) bias says so -, sigmoid gates, tanh candidate).
-The weights are the reference's own checkpoint files (ros_agent/checkpoints/<name>/{rssm,actor}.pkl: tuples of float32 arrays in
+The weights are the reference's own checkpoint files (ros_agent/checkpoints/<name>/{rssm,actor,reward}.pkl: tuples of float32 arrays in
 `tf.Module.variables` order), converted by tests/golden/make_golden_dreamer_policy.py, which unpickles them with an allow-list
 (numpy array reconstruction only).
 
@@ -25,6 +25,7 @@ RAW_INIT_STD = float(np.log(np.exp(5.0) - 1.0))
 RSSM_KEYS = ("gru_kernel", "gru_recurrent", "gru_bias", "img1_w", "img1_b", "img2_w", "img2_b", "img3_w", "img3_b",
              "obs1_w", "obs1_b", "obs2_w", "obs2_b")
 ACTOR_KEYS = ("h0_w", "h0_b", "h1_w", "h1_b", "h2_w", "h2_b", "h3_w", "h3_b", "hout_w", "hout_b")
+REWARD_KEYS = ("reward_h0_w", "reward_h0_b", "reward_h1_w", "reward_h1_b", "reward_hout_w", "reward_hout_b")
 
 
 def elu(x):
@@ -36,13 +37,13 @@ def softplus(x):
 
 
 def sigmoid(x):
-    return (1.0 / (1.0 + np.exp(-x))).astype(f32)
+    return (1.0 / (1.0 + np.exp(-np.clip(x, -60.0, 60.0)))).astype(f32)
 
 
 class DreamerPolicy:
     def __init__(self, weights, sample=True, seed=0):
         """weights: mapping with RSSM_KEYS and ACTOR_KEYS (float32 arrays)."""
-        self.w = {k: np.asarray(weights[k], f32) for k in RSSM_KEYS + ACTOR_KEYS}
+        self.w = {k: np.asarray(weights[k], f32) for k in RSSM_KEYS + ACTOR_KEYS + REWARD_KEYS if k in weights}
         assert self.w["obs1_w"].shape == (200 + 1080, 200) and self.w["h0_w"].shape == (230, 400)
         self.sample = bool(sample)
         self.rng = np.random.default_rng(seed)
@@ -53,6 +54,15 @@ class DreamerPolicy:
     @staticmethod
     def preprocess(scan_m):
         return (np.clip(np.asarray(scan_m, f32), 0.0, 15.0) / f32(15.0) - f32(0.5)).astype(f32)
+
+    def predicted_reward(self, state):
+        """The reference's reward head on the feature of `state` (models.py:301-318: two ELU layers of 400, mean of a unit
+        normal): what the world model, trained on the reference simulator's rewards, expects for the step that led here."""
+        w = self.w
+        h = np.concatenate([state["stoch"], state["deter"]], 1)
+        for i in range(2):
+            h = elu(h @ w[f"reward_h{i}_w"] + w[f"reward_h{i}_b"])
+        return (h @ w["reward_hout_w"] + w["reward_hout_b"])[:, 0].astype(f32)
 
     def _gru(self, x, h):
         w = self.w

@@ -7,7 +7,7 @@ checkpoints its ROS node deploys (ros_agent/models/dreamer/racing_dreamer.py:30-
 The pickles are read with an allow-list unpickler: nothing but NumPy array reconstruction may be named in them (they are
 `pickle.dump(tf.Module.variables as numpy)`, dreamer/tools.py:26-33).  Array order = `tf.Module.variables` order, identified
 by shape: GRU cell (kernel, recurrent kernel, bias [2, 600] = reset_after), Dense img1, img2, img3, obs1 (1 280 = deter 200 +
-the 1 080-beam scan: the deployed agent has no encoder, encoder.pkl is empty), obs2; actor h0..h3, hout.
+the 1 080-beam scan: the deployed agent has no encoder, encoder.pkl is empty), obs2; actor h0..h3, hout; reward head h0, h1, hout.
 """
 import hashlib
 import os
@@ -18,11 +18,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle.dreamer_policy_port import ACTOR_KEYS, RSSM_KEYS   # noqa: E402
+from oracle.dreamer_policy_port import ACTOR_KEYS, REWARD_KEYS, RSSM_KEYS   # noqa: E402
 
 CHECKPOINTS = "/root/reference/ros_agent/checkpoints"
 RSSM_SHAPES = [(200, 600), (200, 600), (2, 600), (32, 200), (200,), (200, 200), (200,), (200, 60), (60,), (1280, 200), (200,), (200, 60), (60,)]
 ACTOR_SHAPES = [(230, 400), (400,), (400, 400), (400,), (400, 400), (400,), (400, 400), (400,), (400, 4), (4,)]
+REWARD_SHAPES = [(230, 400), (400,), (400, 400), (400,), (400, 1), (1,)]        # the reward head (DenseDecoder, models.py:301-318)
 
 
 class ArraysOnly(pickle.Unpickler):
@@ -46,9 +47,11 @@ def main():
     for name, directory in (("austria", "austria_dreamer"), ("treitlstrasse", "treitlstrasse_dreamer")):
         rssm, h1 = read(os.path.join(CHECKPOINTS, directory, "rssm.pkl"), RSSM_SHAPES)
         actor, h2 = read(os.path.join(CHECKPOINTS, directory, "actor.pkl"), ACTOR_SHAPES)
+        reward, h3 = read(os.path.join(CHECKPOINTS, directory, "reward.pkl"), REWARD_SHAPES)
         out = dict(zip(RSSM_KEYS, rssm))
         out.update(zip(ACTOR_KEYS, actor))
-        out["source"] = np.array(f"ros_agent/checkpoints/{directory}/rssm.pkl sha256 {h1}; actor.pkl sha256 {h2}")
+        out.update(zip(REWARD_KEYS, reward))
+        out["source"] = np.array(f"ros_agent/checkpoints/{directory}/rssm.pkl sha256 {h1}; actor.pkl sha256 {h2}; reward.pkl sha256 {h3}")
         path = os.path.join(ROOT, "tests", "golden", f"dreamer_policy_{name}.npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path), "bytes")

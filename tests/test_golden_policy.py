@@ -103,3 +103,25 @@ def test_the_agent_refutes_other_steering_locks(wheel_max, monkeypatch):
     policy = DreamerPolicy(weights("austria"), sample=True, seed=0)
     crashes, _, laps = drive(env, policy, n, 330)
     assert crashes >= n, (wheel_max, crashes, laps)
+
+
+def test_reference_reward_model_follows_this_envs_reward():
+    """The reference's REWARD head (reward.pkl: trained on the reference simulator's rewards) evaluated on the agent's latent
+    state while it laps here: its prediction rises and falls with this env's progress reward (correlation > 0.7 over 7 000
+    agent steps).  Its scale does not match - 0.25 per agent step predicted where the env pays 0.15 at 3.5 m/s, a factor the
+    build cannot explain - so only the proportionality is asserted."""
+    n = 16
+    env = c_env("austria", n)
+    policy = DreamerPolicy(weights("austria"), sample=True, seed=0)
+    out = env.reset(mode=ro.RESET_GRID, seed=1)
+    state = policy.initial(n)
+    predicted, paid = [], []
+    for k in range(480):
+        action, state = policy.act(np.asarray(out["lidar"]).reshape(n, ro.N_BEAMS), state)
+        if k >= 40:
+            predicted.append(policy.predicted_reward(state))
+            paid.append(np.asarray(out["reward"]).reshape(n).copy())
+        out = env.step(action, repeat=4)
+    predicted, paid = np.concatenate(predicted), np.concatenate(paid)
+    corr = float(np.corrcoef(predicted, paid)[0, 1])
+    assert corr > 0.7 and predicted.mean() > 0.1 and paid.mean() > 0.1, (corr, predicted.mean(), paid.mean())
