@@ -26,6 +26,12 @@ RSSM_KEYS = ("gru_kernel", "gru_recurrent", "gru_bias", "img1_w", "img1_b", "img
              "obs1_w", "obs1_b", "obs2_w", "obs2_b")
 ACTOR_KEYS = ("h0_w", "h0_b", "h1_w", "h1_b", "h2_w", "h2_b", "h3_w", "h3_b", "hout_w", "hout_b")
 REWARD_KEYS = ("reward_h0_w", "reward_h0_b", "reward_h1_w", "reward_h1_b", "reward_hout_w", "reward_hout_b")
+# actor_version "normalized" (racing_dreamer.py:23-25; models.py:354-364): batch normalisation of the output layer, no mean scaling.
+# Order inside the checkpoint as identified by the moments of the layer's input on live states: moving mean, moving variance, gamma, beta.
+ACTOR_NORM_KEYS = ACTOR_KEYS[:8] + ("hnorm_mean", "hnorm_var", "hnorm_gamma", "hnorm_beta") + ACTOR_KEYS[8:]
+# LidarOccupancyDecoder (dreamer/models.py:444-465): Dense 230 -> 64, then four stride-2 'valid' Conv2DTranspose layers with ReLU
+# (1 -> 5 -> 13 -> 30 -> 64 pixels; kernels [kh, kw, out, in]); the output are the Bernoulli logits of the 64 x 64 lidar_occupancy image
+DECODER_KEYS = ("dec_h1_w", "dec_h1_b", "dec_h2_k", "dec_h2_b", "dec_h3_k", "dec_h3_b", "dec_h4_k", "dec_h4_b", "dec_h5_k", "dec_h5_b")
 
 
 def elu(x):
@@ -43,7 +49,8 @@ def sigmoid(x):
 class DreamerPolicy:
     def __init__(self, weights, sample=True, seed=0):
         """weights: mapping with RSSM_KEYS and ACTOR_KEYS (float32 arrays)."""
-        self.w = {k: np.asarray(weights[k], f32) for k in RSSM_KEYS + ACTOR_KEYS + REWARD_KEYS if k in weights}
+        self.w = {k: np.asarray(weights[k], f32) for k in RSSM_KEYS + ACTOR_NORM_KEYS + REWARD_KEYS + DECODER_KEYS if k in weights}
+        self.normalized = "hnorm_gamma" in self.w
         assert self.w["obs1_w"].shape == (200 + 1080, 200) and self.w["h0_w"].shape == (230, 400)
         self.sample = bool(sample)
         self.rng = np.random.default_rng(seed)
@@ -63,6 +70,20 @@ class DreamerPolicy:
         for i in range(2):
             h = elu(h @ w[f"reward_h{i}_w"] + w[f"reward_h{i}_b"])
         return (h @ w["reward_hout_w"] + w["reward_hout_b"])[:, 0].astype(f32)
+
+    def decoded_occupancy(self, state):
+        """Bernoulli logits [n, 64, 64] of the lidar_occupancy image the reference's decoder reconstructs from `state`."""
+        w = self.w
+        x = (np.concatenate([state["stoch"], state["deter"]], 1) @ w["dec_h1_w"] + w["dec_h1_b"]).reshape(-1, 1, 1, 64)
+        for name in ("dec_h2", "dec_h3", "dec_h4", "dec_h5"):
+            k, b = w[name + "_k"], w[name + "_b"]
+            n, hh, ww, _ = x.shape
+            out = np.zeros((n, (hh - 1) * 2 + k.shape[0], (ww - 1) * 2 + k.shape[1], k.shape[2]), f32)
+            for u in range(k.shape[0]):
+                for v in range(k.shape[1]):
+                    out[:, u:u + 2 * hh:2, v:v + 2 * ww:2, :] += np.einsum("bhwc,oc->bhwo", x, k[u, v])
+            x = np.maximum(out + b, 0.0)
+        return x[..., 0]
 
     def _gru(self, x, h):
         w = self.w
@@ -95,8 +116,12 @@ class DreamerPolicy:
         for i in range(4):
             h = elu(h @ w[f"h{i}_w"] + w[f"h{i}_b"])
         out = h @ w["hout_w"] + w["hout_b"]
-        mu = f32(5.0) * np.tanh(out[:, :2] / f32(5.0))
-        sd = softplus(out[:, 2:] + f32(RAW_INIT_STD)) + f32(1e-4)
+        if self.normalized:             # inference-mode batch normalisation (Keras epsilon 1e-3), linear mean
+            out = (out - w["hnorm_mean"]) / np.sqrt(w["hnorm_var"] + f32(1e-3)) * w["hnorm_gamma"] + w["hnorm_beta"]
+            mu, sd = out[:, :2], softplus(out[:, 2:]) + f32(1e-4)
+        else:
+            mu = f32(5.0) * np.tanh(out[:, :2] / f32(5.0))
+            sd = softplus(out[:, 2:] + f32(RAW_INIT_STD)) + f32(1e-4)
         if self.sample:
             u = mu[None] + sd[None] * self.rng.standard_normal((100, n, 2)).astype(f32)
             a = np.tanh(u)

@@ -18,12 +18,14 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle.dreamer_policy_port import ACTOR_KEYS, REWARD_KEYS, RSSM_KEYS   # noqa: E402
+from oracle.dreamer_policy_port import ACTOR_KEYS, ACTOR_NORM_KEYS, DECODER_KEYS, REWARD_KEYS, RSSM_KEYS   # noqa: E402
 
 CHECKPOINTS = "/root/reference/ros_agent/checkpoints"
 RSSM_SHAPES = [(200, 600), (200, 600), (2, 600), (32, 200), (200,), (200, 200), (200,), (200, 60), (60,), (1280, 200), (200,), (200, 60), (60,)]
 ACTOR_SHAPES = [(230, 400), (400,), (400, 400), (400,), (400, 400), (400,), (400, 400), (400,), (400, 4), (4,)]
 REWARD_SHAPES = [(230, 400), (400,), (400, 400), (400,), (400, 1), (1,)]        # the reward head (DenseDecoder, models.py:301-318)
+ACTOR_NORM_SHAPES = ACTOR_SHAPES[:8] + [(4,)] * 4 + ACTOR_SHAPES[8:]             # actor_version "normalized": + batch normalisation
+DECODER_SHAPES = [(230, 64), (64,), (5, 5, 32, 64), (32,), (5, 5, 16, 32), (16,), (6, 6, 8, 16), (8,), (6, 6, 1, 8), (1,)]
 
 
 class ArraysOnly(pickle.Unpickler):
@@ -57,5 +59,22 @@ def main():
         print(path, os.path.getsize(path), "bytes")
 
 
+def occupancy_agent():
+    """treitlstrasse_dreamer_20210224: the agent trained with the lidar_occupancy reconstruction (LidarOccupancyDecoder)."""
+    directory = "treitlstrasse_dreamer_20210224"
+    rssm, h1 = read(os.path.join(CHECKPOINTS, directory, "rssm.pkl"), RSSM_SHAPES)
+    actor, h2 = read(os.path.join(CHECKPOINTS, directory, "actor.pkl"), ACTOR_NORM_SHAPES)
+    decoder, h3 = read(os.path.join(CHECKPOINTS, directory, "decoder.pkl"), DECODER_SHAPES)
+    out = dict(zip(RSSM_KEYS, rssm))
+    out.update(zip(ACTOR_NORM_KEYS, actor))
+    out.update(zip(DECODER_KEYS, decoder))
+    assert (out["hnorm_var"] > 0).all()
+    out["source"] = np.array(f"ros_agent/checkpoints/{directory}/rssm.pkl sha256 {h1}; actor.pkl sha256 {h2}; decoder.pkl sha256 {h3}")
+    path = os.path.join(ROOT, "tests", "golden", "dreamer_policy_treitlstrasse_occupancy.npz")
+    np.savez_compressed(path, **out)
+    print(path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
     main()
+    occupancy_agent()

@@ -125,3 +125,43 @@ def test_reference_reward_model_follows_this_envs_reward():
     predicted, paid = np.concatenate(predicted), np.concatenate(paid)
     corr = float(np.corrcoef(predicted, paid)[0, 1])
     assert corr > 0.7 and predicted.mean() > 0.1 and paid.mean() > 0.1, (corr, predicted.mean(), paid.mean())
+
+
+def _image_correlation(a, b):
+    a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
+    a, b = a - a.mean(1, keepdims=True), b - b.mean(1, keepdims=True)
+    return (a * b).sum(1) / np.sqrt((a * a).sum(1) * (b * b).sum(1) + 1e-9)
+
+
+def test_reference_occupancy_decoder_reconstructs_this_envs_patches_the_right_way_round():
+    """G11.  treitlstrasse_dreamer_20210224 was trained to reconstruct the `lidar_occupancy` image from the latent state
+    (LidarOccupancyDecoder), i.e. on (scan -> image) pairs of the REFERENCE simulator.  Fed with this env's scans while its own
+    actor drives, what it reconstructs matches this env's render of the same pose as it stands - not mirrored, not rotated:
+    the render's registration to the scan (which side of the image the low beam indices are on) is the reference's."""
+    n = 16
+    t = load_track("treitlstrasse_v2")
+    cfg = ro.OracleConfig(num_envs=n, auto_reset=True, remap_actions=True, render_occupancy=True)
+    env = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=8)
+    policy = DreamerPolicy(weights("treitlstrasse_occupancy"), sample=False)
+    assert policy.normalized
+    out = env.reset(mode=ro.RESET_RANDOM, seed=1)
+    state = policy.initial(n)
+    scores = {k: [] for k in ("identity", "mirrored", "upside_down", "rotated")}
+    crashes = 0
+    for k in range(260):
+        action, state = policy.act(np.asarray(out["lidar"]).reshape(n, ro.N_BEAMS), state,
+                                   reset=(np.asarray(out["fresh"]).reshape(n) != 0) if k else None)
+        if k >= 20 and k % 4 == 0:
+            seen = policy.decoded_occupancy(state)
+            mine = np.asarray(out["lidar_occupancy"]).reshape(n, 64, 64).astype(np.float32)
+            scores["identity"].append(_image_correlation(seen, mine))
+            scores["mirrored"].append(_image_correlation(seen, mine[:, :, ::-1]))
+            scores["upside_down"].append(_image_correlation(seen, mine[:, ::-1, :]))
+            scores["rotated"].append(_image_correlation(seen, np.rot90(mine, 1, (1, 2))))
+        out = env.step(action, repeat=4)
+        crashes += int(np.count_nonzero(np.asarray(out["wall_collision"])))
+    s = {k: np.concatenate(v) for k, v in scores.items()}
+    assert crashes <= n, crashes                                       # (its own actor drives: 1 m/s, ~ 10 contacts in 4 160 agent steps from random poses)
+    assert s["identity"].mean() > 0.5 and s["identity"].mean() > s["mirrored"].mean() + 0.08, {k: v.mean() for k, v in s.items()}
+    assert (s["identity"] > s["mirrored"]).mean() > 0.7                # frame by frame
+    assert s["upside_down"].mean() < 0.4 and abs(s["rotated"].mean()) < 0.15
