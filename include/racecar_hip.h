@@ -170,7 +170,9 @@ int rc_reset(rc_env *env, const uint8_t *mask_or_null, int32_t mode, uint64_t se
 
 /* One agent step = up to `repeat` simulator sub-steps of dt = 0.01 s, then the observation.
  * `actions_dev` is device memory float32 [n, 2] = (motor, steering); NULL = use the buffer
- * behind RC_F_ACTION_IN (e.g. after rc_fill_random_actions). */
+ * behind RC_F_ACTION_IN (e.g. after rc_fill_random_actions).  motor >= 0 accelerates, < 0 brakes; a POSITIVE steering command
+ * turns RIGHT - towards higher beam indices (beam 0 is at +135 deg on the left) - and +-1 is a front-wheel angle of 0.19 rad:
+ * the convention under which the reference's own trained agents (ros_agent/checkpoints) drive (tests/test_golden_policy.py). */
 int rc_step(rc_env *env, const float *actions_dev, int32_t repeat);
 /* Same, actions in host memory (copied with the stream). */
 int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat);
@@ -189,9 +191,9 @@ int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step);
 int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat);
 
 /* Batched follow-the-gap agent on the device (the prefill / baseline agent of dreamer/dream.py:211-216, whose
- * host form is agents.gap_follower.GapFollower): from the current LiDAR scan of every car, clip to 3 m,
- * 5-beam smoothing over the forward 202.5 deg, safety bubble of +-60 beams around the closest return, steer to
- * the centre of the widest run of beams whose smoothed range exceeds 1 m.  Writes (motor, steering) into RC_F_ACTION_IN: steering in [-1, 1],
+ * host form is agents.gap_follower.GapFollower): from the current LiDAR scan of every car, clip to 6 m,
+ * 5-beam smoothing over the forward 202.5 deg, safety bubble of +-60 beams around the closest return, point the wheels at
+ * the centre of the widest run of beams whose smoothed range exceeds 2 m (full lock beyond 0.19 rad).  Writes (motor, steering) into RC_F_ACTION_IN: steering in [-1, 1],
  * motor = motor_corner if |steering| > 0.35 else motor_straight (values in the caller's action convention). */
 int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner);
 
@@ -200,7 +202,8 @@ int rc_follow_the_gap(rc_env *env, float motor_straight, float motor_corner);
  * by the vehicle's half-width, heading = mean angle of the beams at or above the 83.3rd percentile; :200-234: steering =
  * 1.4 heading - 0.1 d(heading)/dt clipped to +-24 deg, speed 6 m/s less up to 30 % with the steering angle, at most 4/5
  * of the free distance below 5 m, at least 1.5 m/s).  Writes (motor, steering) into RC_F_ACTION_IN - the node's speed over
- * the car's top speed, its steering angle over the car's steering limit, in the caller's action convention (the remap of
+ * the car's top speed, and the command that puts the front wheels at the node's steering angle (positive command = right; full
+ * lock beyond the car's 0.19 rad), in the caller's action convention (the remap of
  * rc_config is inverted when it is on).  dt = seconds per agent step (the derivative term; none on an episode's first
  * command).  detail_dev: optional device float32 [n, 4] = heading [rad], free distance [m], steering angle [rad], speed
  * [m/s].  The generic bubble / widest-gap agent above stays available as rc_follow_the_gap. */
