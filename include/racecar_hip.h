@@ -302,6 +302,18 @@ size_t rc_gather_rows_bytes(rc_env *env, uint32_t field_mask, int32_t n_rows);
 int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const int32_t *slot_idx_dev, const int32_t *car_idx_dev,
                    int32_t n_rows, uint32_t field_mask, void *out_dev, size_t out_bytes);
 
+/* Window starts for that gather, drawn on the device (the reference draws a random index into an episode file and takes
+ * `length` steps from there: dreamer/tools.py:250-262).  The ring holds `count` consecutive records (`oldest` = slot of the
+ * oldest, capacity slots in all); n_windows windows of `length` records of one car each, (first record, car) uniform -
+ * Philox4x32-10 keyed by `seed`, counter (window, try, draw) - among the windows that stay inside one episode: no fresh record
+ * strictly inside, a fresh last record only if it is the terminal transition (done).  Device int32 outputs: slot_idx /
+ * slot_obs_idx / car_idx [n_windows * length] = the rows for rc_gather_rows (slot_obs_idx: a terminal row reads the slot before
+ * it - for the observation fields), meta [n_windows * 4] = (ring age of the first record, car, terminal, starts an episode);
+ * *failed_dev is incremented for every window that found no such start in max_tries draws.  Queued on the handle's stream. */
+int rc_sample_windows(rc_env *env, const void *ring_base, size_t slot_bytes, int32_t capacity, int32_t oldest, int32_t count,
+                      int32_t length, int32_t n_windows, uint64_t seed, uint32_t draw, int32_t max_tries, int32_t *slot_idx_dev,
+                      int32_t *slot_obs_idx_dev, int32_t *car_idx_dev, int32_t *meta_dev, uint32_t *failed_dev);
+
 int rc_sync(rc_env *env);
 void *rc_stream(rc_env *env);      /* the hipStream_t the handle launches on */
 

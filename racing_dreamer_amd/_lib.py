@@ -72,6 +72,8 @@ SYMBOLS = {
     "rc_trajectory_slab": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_size_t)]),
     "rc_gather_rows_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_int32]),
     "rc_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t]),
+    "rc_sample_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                    C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rc_sync": (C.c_int, [C.c_void_p]),
     "rc_stream": (C.c_void_p, [C.c_void_p]),
     "rc_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),

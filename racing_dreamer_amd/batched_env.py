@@ -484,6 +484,23 @@ class BatchedRaceEnv:
             off = (off + per * rows + 63) // 64 * 64
         return res
 
+    def sample_windows(self, ring: torch.Tensor, slot_bytes: int, capacity: int, oldest: int, count: int, length: int,
+                       n_windows: int, seed: int, draw: int, max_tries: int = 16) -> Dict[str, torch.Tensor]:
+        """`rc_sample_windows`: window starts of a replay sampler drawn on the device - no host round trip.  Returns int32
+        device tensors `slots`, `slots_obs`, `cars` [n_windows * length] (rows for `gather_rows`), `meta` [n_windows, 4] =
+        (t0, car, terminal, first) and `failed` [1] (windows that found no episode-internal start in `max_tries` draws)."""
+        i32 = dict(dtype=torch.int32, device=self.device)
+        out = dict(slots=torch.empty(n_windows * length, **i32), slots_obs=torch.empty(n_windows * length, **i32),
+                   cars=torch.empty(n_windows * length, **i32), meta=torch.empty((n_windows, 4), **i32),
+                   failed=torch.zeros(1, dtype=torch.int32, device=self.device))
+        self._enter()
+        L.check(self._lib.rc_sample_windows(self._h, ring.data_ptr(), int(slot_bytes), int(capacity), int(oldest), int(count),
+                                            int(length), int(n_windows), C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(draw) & 0xffffffff),
+                                            int(max_tries), out["slots"].data_ptr(), out["slots_obs"].data_ptr(),
+                                            out["cars"].data_ptr(), out["meta"].data_ptr(), out["failed"].data_ptr()))
+        self._exit()
+        return out
+
     def host_snapshot(self) -> Dict[str, np.ndarray]:
         """Every output field on the host from ONE device-to-host copy of the arena (for small batches, e.g. the
         single-env shim): dict of NumPy views [num_envs, cars_per_env, ...] into one host buffer."""

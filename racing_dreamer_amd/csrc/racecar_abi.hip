@@ -1073,6 +1073,27 @@ int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const 
     return RC_OK;
 }
 
+int rc_sample_windows(rc_env *env, const void *ring_base, size_t slot_bytes, int32_t capacity, int32_t oldest, int32_t count,
+                      int32_t length, int32_t n_windows, uint64_t seed, uint32_t draw, int32_t max_tries, int32_t *slot_idx_dev,
+                      int32_t *slot_obs_idx_dev, int32_t *car_idx_dev, int32_t *meta_dev, uint32_t *failed_dev) {
+    if (!env || !ring_base || !slot_idx_dev || !slot_obs_idx_dev || !car_idx_dev || !meta_dev || !failed_dev) return fail(RC_ERR_INVALID, "NULL argument");
+    if (slot_bytes < env->layout.total) return fail(RC_ERR_INVALID, "slot_bytes %zu is smaller than an arena (%zu)", slot_bytes, env->layout.total);
+    if (env->shared_arena) return fail(RC_ERR_INVALID, "rc_sample_windows works on whole arenas, not on a slice handle");
+    if (capacity < 1 || oldest < 0 || oldest >= capacity || count < 1 || count > capacity) return fail(RC_ERR_INVALID, "ring of %d slots, oldest %d, %d filled", capacity, oldest, count);
+    if (length < 1 || length > count) return fail(RC_ERR_INVALID, "a window of %d records does not fit the %d records of the ring", length, count);
+    if (n_windows < 1 || max_tries < 1) return fail(RC_ERR_INVALID, "n_windows and max_tries must be >= 1");
+    RcSampleWindows a{};
+    a.ring = (const unsigned char *)ring_base; a.slot_bytes = slot_bytes;
+    a.fresh_off = env->layout.offset[RC_F_FRESH]; a.done_off = env->layout.offset[RC_F_DONE];
+    a.capacity = capacity; a.oldest = oldest; a.n_start = count - length + 1; a.length = length; a.n_windows = n_windows;
+    a.n_cars = env->n_cars; a.max_tries = max_tries;
+    a.seed_lo = (uint32_t)seed; a.seed_hi = (uint32_t)(seed >> 32); a.draw = draw;
+    a.slot_idx = slot_idx_dev; a.slot_obs_idx = slot_obs_idx_dev; a.car_idx = car_idx_dev; a.meta = meta_dev; a.failed = failed_dev;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(rck_sample_windows(a, env->stream));
+    return RC_OK;
+}
+
 int rc_sync(rc_env *env) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     HIP_TRY(hipSetDevice(env->cfg.device));

@@ -102,6 +102,15 @@ struct RcLaunchInfo {            // per-handle launch geometry decided at rc_loa
 };
 
 #define RC_GATHER_MAX_FIELDS 24
+struct RcSampleWindows {
+    const unsigned char *ring;
+    size_t slot_bytes, fresh_off, done_off;
+    int32_t capacity, oldest, n_start, length, n_windows, n_cars, max_tries;
+    uint32_t seed_lo, seed_hi, draw;
+    int32_t *slot_idx, *slot_obs_idx, *car_idx, *meta;
+    uint32_t *failed;
+};
+hipError_t rck_sample_windows(const RcSampleWindows &a, hipStream_t s);
 hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *slot_idx, const int32_t *car_idx, int n_rows,
                            const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s);
 #define RC_P2P_MAX_RANKS 64

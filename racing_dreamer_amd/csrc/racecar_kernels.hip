@@ -2450,6 +2450,52 @@ hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *s
     return hipGetLastError();
 }
 
+// ---- window starts of a replay sampler (rc_sample_windows): one wave per window.  Draw (first record, car) - Philox keyed by
+// the caller's seed, counter (window, try, draw) - until the `length` records of that car from ring age t0 on stay inside one
+// episode: no fresh record strictly inside, a fresh LAST record only if it is the episode's terminal one (done, written by
+// auto-reset).  Lanes test the records of the window side by side.  Then the window's rows for rc_gather_rows.
+__global__ __launch_bounds__(256) void rc_sample_windows_kernel(RcSampleWindows a) {
+    const int win = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (win >= a.n_windows) return;
+    const int lane = threadIdx.x & 63;
+    int t0 = 0, car = 0;
+    bool ok = false;
+    for (int attempt = 0; attempt < a.max_tries && !ok; ++attempt) {
+        const rcd::u32x4 r = rcd::philox4x32((uint32_t)win, (uint32_t)attempt, a.draw, 0x57494e44u, a.seed_lo, a.seed_hi);
+        t0 = (int)(r.x % (uint32_t)a.n_start);
+        car = (int)(r.y % (uint32_t)a.n_cars);
+        bool bad = false;
+        for (int j = lane; j < a.length; j += 64) {
+            if (j == 0) continue;
+            const size_t slot = (size_t)((a.oldest + t0 + j) % a.capacity) * a.slot_bytes;
+            const bool fresh = a.ring[slot + a.fresh_off + car] != 0;
+            bad |= fresh && (j < a.length - 1 || a.ring[slot + a.done_off + car] == 0);
+        }
+        ok = __builtin_amdgcn_ballot_w64(bad) == 0ull;
+    }
+    if (!ok && lane == 0) atomicAdd(a.failed, 1u);
+    const size_t last = (size_t)((a.oldest + t0 + a.length - 1) % a.capacity) * a.slot_bytes;
+    const bool terminal = a.length > 1 && a.ring[last + a.fresh_off + car] != 0 && a.ring[last + a.done_off + car] != 0;
+    for (int j = lane; j < a.length; j += 64) {
+        const int slot = (a.oldest + t0 + j) % a.capacity;
+        const size_t o = (size_t)win * a.length + j;
+        a.slot_idx[o] = slot;
+        // a terminal row takes its OBSERVATION from the record before it: the new episode's observation is not this episode's
+        a.slot_obs_idx[o] = (terminal && j == a.length - 1) ? (a.oldest + t0 + j - 1) % a.capacity : slot;
+        a.car_idx[o] = car;
+    }
+    if (lane == 0) {
+        const size_t first = (size_t)((a.oldest + t0) % a.capacity) * a.slot_bytes;
+        a.meta[4 * win] = t0; a.meta[4 * win + 1] = car; a.meta[4 * win + 2] = terminal ? 1 : 0;
+        a.meta[4 * win + 3] = a.ring[first + a.fresh_off + car] != 0 ? 1 : 0;          // the window starts an episode
+    }
+}
+
+hipError_t rck_sample_windows(const RcSampleWindows &a, hipStream_t s) {
+    hipLaunchKernelGGL(rc_sample_windows_kernel, dim3((unsigned)((a.n_windows + 3) / 4)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ---- flags of the peer-copy all-gather (rc_gather_trajectory_p2p): sequence numbers in uncached device memory that a
 // PEER's kernel writes (over xGMI) and the owner's kernel polls.  Both kernels are one wave; the poll is bounded (wall
 // clock) and reports a time-out instead of hanging the queue.

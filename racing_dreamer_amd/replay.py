@@ -103,18 +103,54 @@ class TrajectoryRing:
         """Number of distinct start times of a `length`-step window inside the filled part of the ring."""
         return max(self.count - length + 1, 0)
 
+    def _sample_native(self, batch, length, names, seed, reset_rows, max_tries, check):
+        """The whole draw on the device: `rc_sample_windows` (a wave per window: draw, test the episode boundary, emit the
+        rows) and two `rc_gather_rows` launches; no host round trip unless `check`."""
+        env = self.env
+        oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
+        self._draws = getattr(self, "_draws", 0) + 1
+        w = env.sample_windows(self.buffer, self.slot_bytes, self.capacity, oldest, self.count, length, batch, seed, self._draws, max_tries)
+        if check and int(w["failed"].item()):
+            raise RuntimeError(f"could not find {batch} windows of {length} records without an episode boundary")
+        obs_names = [n for n in names if n in OBSERVATION_FIELDS]
+        rest = [n for n in names if n not in OBSERVATION_FIELDS]
+        rows = {}
+        if obs_names:
+            rows.update(env.gather_rows(self.buffer, self.slot_bytes, w["slots_obs"], w["cars"], obs_names))
+        if rest:
+            rows.update(env.gather_rows(self.buffer, self.slot_bytes, w["slots"], w["cars"], rest))
+        out = {n: v.view(batch, length, *v.shape[1:]) for n, v in rows.items()}
+        meta = w["meta"]
+        if reset_rows:                      # the reference's reset row (wrappers.py:221-226), without a mask-indexed write
+            first = meta[:, 3] != 0
+            for name, value in (("action", 0.0), ("reward", 0.0), ("discount", 1.0), ("time", 0.0), ("progress_total", -1.0)):
+                if name in out:
+                    head = out[name][:, 0]
+                    out[name][:, 0] = torch.where(first.view(-1, *([1] * (head.dim() - 1))), torch.full_like(head, value), head)
+        car = meta[:, 1].long()
+        out["env"], out["car"] = car // env.cars_per_env, car % env.cars_per_env
+        out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+        return out
+
     def sample(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
                generator: Optional[torch.Generator] = None, reset_rows: bool = True,
-               max_tries: int = 16) -> Dict[str, torch.Tensor]:
+               max_tries: int = 16, native: Optional[bool] = None, check: bool = True) -> Dict[str, torch.Tensor]:
         """`batch` windows of `length` consecutive records of one car each, uniformly over (time, env, car) among
         the windows that stay inside one episode: no fresh record strictly inside, and a fresh LAST record only if it
         is the terminal transition of the window's episode (done = 1, written by auto-reset).  Returns field ->
         [batch, length, ...] (copies, on the ring's device) plus `env`, `car`, `t0` (ring age of the first record,
-        0 = oldest) and `terminal` (bool [batch]: the last row is such a terminal transition)."""
+        0 = oldest) and `terminal` (bool [batch]: the last row is such a terminal transition).  On a device ring the draw
+        itself runs on the device (`native`, default there; `check=False` also drops the one host read of the failure count);
+        `native=False` is the tensor-indexing form with torch's generator."""
         nstart = self.window_starts(length)
         if nstart <= 0:
             raise ValueError(f"ring holds {self.count} records, a window needs {length}")
         names = [f for f in (fields or DEFAULT_SAMPLE_FIELDS) if f in self.fields]
+        if native is None:
+            native = hasattr(self.env, "sample_windows") and self.buffer.is_cuda
+        if native:                          # (the draw comes from Philox on the device, keyed by the generator's seed and a counter)
+            seed = generator.initial_seed() if generator is not None else 0x5eed
+            return self._sample_native(batch, length, names, seed, reset_rows, max_tries, check)
         dev = self.buffer.device
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
         ar = torch.arange(length, device=dev)

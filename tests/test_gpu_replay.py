@@ -170,14 +170,71 @@ def test_native_window_gather_equals_tensor_indexing():
     # through the sampler: identical to the indexing form of the same draw
     g1, g2 = torch.Generator(device="cuda").manual_seed(9), torch.Generator(device="cuda").manual_seed(9)
     fields = ("lidar", "lidar_occupancy", "action", "reward", "discount", "time", "speed", "done", "fresh")
-    a = ring.sample(768, 3, fields=fields, generator=g1)
+    a = ring.sample(768, 3, fields=fields, generator=g1, native=False)
     native = env.gather_rows
     try:
         del BatchedRaceEnv.gather_rows                  # the indexing path of the same sampler
-        b = ring.sample(768, 3, fields=fields, generator=g2)
+        b = ring.sample(768, 3, fields=fields, generator=g2, native=False)
     finally:
         BatchedRaceEnv.gather_rows = native.__func__
     assert set(a) == set(b) and bool(a["terminal"].any())
     for n in a:
         assert torch.equal(a[n], b[n]), n
+    env.close()
+
+
+def test_windows_drawn_on_the_device_are_the_rows_they_say_and_uniform():
+    """rc_sample_windows (the draw, the episode-boundary test and the row list in one launch) through TrajectoryRing.sample:
+    every window is what plain indexing of the ring gives at its (t0, env, car) - terminal rows with the previous record's
+    observation, reset rows at episode starts -, no window crosses an episode boundary, both draws of one seed differ, and the
+    starts are spread evenly over ring age and cars."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.replay import OBSERVATION_FIELDS, TrajectoryRing
+    from oracle import racecar_oracle as ro
+    env = BatchedRaceEnv("columbia", 128, 2, obs_type="lidar_occupancy", auto_reset=True, action_repeat=4)
+    ring = TrajectoryRing(env, capacity=16)
+    ring.reset(mode="random_ball", seed=1)
+    for k in range(40):                                     # more records than slots: the ring has wrapped
+        act = ro.random_actions(7, k, 256)
+        act[:, 0] = 1.0
+        ring.step(torch.from_numpy(act).cuda().view(128, 2, 2))
+    g = torch.Generator(device="cuda").manual_seed(11)
+    fields = ("lidar", "lidar_occupancy", "action", "reward", "discount", "time", "done", "fresh", "progress_total")
+    length, batch = 5, 4096
+    a = ring.sample(batch, length, fields=fields, generator=g)
+    b = ring.sample(batch, length, fields=fields, generator=g)
+    torch.cuda.synchronize()
+    assert not torch.equal(a["t0"], b["t0"]) and a["lidar"].shape == (batch, length, 1080)
+    oldest = (ring.head + 1) % 16
+    slots = (oldest + a["t0"][:, None] + torch.arange(length, device="cuda")[None, :]) % 16
+    e, c = a["env"][:, None], a["car"][:, None]
+    fresh, done = ring.fields["fresh"][slots, e, c], ring.fields["done"][slots, e, c]
+    assert not (fresh[:, 1:-1] != 0).any() and bool((((fresh[:, -1] == 0) | (done[:, -1] != 0))).all())
+    term = (fresh[:, -1] != 0) & (done[:, -1] != 0)
+    assert torch.equal(a["terminal"], term) and int(term.sum()) > 20
+    first = fresh[:, 0] != 0
+    assert int(first.sum()) > 20
+    for name in fields:
+        want = ring.fields[name][slots, e, c].clone()
+        if name in OBSERVATION_FIELDS:
+            want[term, -1] = want[term, -2]
+        if name in ("action", "reward", "time"):
+            want[first, 0] = 0.0
+        if name == "discount":
+            want[first, 0] = 1.0
+        if name == "progress_total":
+            want[first, 0] = -1.0
+        assert torch.equal(a[name], want), name
+    # uniform over (start, car) among the admissible windows: compare the start histogram with the admissible counts
+    n_start = 16 - length + 1
+    idx = (oldest + torch.arange(n_start, device="cuda")[:, None] + torch.arange(length, device="cuda")[None, :]) % 16   # [start, j]
+    fr, dn = ring.fields["fresh"][idx], ring.fields["done"][idx]                  # [start, j, env, car]
+    ok = ~(fr[:, 1:-1] != 0).any(1) & ((fr[:, -1] == 0) | (dn[:, -1] != 0))      # [start, env, car]
+    share = ok.flatten(1).sum(1).float() / ok.sum()
+    got = torch.bincount(a["t0"], minlength=n_start).float() / batch
+    assert float((got - share).abs().max()) < 0.03, (got, share)
+    assert bool(ok[a["t0"], a["env"], a["car"]].all())
+    with pytest.raises(Exception, match="does not fit"):
+        env.sample_windows(ring.buffer, ring.slot_bytes, 16, oldest, 16, 17, 4, 1, 1)
     env.close()
