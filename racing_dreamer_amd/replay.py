@@ -239,6 +239,9 @@ class ShardedReplay:
         local = self.ring.sample(batch // self.world, length, fields=fields, generator=generator)
         out = {}
         host_bounce = self._dist.get_backend(self.group) == "gloo"
+        # the four per-window integers travel as one [windows, 4] tensor: one collective instead of four
+        meta_names = ("env", "car", "t0", "terminal")
+        local["_meta"] = torch.stack([local.pop(n).to(torch.int64) for n in meta_names], 1)
         for name, t in local.items():
             src = t.contiguous()
             if host_bounce and src.is_cuda:                  # gloo has no device collectives (functional tests only)
@@ -249,5 +252,8 @@ class ShardedReplay:
             self._dist.all_gather_into_tensor(dst, wide, group=self.group)          # rank r's rows at r * batch / world
             dst = dst.view(torch.uint16) if src.dtype == torch.uint16 else (dst.to(torch.bool) if src.dtype == torch.bool else dst)
             out[name] = dst.to(t.device)
+        meta = out.pop("_meta")
+        for i, n in enumerate(meta_names):
+            out[n] = meta[:, i] != 0 if n == "terminal" else meta[:, i]
         out["rank"] = torch.arange(self.world, device=out["env"].device).repeat_interleave(batch // self.world)
         return out
