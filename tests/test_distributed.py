@@ -224,4 +224,5 @@ def test_bench_starts_its_own_ranks_and_reports_their_failure():
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
                         "--envs", "64", "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode not in (0, 2), r.stderr[-1500:]          # (2 was round 2's "needs torch.distributed.run")
-    assert r.stderr.count("No HIP GPUs are available") >= 2 and "{" not in r.stdout
+    # (the launcher ends the second rank as soon as the first has failed: its own message may or may not have been printed)
+    assert r.stderr.count("No HIP GPUs are available") >= 1 and "{" not in r.stdout
