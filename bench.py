@@ -698,8 +698,8 @@ def main():
                 e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n,
                          includes=f"records kept in a {64}-slot device ring per rank (rc_set_arena, no copy); every step "
                                   f"ShardedReplay.sample({batch} windows x {length} steps: lidar, action, reward, discount) "
-                                  f"all-gathered over torch.distributed - {nbytes} B per rank per sample; the sampler's "
-                                  f"rejection loop synchronises the host once per sample")
+                                  f"all-gathered over torch.distributed - {nbytes} B per rank per sample; windows drawn "
+                                  f"and gathered on the device (rc_sample_windows, rc_gather_rows), one host read of the failure count per sample")
                 table["batch"] = e
             out["gather_modes"] = table
         if gather_checks:
