@@ -190,6 +190,15 @@ int rc_fill_random_actions(rc_env *env, uint64_t seed, uint32_t step);
  * launch of its own for the action generator.  Results are identical to the two-call form. */
 int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat);
 
+/* rc_step / rc_step_random of SEVERAL handles as one launch per kernel - the handles of a batch that mixes tracks (one handle
+ * per track, each filling its block of cars of ONE arena: rc_config.arena_total_cars / arena_first_car; SURVEY.md 8e "per-env
+ * track_id selecting a device-resident grid", BASELINE configs[4]'s track mix).  Every wave of the launch works from the
+ * parameters of the block it lies in, so the chip sees one dynamics and one scan kernel over all cars instead of one small pair
+ * per track.  The handles share a device, a stream and cars_per_env (at most 8 of them); `actions_dev` is float32 [total cars, 2]
+ * in arena order, NULL = every handle's RC_F_ACTION_IN.  Results are those of stepping the handles one by one. */
+int rc_step_group(rc_env **envs, int32_t n, const float *actions_dev, int32_t repeat);
+int rc_step_random_group(rc_env **envs, int32_t n, uint64_t seed, uint32_t step, int32_t repeat);
+
 /* Batched follow-the-gap agent on the device (the prefill / baseline agent of dreamer/dream.py:211-216, whose
  * host form is agents.gap_follower.GapFollower): from the current LiDAR scan of every car, clip to 6 m,
  * 5-beam smoothing over the forward 202.5 deg, safety bubble of +-60 beams around the closest return, point the wheels at

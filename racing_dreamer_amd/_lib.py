@@ -67,6 +67,8 @@ SYMBOLS = {
     "rc_follow_the_gap_reference": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p]),
     "rc_fill_random_actions": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32]),
     "rc_step_random": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32]),
+    "rc_step_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]),
+    "rc_step_random_group": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64, C.c_uint32, C.c_int32]),
     "rc_get": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
     "rc_copy_out": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_size_t]),
     "rc_trajectory_slab": (C.c_int, [C.c_void_p, _P(C.c_void_p), _P(C.c_size_t)]),

@@ -553,7 +553,7 @@ class MixedTrackEnv:
         for track, n in zip(tracks, envs_per_track):
             self.parts.append(BatchedRaceEnv(track, int(n), cars_per_env, obs_type=obs_type, device=device, first_env=first_env + e0,
                                              shared_arena=self.arena, arena_total_cars=self.n_cars,
-                                             arena_first_car=e0 * self.cars_per_env, **kw))
+                                             arena_first_car=e0 * self.cars_per_env, stream=self.stream, **kw))
             self.blocks.append((e0, e0 + int(n)))
             e0 += int(n)
         self.track_id = torch.cat([torch.full((b - a,), i, dtype=torch.int32) for i, (a, b) in enumerate(self.blocks)]).to(self.device)
@@ -592,18 +592,34 @@ class MixedTrackEnv:
         """Arena order -> caller order (e.g. `to_envs(out["lidar"])`)."""
         return x[self.row_of_env]
 
-    # Every block runs on a stream of its own, forked from and joined to the caller's current stream around each call: the
-    # blocks' kernels overlap (a block of a third of the batch leaves the tail of its scan half empty; the next block's
-    # waves fill it), and the caller sees one stream-ordered operation.
-    def _fork_join(self, call):
+    # All blocks work on ONE stream (`self.stream`), ordered behind and before the caller's current stream around each call.  A
+    # step is ONE dynamics and ONE scan launch over all blocks (`rc_step_group`: every wave works from the parameters of the
+    # block it lies in): with a launch pair per block on streams of their own, each block's small dynamics kernel waited behind
+    # the previous block's scan, the three scans shared the chip and 33 us passed between the join of one step and the first
+    # kernel of the next (0.258 -> 0.230 ms per step of three blocks of 21 845 envs; the three tracks alone average 0.20;
+    # EXPERIMENTS I.10).
+    def _ordered(self, call):
         cur = torch.cuda.current_stream(self.device)
-        for p in self.parts:
-            p.stream.wait_stream(cur)
-        for p, blk in zip(self.parts, self.blocks):
-            L.check(call(p, blk))
-        for p in self.parts:
-            cur.wait_stream(p.stream)
+        if cur.cuda_stream != self.stream.cuda_stream:
+            self.stream.wait_stream(cur)
+        L.check(call())
+        if cur.cuda_stream != self.stream.cuda_stream:
+            cur.wait_stream(self.stream)
         return self.views
+
+    def _fork_join(self, call):
+        def every_block():
+            for p, blk in zip(self.parts, self.blocks):
+                rc = call(p, blk)
+                if rc:
+                    return rc
+            return 0
+        return self._ordered(every_block)
+
+    def _handles(self):
+        if getattr(self, "_handle_array", None) is None:
+            self._handle_array = (C.c_void_p * len(self.parts))(*[p._h for p in self.parts])
+        return self._handle_array
 
     def reset(self, mode: str = "grid", seed: Optional[int] = None):
         if mode not in spec.RESET_MODES:
@@ -617,12 +633,17 @@ class MixedTrackEnv:
         """actions: float32 [total_envs, cars_per_env, 2] on the device (None: each block's `action_in`)."""
         if actions is not None:
             actions = actions.to(self.device, torch.float32).reshape(self.num_envs, self.cars_per_env, 2).contiguous()
-        return self._fork_join(lambda p, blk: p._lib.rc_step(
-            p._h, None if actions is None else actions[blk[0]:blk[1]].data_ptr(), p.action_repeat if repeat is None else int(repeat)))
+        rep = self.parts[0].action_repeat if repeat is None else int(repeat)
+        if len(self.parts) > 8:             # (more blocks than a group launch carries: one launch pair per block)
+            return self._fork_join(lambda p, blk: p._lib.rc_step(p._h, None if actions is None else actions[blk[0]:blk[1]].data_ptr(), rep))
+        return self._ordered(lambda: self._lib.rc_step_group(self._handles(), len(self.parts),
+                                                             None if actions is None else actions.data_ptr(), rep))
 
     def step_random(self, seed: int, step: int, repeat: Optional[int] = None):
-        return self._fork_join(lambda p, blk: p._lib.rc_step_random(p._h, C.c_uint64(seed), C.c_uint32(step),
-                                                                    p.action_repeat if repeat is None else int(repeat)))
+        rep = self.parts[0].action_repeat if repeat is None else int(repeat)
+        if len(self.parts) > 8:
+            return self._fork_join(lambda p, blk: p._lib.rc_step_random(p._h, C.c_uint64(seed), C.c_uint32(step), rep))
+        return self._ordered(lambda: self._lib.rc_step_random_group(self._handles(), len(self.parts), C.c_uint64(seed), C.c_uint32(step), rep))
 
     def follow_the_gap_reference(self, dt: Optional[float] = None):
         self._fork_join(lambda p, blk: p._lib.rc_follow_the_gap_reference(p._h, 0.01 * p.action_repeat if dt is None else float(dt), None))

@@ -220,6 +220,14 @@ struct rc_env {
     bool gather_pending = false;
     P2p *p2p = nullptr;                // peer-copy all-gather (rc_p2p_setup), else null
     float *ftg_prev = nullptr;         // rc_follow_the_gap_reference: previous heading per car (NaN = none), allocated on first use
+    // rc_step_group (this handle as the first of a group): the blocks' RcParams as the last launch saw them, on the device
+    // and on the host (pinned staging slots taken in turn, each with the event of its copy)
+    RcParams *group_dev = nullptr;
+    RcParams *group_host = nullptr;    // [kGroupSlots][RC_GROUP_MAX], pinned
+    hipEvent_t group_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t group_slot = 0;
+    int group_n = 0;
+    RcParams group_last[RC_GROUP_MAX];
 };
 
 namespace {
@@ -677,6 +685,9 @@ void rc_destroy(rc_env *env) {
     if (env->own_arena && env->arena) (void)hipFree(env->arena);
     if (env->state_mem) (void)hipFree(env->state_mem);
     if (env->ftg_prev) (void)hipFree(env->ftg_prev);
+    if (env->group_dev) (void)hipFree(env->group_dev);
+    if (env->group_host) (void)hipHostFree(env->group_host);
+    for (hipEvent_t e : env->group_ev) if (e) (void)hipEventDestroy(e);
     env->track.reset();
     if (env->mask_dev) (void)hipFree(env->mask_dev);
     if (env->own_stream && env->stream) (void)hipStreamDestroy(env->stream);
@@ -955,6 +966,87 @@ int rc_step_random(rc_env *env, uint64_t seed, uint32_t step, int32_t repeat) {
     const RcRandomActions ra{1, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step};
     TIMED(env, RC_K_DYNAMICS, rck_launch_dynamics(env->params, env->actions_in, repeat, ra, env->stream));
     return observe(env);
+}
+
+// ---- several handles, one launch per kernel --------------------------------------------------------------------------
+static int group_step(rc_env **envs, int32_t n, const float *actions_dev, int32_t repeat, const RcRandomActions &ra, const char *who) {
+    if (!envs || n < 1) return fail(RC_ERR_INVALID, "%s: no handles", who);
+    if (n > RC_GROUP_MAX) return fail(RC_ERR_INVALID, "%s: at most %d handles in a group (got %d)", who, RC_GROUP_MAX, n);
+    if (repeat < 1) return fail(RC_ERR_INVALID, "repeat must be >= 1 (got %d)", repeat);
+    rc_env *lead = envs[0];
+    for (int b = 0; b < n; ++b) {
+        rc_env *e = envs[b];
+        if (!e) return fail(RC_ERR_INVALID, "%s: handle %d is NULL", who, b);
+        if (!e->has_track) return fail(RC_ERR_NO_TRACK, "rc_load_track must be called before %s (handle %d)", who, b);
+        if (!e->was_reset) return fail(RC_ERR_NEEDS_RESET, "Must reset environment.");
+        if (e->cfg.device != lead->cfg.device || e->stream != lead->stream)
+            return fail(RC_ERR_INVALID, "%s: the handles of a group share one device and one stream (handle %d does not)", who, b);
+        if (e->cfg.cars_per_env != lead->cfg.cars_per_env)
+            return fail(RC_ERR_INVALID, "%s: the handles of a group have the same cars_per_env", who);
+        if (e->launch.raycast_variant != 7 || e->launch.scan_guarded || e->launch.scan_stamps || e->compact_slab)
+            return fail(RC_ERR_INVALID, "%s: handle %d runs a scan variant / validation build / uint16 copy that a group launch does not carry", who, b);
+        for (int c = 0; c < b; ++c)
+            if (envs[c] == e) return fail(RC_ERR_INVALID, "%s: handle %d appears twice", who, b);
+    }
+    HIP_TRY(hipSetDevice(lead->cfg.device));
+    if (!lead->group_dev) {
+        HIP_TRY(hipMalloc((void **)&lead->group_dev, sizeof(RcParams) * RC_GROUP_MAX));
+        HIP_TRY(hipHostMalloc((void **)&lead->group_host, sizeof(RcParams) * RC_GROUP_MAX * 4, hipHostMallocDefault));
+        for (hipEvent_t &ev : lead->group_ev) HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        lead->group_n = 0;
+    }
+    // the device table follows the handles' parameters in stream order: a copy is queued only when something changed (an arena
+    // re-pointed by rc_set_arena, a knob), from a pinned slot that is not rewritten before its copy has run
+    bool changed = lead->group_n != n;
+    for (int b = 0; b < n && !changed; ++b) changed = std::memcmp(&lead->group_last[b], &envs[b]->params, sizeof(RcParams)) != 0;
+    if (changed) {
+        const uint32_t slot = lead->group_slot++ & 3u;
+        HIP_TRY(hipEventSynchronize(lead->group_ev[slot]));
+        RcParams *host = lead->group_host + (size_t)slot * RC_GROUP_MAX;
+        for (int b = 0; b < n; ++b) { host[b] = envs[b]->params; lead->group_last[b] = envs[b]->params; }
+        HIP_TRY(hipMemcpyAsync(lead->group_dev, host, sizeof(RcParams) * n, hipMemcpyHostToDevice, lead->stream));
+        HIP_TRY(hipEventRecord(lead->group_ev[slot], lead->stream));
+        lead->group_n = n;
+    }
+    RcGroup g{};
+    g.params = lead->group_dev;
+    g.n = n;
+    // dynamics: a wave = 64 envs of one block
+    int waves = 0, cars = 0;
+    for (int b = 0; b < n; ++b) {
+        g.wave_start[b] = waves;
+        waves += (envs[b]->cfg.num_envs + 63) / 64;
+        // (the caller's actions are in arena order: block b's start where its cars start)
+        g.actions[b] = (actions_dev && !ra.on) ? const_cast<float *>(actions_dev) + 2 * (size_t)cars : envs[b]->actions_in;
+        cars += envs[b]->n_cars;
+    }
+    g.wave_start[n] = waves;
+    TIMED(lead, RC_K_DYNAMICS, rck_launch_dynamics_group(g, lead->cfg.cars_per_env, repeat, ra, lead->stream));
+    // scan: a wave = one car (or 1 / split of one); the split follows the group's total, as one handle of that size would
+    const long long want = 48LL * lead->launch.n_cu;
+    int split = lead->dbg[RC_DBG_RAY_SPLIT];
+    if (split < 1 || split > 17) split = (int)std::min<long long>(17, std::max<long long>(1, (want + cars - 1) / cars));
+    waves = 0;
+    for (int b = 0; b < n; ++b) {
+        g.wave_start[b] = waves;
+        waves += envs[b]->n_cars * split;
+    }
+    g.wave_start[n] = waves;
+    TIMED(lead, RC_K_RAYCAST, rck_launch_raycast_group(g, lead->cfg.cars_per_env, split, lead->stream));
+    for (int b = 0; b < n; ++b)
+        if (envs[b]->params.render_patch)
+            TIMED(envs[b], RC_K_PATCH, rck_launch_patch(envs[b]->params, envs[b]->launch, envs[b]->stream));
+    return RC_OK;
+}
+
+int rc_step_group(rc_env **envs, int32_t n, const float *actions_dev, int32_t repeat) {
+    const RcRandomActions none{0, 0u, 0u, 0u};
+    return group_step(envs, n, actions_dev, repeat, none, "rc_step_group");
+}
+
+int rc_step_random_group(rc_env **envs, int32_t n, uint64_t seed, uint32_t step, int32_t repeat) {
+    const RcRandomActions ra{1, (uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), step};
+    return group_step(envs, n, nullptr, repeat, ra, "rc_step_random_group");
 }
 
 int rc_step_host(rc_env *env, const float *actions_host, int32_t repeat) {

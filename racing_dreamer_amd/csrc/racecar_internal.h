@@ -83,6 +83,14 @@ struct RcParams {
     uint32_t *scan_overrun;      // device counter: waves of the BOUNDED scan build that used up a round's trip budget
 };
 
+#define RC_GROUP_MAX 8
+struct RcGroup {                 // several handles in one launch (rc_step_group)
+    const RcParams *params;      // device table, one entry per block
+    float *actions[RC_GROUP_MAX];          // dynamics: the block's action buffer
+    int32_t wave_start[RC_GROUP_MAX + 1];  // first wave of every block in the launch's grid, and the total
+    int32_t n;
+};
+
 struct RcLaunchInfo {            // per-handle launch geometry decided at rc_load_track
     int32_t n_cu;
     int32_t ray_blocks, ray_threads;
@@ -111,6 +119,9 @@ struct RcSampleWindows {
     uint32_t *failed;
 };
 hipError_t rck_sample_windows(const RcSampleWindows &a, hipStream_t s);
+struct RcRandomActions;
+hipError_t rck_launch_dynamics_group(const RcGroup &g, int cars_per_env, int repeat, const RcRandomActions &ra, hipStream_t s);
+hipError_t rck_launch_raycast_group(const RcGroup &g, int cars_per_env, int split, hipStream_t s);
 hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *slot_idx, const int32_t *car_idx, int n_rows,
                            const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s);
 #define RC_P2P_MAX_RANKS 64

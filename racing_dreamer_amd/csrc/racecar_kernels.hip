@@ -234,10 +234,8 @@ template <int A>
 // rand_on != 0: the actions are not read but drawn here, U(-1, 1)^2 from Philox keyed by (seed, step, global car id) -
 // the same numbers rc_random_actions_kernel writes (synthetic random-action rollouts without a launch of their own);
 // they are stored to `actions` as well, so the buffer shows what was applied.
-__global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__restrict__ actions, int repeat,
-                                                          int rand_on, uint32_t rand_lo, uint32_t rand_hi, uint32_t rand_step) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= p.num_envs) return;
+__device__ __forceinline__ void dynamics_env(const RcParams &p, float *__restrict__ actions, const int repeat, const int rand_on,
+                                             const uint32_t rand_lo, const uint32_t rand_hi, const uint32_t rand_step, const int e) {
     const RcTrackDev &t = p.trk;
     // the episode counter first: it is the oldest load in flight, so the reset's Philox draw can wait for it alone
     const uint32_t episode = p.auto_reset ? p.st.episode[e] : 0u;
@@ -374,6 +372,38 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
         if (fin) apply_reset<A>(p, e, car, spawn, episode, steps, agent_steps);
     }
     store_state_and_obs<A>(p, e, car, steps, agent_steps);
+}
+
+template <int A>
+__global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__restrict__ actions, int repeat,
+                                                          int rand_on, uint32_t rand_lo, uint32_t rand_hi, uint32_t rand_step) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= p.num_envs) return;
+    dynamics_env<A>(p, actions, repeat, rand_on, rand_lo, rand_hi, rand_step, e);
+}
+
+// ---- Several handles in ONE launch (rc_step_group: one handle per track, each filling its block of cars of one arena).  A
+// wave belongs to one block: it finds it among <= RC_GROUP_MAX wave ranges (scalar compares) and works from THAT block's
+// RcParams, read from a device table with scalar loads - the same loads, from another address, that the single-handle
+// kernels do from their argument block.  The device code is the single-handle kernels' (dynamics_env, scan_car).
+__device__ __forceinline__ int group_block(const RcGroup &g, const int wave) {
+    int b = 0;
+#pragma unroll
+    for (int k = 1; k < RC_GROUP_MAX; ++k) b += (k < g.n && wave >= g.wave_start[k]) ? 1 : 0;
+    return b;
+}
+
+template <int A>
+__global__ __launch_bounds__(256) void rc_dynamics_group_kernel(const RcParams *__restrict__ params, RcGroup g, int repeat, int rand_on,
+                                                                uint32_t rand_lo, uint32_t rand_hi, uint32_t rand_step) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= g.wave_start[g.n]) return;
+    const int b = group_block(g, wave);
+    const RcParams p = params[b];           // a COPY (top-level pointer argument + uniform index: scalar loads; a reference would be
+                                            // re-read after every store, the table not being known to stay as it is)
+    const int e = (wave - g.wave_start[b]) * 64 + (int)(threadIdx.x & 63u);
+    if (e >= p.num_envs) return;
+    dynamics_env<A>(p, g.actions[b], repeat, rand_on, rand_lo, rand_hi, rand_step, e);
 }
 
 template <int A>
@@ -1631,6 +1661,21 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     scan_car<A, false, OVERLAP, GUARD>(p, car, part, split, lane, lds_row);
 }
 
+template <int A, bool OVERLAP>
+__global__ __launch_bounds__(256) void rc_raycast_group_kernel(const RcParams *__restrict__ params, RcGroup g, int split) {
+    extern __shared__ uint32_t lds_words[];
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_words;
+    const uint32_t lds_row = __builtin_amdgcn_readfirstlane(lds_base + (threadIdx.x >> 6) * kCarLdsBytes);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    if (wave >= g.wave_start[g.n]) return;
+    const int b = group_block(g, wave);
+    const RcParams p = params[b];           // (a copy: see rc_dynamics_group_kernel)
+    const unsigned local = (unsigned)(wave - g.wave_start[b]);
+    const unsigned car = local / (unsigned)split, part = local - car * (unsigned)split;
+    if (car >= (unsigned)p.n_cars) return;
+    scan_car<A, false, OVERLAP, false>(p, car, part, split, threadIdx.x & 63u, lds_row);
+}
+
 // The instrumented build of the same kernel (rc_debug_scan_stamps; one car per env, analysis only).
 __global__ __launch_bounds__(256) void rc_raycast_car_stamps_kernel(RcParams p, int split, unsigned long long *stamps, int n_waves) {
     extern __shared__ uint32_t lds_words[];
@@ -2595,6 +2640,22 @@ hipError_t rck_set_lds_limits(size_t lds_bytes) {
 hipError_t rck_launch_dynamics(const RcParams &p, float *actions, int repeat, const RcRandomActions &ra, hipStream_t s) {
     const int threads = 256, blocks = (p.num_envs + threads - 1) / threads;
     DISPATCH_A(p.cars_per_env, launch((rc_dynamics_kernel<kA>), dim3(blocks), dim3(threads), 0, s, p, actions, repeat, ra.on, ra.seed_lo, ra.seed_hi, ra.step));
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_dynamics_group(const RcGroup &g, int cars_per_env, int repeat, const RcRandomActions &ra, hipStream_t s) {
+    const int waves = g.wave_start[g.n], blocks = (waves + 3) / 4;
+    DISPATCH_A(cars_per_env, launch((rc_dynamics_group_kernel<kA>), dim3(blocks), dim3(256), 0, s, g.params, g, repeat, ra.on, ra.seed_lo, ra.seed_hi, ra.step));
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_raycast_group(const RcGroup &g, int cars_per_env, int split, hipStream_t s) {
+    const int waves = g.wave_start[g.n];                     // one wave per workgroup, as the single-handle scan
+    if (split > 1) {
+        DISPATCH_A(cars_per_env, launch((rc_raycast_group_kernel<kA, true>), dim3((unsigned)waves), dim3(64), (size_t)kCarLdsBytes, s, g.params, g, split));
+    } else {
+        DISPATCH_A(cars_per_env, launch((rc_raycast_group_kernel<kA, false>), dim3((unsigned)waves), dim3(64), (size_t)kCarLdsBytes, s, g.params, g, split));
+    }
     return hipGetLastError();
 }
 

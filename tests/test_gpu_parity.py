@@ -990,3 +990,36 @@ def test_every_compiled_map_steps_like_the_oracle():
             act[:, 0] = np.abs(act[:, 0])
             compare_outputs(env.step(torch.from_numpy(act).cuda(), repeat=4), ora.step(act, repeat=4), n, 1, f"{name} step {k}")
         env.close()
+
+
+def test_group_step_is_the_handles_stepped_one_by_one():
+    """rc_step_group (one dynamics and one scan launch over the blocks of a MixedTrackEnv) against the same handles stepped one
+    after the other with rc_step, external actions and a re-pointed arena (the device table of parameters follows rc_set_arena):
+    every output identical; and its error paths."""
+    import ctypes as C
+    import torch
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import MixedTrackEnv
+    names, sizes = ["columbia", "barcelona", "austria"], [70, 33, 90]
+    a = MixedTrackEnv(names, sizes, cars_per_env=2, obs_type="lidar_occupancy", auto_reset=True)
+    b = MixedTrackEnv(names, sizes, cars_per_env=2, obs_type="lidar_occupancy", auto_reset=True)
+    a.reset(mode="random_ball", seed=3); b.reset(mode="random_ball", seed=3)
+    n = sum(sizes)
+    for k in range(20):
+        act = ro.random_actions(9, k, n * 2)
+        act[:, 0] = np.abs(act[:, 0])
+        t = torch.from_numpy(act).cuda().view(n, 2, 2)
+        out_a = a.step(t, repeat=3)                                              # the group launch
+        for p, (lo, hi) in zip(b.parts, b.blocks):                               # handle by handle
+            L.check(p._lib.rc_step(p._h, t[lo:hi].contiguous().data_ptr(), 3))
+        torch.cuda.synchronize()
+        for name, v in out_a.items():
+            assert torch.equal(v, b.views[name]), (k, name)
+    lib = a._lib
+    two = (C.c_void_p * 2)(a.parts[0]._h, a.parts[0]._h)
+    with pytest.raises(L.RacecarHipError, match="twice"):
+        L.check(lib.rc_step_random_group(two, 2, C.c_uint64(1), C.c_uint32(0), 1))
+    other = (C.c_void_p * 2)(a.parts[0]._h, b.parts[1]._h)
+    with pytest.raises(L.RacecarHipError, match="one stream"):
+        L.check(lib.rc_step_random_group(other, 2, C.c_uint64(1), C.c_uint32(0), 1))
+    a.close(); b.close()
