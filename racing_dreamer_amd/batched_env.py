@@ -596,7 +596,7 @@ class MixedTrackEnv:
     # step is ONE dynamics and ONE scan launch over all blocks (`rc_step_group`: every wave works from the parameters of the
     # block it lies in): with a launch pair per block on streams of their own, each block's small dynamics kernel waited behind
     # the previous block's scan, the three scans shared the chip and 33 us passed between the join of one step and the first
-    # kernel of the next (0.258 -> 0.230 ms per step of three blocks of 21 845 envs; the three tracks alone average 0.20;
+    # kernel of the next (0.258 -> 0.208 ms per step of three blocks of 21 845 envs; the three tracks alone average 0.20;
     # EXPERIMENTS I.10).
     def _ordered(self, call):
         cur = torch.cuda.current_stream(self.device)

@@ -1666,8 +1666,13 @@ __global__ __launch_bounds__(256) void rc_raycast_group_kernel(const RcParams *_
     extern __shared__ uint32_t lds_words[];
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_words;
     const uint32_t lds_row = __builtin_amdgcn_readfirstlane(lds_base + (threadIdx.x >> 6) * kCarLdsBytes);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
-    if (wave >= g.wave_start[g.n]) return;
+    // Workgroups go to the 8 XCDs in turn, each with an L2 of its own: workgroup i takes wave (i mod 8) x ceil(W / 8) + i / 8, so
+    // that an XCD works through ONE stretch of the car order - one track's tables in its L2, two at a block boundary - instead
+    // of every eighth car of all tracks.
+    const int launched = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)));
+    const int per_xcd = (g.wave_start[g.n] + 7) >> 3;
+    const int wave = (launched & 7) * per_xcd + (launched >> 3);
+    if ((launched >> 3) >= per_xcd || wave >= g.wave_start[g.n]) return;
     const int b = group_block(g, wave);
     const RcParams p = params[b];           // (a copy: see rc_dynamics_group_kernel)
     const unsigned local = (unsigned)(wave - g.wave_start[b]);
@@ -2650,7 +2655,7 @@ hipError_t rck_launch_dynamics_group(const RcGroup &g, int cars_per_env, int rep
 }
 
 hipError_t rck_launch_raycast_group(const RcGroup &g, int cars_per_env, int split, hipStream_t s) {
-    const int waves = g.wave_start[g.n];                     // one wave per workgroup, as the single-handle scan
+    const int waves = ((g.wave_start[g.n] + 7) / 8) * 8;     // one wave per workgroup, as the single-handle scan; whole turns of the 8 XCDs
     if (split > 1) {
         DISPATCH_A(cars_per_env, launch((rc_raycast_group_kernel<kA, true>), dim3((unsigned)waves), dim3(64), (size_t)kCarLdsBytes, s, g.params, g, split));
     } else {
