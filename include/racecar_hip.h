@@ -348,7 +348,8 @@ int rc_scan_kernel_name(rc_env *env, char *out, size_t bytes);
 enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, RC_DBG_BAND_LOG2 = 3,
        RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiment: bit 1 = plain instead of non-temporal stores */
        RC_DBG_SCAN_BOUNDED = 5,     /* != 0: the scan runs the build whose trip loop carries a trip budget (see below) */
-       RC_DBG_COUNT = 6 };
+       RC_DBG_SCAN_ORDER = 6,   /* 0 = production (the scan takes the cars in track order, sorted every 64 observations), 1 = car index order, k > 1 = sorted every k - 1 observations */
+    RC_DBG_COUNT = 7 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
 
 /* The default scan's trip loop is unbounded in the production build (its termination is a property of the tables and

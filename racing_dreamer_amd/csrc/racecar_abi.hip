@@ -220,6 +220,8 @@ struct rc_env {
     bool gather_pending = false;
     P2p *p2p = nullptr;                // peer-copy all-gather (rc_p2p_setup), else null
     float *ftg_prev = nullptr;         // rc_follow_the_gap_reference: previous heading per car (NaN = none), allocated on first use
+    void *order_mem = nullptr;         // RcStateDev::order + the sort's bucket counters (batches of RC_ORDER_MIN_CARS cars and more)
+    uint32_t order_age = 0;            // observations since the cars were last sorted by track position
     // rc_step_group (this handle as the first of a group): the blocks' RcParams as the last launch saw them, on the device
     // and on the host (pinned staging slots taken in turn, each with the event of its copy)
     RcParams *group_dev = nullptr;
@@ -372,7 +374,24 @@ void bind_outputs(rc_env *env, void *arena) {
     env->out_arena = arena;
 }
 
+// Every RC_ORDER_PERIOD observations (and at the first one after a reset) the cars are sorted by their progress along the track:
+// three small launches; the scan then takes them in that order.
+int sort_cars_if_due(rc_env *env) {
+    if (!env->order_mem || env->dbg[RC_DBG_SCAN_ORDER] == 1) { env->params.st.order = nullptr; return RC_OK; }
+    const uint32_t period = env->dbg[RC_DBG_SCAN_ORDER] > 1 ? (uint32_t)env->dbg[RC_DBG_SCAN_ORDER] - 1u : (uint32_t)RC_ORDER_PERIOD;
+    if (env->params.st.order == nullptr || env->order_age >= period) {
+        int32_t *order = (int32_t *)env->order_mem;
+        HIP_TRY(rck_sort_cars(env->params.st.progress, env->n_cars, (uint32_t *)(order + env->n_cars), order, env->stream));
+        env->params.st.order = order;
+        env->order_age = 0;
+    }
+    env->order_age += 1;
+    return RC_OK;
+}
+
 int observe(rc_env *env) {
+    int rc_sort = sort_cars_if_due(env);
+    if (rc_sort) return rc_sort;
     TIMED(env, RC_K_RAYCAST, rck_launch_raycast(env->params, env->launch, env->stream));
     if (env->params.render_patch)
         TIMED(env, RC_K_PATCH, rck_launch_patch(env->params, env->launch, env->stream));
@@ -640,6 +659,10 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         if (any_nstep) m += nc * RC_NSTEP_MAX * 4;
         env->params.scan_overrun = (uint32_t *)m;             // (zeroed with the rest)
     }
+    if (n >= RC_ORDER_MIN_CARS) {          // the scan takes the cars in track order (sorted every RC_ORDER_PERIOD observations)
+        HIP_TRY_FREE(hipMalloc(&env->order_mem, (size_t)n * 4 + RC_ORDER_BUCKETS * 4));
+        env->params.st.order = nullptr;    // (identity until the first sort: set in sort_cars_if_due)
+    }
     bind_outputs(env, env->arena);
     env->actions_in = (float *)((char *)env->arena + env->layout.offset[RC_F_ACTION_IN]);
     RcParams &p = env->params;
@@ -685,6 +708,7 @@ void rc_destroy(rc_env *env) {
     if (env->own_arena && env->arena) (void)hipFree(env->arena);
     if (env->state_mem) (void)hipFree(env->state_mem);
     if (env->ftg_prev) (void)hipFree(env->ftg_prev);
+    if (env->order_mem) (void)hipFree(env->order_mem);
     if (env->group_dev) (void)hipFree(env->group_dev);
     if (env->group_host) (void)hipHostFree(env->group_host);
     for (hipEvent_t e : env->group_ev) if (e) (void)hipEventDestroy(e);
@@ -941,6 +965,7 @@ int rc_reset(rc_env *env, const uint8_t *mask_or_null, int32_t mode, uint64_t se
     }
     TIMED(env, RC_K_RESET, rck_launch_reset(env->params, mask_dev, env->stream));
     env->was_reset = true;
+    if (!mask_or_null) env->order_age = 0xffffffffu;      // every car has a new place: sort before this observation
     return observe(env);
 }
 
@@ -989,6 +1014,11 @@ static int group_step(rc_env **envs, int32_t n, const float *actions_dev, int32_
             if (envs[c] == e) return fail(RC_ERR_INVALID, "%s: handle %d appears twice", who, b);
     }
     HIP_TRY(hipSetDevice(lead->cfg.device));
+    for (int b = 0; b < n; ++b) {
+        // (the sort reads last step's progress: the order is a matter of locality, not of results)
+        int rc_sort = sort_cars_if_due(envs[b]);
+        if (rc_sort) return rc_sort;
+    }
     if (!lead->group_dev) {
         HIP_TRY(hipMalloc((void **)&lead->group_dev, sizeof(RcParams) * RC_GROUP_MAX));
         HIP_TRY(hipHostMalloc((void **)&lead->group_host, sizeof(RcParams) * RC_GROUP_MAX * 4, hipHostMallocDefault));

@@ -54,6 +54,9 @@ struct RcStateDev {              // persistent per-car / per-env simulator state
                                     // scalar 16-byte load (four separate words cost it a second serial round trip)
     float *nstep_hist;              // [n_cars][RC_NSTEP_MAX] total progress at sub-step s in slot s % n_steps; null unless
                                     // some car runs RC_TASK_N_STEP_PROGRESS
+    const int32_t *order;           // [n_cars] the order in which the scan's waves take the cars: sorted by track position every
+                                    // RC_ORDER_PERIOD observations, so that the waves in flight at one time read one stretch of the
+                                    // track's tables (L2); null = car index order (small batches)
 };
 
 struct RcOutDev {                // output arena sections (see rc_field)
@@ -83,6 +86,9 @@ struct RcParams {
     uint32_t *scan_overrun;      // device counter: waves of the BOUNDED scan build that used up a round's trip budget
 };
 
+#define RC_ORDER_BUCKETS 1024       // counting sort of the cars by progress
+#define RC_ORDER_PERIOD 64          // observations between two sorts (cars move centimetres per step)
+#define RC_ORDER_MIN_CARS 16384     // below this the whole batch is in flight at once anyway
 #define RC_GROUP_MAX 8
 struct RcGroup {                 // several handles in one launch (rc_step_group)
     const RcParams *params;      // device table, one entry per block
@@ -119,6 +125,7 @@ struct RcSampleWindows {
     uint32_t *failed;
 };
 hipError_t rck_sample_windows(const RcSampleWindows &a, hipStream_t s);
+hipError_t rck_sort_cars(const float *progress_dev, int n_cars, uint32_t *counts_dev, int32_t *order_dev, hipStream_t s);
 struct RcRandomActions;
 hipError_t rck_launch_dynamics_group(const RcGroup &g, int cars_per_env, int repeat, const RcRandomActions &ra, hipStream_t s);
 hipError_t rck_launch_raycast_group(const RcGroup &g, int cars_per_env, int split, hipStream_t s);

@@ -1656,8 +1656,10 @@ __global__ __launch_bounds__(256) void rc_raycast_car_kernel(RcParams p, int spl
     const uint32_t lds_row = __builtin_amdgcn_readfirstlane(lds_base + (threadIdx.x >> 6) * kCarLdsBytes);
     const unsigned wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned car = wave / (unsigned)split, part = wave - car * (unsigned)split;
-    if (car >= (unsigned)p.n_cars) return;
+    const unsigned slot = wave / (unsigned)split, part = wave - slot * (unsigned)split;
+    if (slot >= (unsigned)p.n_cars) return;
+    // (the waves take the cars in track order - see RcStateDev::order -: 5 % of the scan at 65 536 cars, EXPERIMENTS I.11)
+    const unsigned car = p.st.order != nullptr ? (unsigned)p.st.order[slot] : slot;
     scan_car<A, false, OVERLAP, GUARD>(p, car, part, split, lane, lds_row);
 }
 
@@ -1676,8 +1678,9 @@ __global__ __launch_bounds__(256) void rc_raycast_group_kernel(const RcParams *_
     const int b = group_block(g, wave);
     const RcParams p = params[b];           // (a copy: see rc_dynamics_group_kernel)
     const unsigned local = (unsigned)(wave - g.wave_start[b]);
-    const unsigned car = local / (unsigned)split, part = local - car * (unsigned)split;
-    if (car >= (unsigned)p.n_cars) return;
+    const unsigned slot = local / (unsigned)split, part = local - slot * (unsigned)split;
+    if (slot >= (unsigned)p.n_cars) return;
+    const unsigned car = p.st.order != nullptr ? (unsigned)p.st.order[slot] : slot;
     scan_car<A, false, OVERLAP, false>(p, car, part, split, threadIdx.x & 63u, lds_row);
 }
 
@@ -2497,6 +2500,47 @@ hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *s
     for (int f = 0; f < n_fields; ++f) { g.src_off[f] = src_off[f]; g.dst_off[f] = dst_off[f]; g.bpc[f] = bpc[f]; }
     hipLaunchKernelGGL(rc_gather_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, (const char *)ring, slot_bytes, slot_idx, car_idx,
                        n_rows, g, (char *)out);
+    return hipGetLastError();
+}
+
+// ---- the order in which the scan takes the cars (RcStateDev::order): a counting sort by progress along the track, RC_ORDER_BUCKETS
+// buckets; within a bucket the order is whatever the atomics give - results do not depend on it, every car is scanned on its own.
+__device__ __forceinline__ int order_bucket(float progress) {
+    int b = (int)(progress * (float)RC_ORDER_BUCKETS);
+    return b < 0 ? 0 : (b > RC_ORDER_BUCKETS - 1 ? RC_ORDER_BUCKETS - 1 : b);
+}
+__global__ __launch_bounds__(256) void rc_order_count_kernel(const float *__restrict__ progress, int n, uint32_t *__restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&counts[order_bucket(progress[i])], 1u);
+}
+__global__ __launch_bounds__(RC_ORDER_BUCKETS) void rc_order_offsets_kernel(uint32_t *__restrict__ counts) {
+    // exclusive prefix sum of the bucket counts, in place (one workgroup): the buckets' first positions
+    __shared__ uint32_t s[RC_ORDER_BUCKETS];
+    const int t = threadIdx.x;
+    const uint32_t mine = counts[t];
+    s[t] = mine;
+    __syncthreads();
+    for (int off = 1; off < RC_ORDER_BUCKETS; off <<= 1) {
+        const uint32_t add = t >= off ? s[t - off] : 0u;
+        __syncthreads();
+        s[t] += add;
+        __syncthreads();
+    }
+    counts[t] = s[t] - mine;
+}
+__global__ __launch_bounds__(256) void rc_order_place_kernel(const float *__restrict__ progress, int n, uint32_t *__restrict__ cursor,
+                                                             int32_t *__restrict__ order) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&cursor[order_bucket(progress[i])], 1u)] = i;
+}
+
+hipError_t rck_sort_cars(const float *progress_dev, int n_cars, uint32_t *counts_dev, int32_t *order_dev, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * RC_ORDER_BUCKETS, s);
+    if (e != hipSuccess) return e;
+    const int blocks = (n_cars + 255) / 256;
+    hipLaunchKernelGGL(rc_order_count_kernel, dim3(blocks), dim3(256), 0, s, progress_dev, n_cars, counts_dev);
+    hipLaunchKernelGGL(rc_order_offsets_kernel, dim3(1), dim3(RC_ORDER_BUCKETS), 0, s, counts_dev);
+    hipLaunchKernelGGL(rc_order_place_kernel, dim3(blocks), dim3(256), 0, s, progress_dev, n_cars, counts_dev, order_dev);
     return hipGetLastError();
 }
 
