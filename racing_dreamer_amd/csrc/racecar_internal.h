@@ -87,6 +87,7 @@ struct RcParams {
 };
 
 #define RC_ORDER_BUCKETS 1024       // counting sort of the cars by progress
+#define RC_ORDER_REGION 256u         // ranks per region handed to one XCD (rc_order_place_kernel)
 #define RC_ORDER_PERIOD 64          // observations between two sorts (cars move centimetres per step)
 #define RC_ORDER_MIN_CARS 16384     // below this the whole batch is in flight at once anyway
 #define RC_GROUP_MAX 8

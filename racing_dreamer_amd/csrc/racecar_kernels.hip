@@ -382,6 +382,14 @@ __global__ __launch_bounds__(256) void rc_dynamics_kernel(RcParams p, float *__r
     dynamics_env<A>(p, actions, repeat, rand_on, rand_lo, rand_hi, rand_step, e);
 }
 
+// Where the car of rank r (position along the track) stands in RcStateDev::order - see rc_order_place_kernel.
+__device__ __forceinline__ uint32_t order_slot_of_rank(uint32_t r, uint32_t n) {
+    const uint32_t whole = (n / (8u * RC_ORDER_REGION)) * (8u * RC_ORDER_REGION);
+    if (r >= whole) return r;
+    const uint32_t g = r / RC_ORDER_REGION, o = r % RC_ORDER_REGION;
+    return ((g >> 3) * RC_ORDER_REGION + o) * 8u + (g & 7u);
+}
+
 // ---- Several handles in ONE launch (rc_step_group: one handle per track, each filling its block of cars of one arena).  A
 // wave belongs to one block: it finds it among <= RC_GROUP_MAX wave ranges (scalar compares) and works from THAT block's
 // RcParams, read from a device table with scalar loads - the same loads, from another address, that the single-handle
@@ -1680,7 +1688,8 @@ __global__ __launch_bounds__(256) void rc_raycast_group_kernel(const RcParams *_
     const unsigned local = (unsigned)(wave - g.wave_start[b]);
     const unsigned slot = local / (unsigned)split, part = local - slot * (unsigned)split;
     if (slot >= (unsigned)p.n_cars) return;
-    const unsigned car = p.st.order != nullptr ? (unsigned)p.st.order[slot] : slot;
+    // (this launch hands every XCD a STRETCH of the slots, not every eighth: it takes the cars by rank)
+    const unsigned car = p.st.order != nullptr ? (unsigned)p.st.order[order_slot_of_rank(slot, (uint32_t)p.n_cars)] : slot;
     scan_car<A, false, OVERLAP, false>(p, car, part, split, threadIdx.x & 63u, lds_row);
 }
 
@@ -2531,7 +2540,14 @@ __global__ __launch_bounds__(RC_ORDER_BUCKETS) void rc_order_offsets_kernel(uint
 __global__ __launch_bounds__(256) void rc_order_place_kernel(const float *__restrict__ progress, int n, uint32_t *__restrict__ cursor,
                                                              int32_t *__restrict__ order) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) order[atomicAdd(&cursor[order_bucket(progress[i])], 1u)] = i;
+    if (i >= n) return;
+    uint32_t pos = atomicAdd(&cursor[order_bucket(progress[i])], 1u);
+    // Workgroups go to the 8 XCDs in turn.  Plain rank order would hand every XCD each eighth car of the stretch in flight - the same
+    // table lines in all eight L2s; instead XCD x gets whole regions x, x + 8, ... of RC_ORDER_REGION ranks (region g, offset o ->
+    // slot ((g / 8) R + o) 8 + g mod 8): the stretch in flight is the same, each L2 holds an eighth of it (1.8 % of the scan;
+    // 64 and 512 ranks per region do 1.2 %, 1 024 and more lose - the XCDs' regions then differ too much in cost).
+    pos = order_slot_of_rank(pos, (uint32_t)n);
+    order[pos] = i;
 }
 
 hipError_t rck_sort_cars(const float *progress_dev, int n_cars, uint32_t *counts_dev, int32_t *order_dev, hipStream_t s) {
