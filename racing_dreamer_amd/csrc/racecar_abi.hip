@@ -377,11 +377,23 @@ void bind_outputs(rc_env *env, void *arena) {
 // Every RC_ORDER_PERIOD observations (and at the first one after a reset) the cars are sorted by their progress along the track:
 // three small launches; the scan then takes them in that order.
 int sort_cars_if_due(rc_env *env) {
-    if (!env->order_mem || env->dbg[RC_DBG_SCAN_ORDER] == 1) { env->params.st.order = nullptr; return RC_OK; }
+    const bool small = env->n_cars < RC_ORDER_MIN_CARS;
+    if (!env->order_mem || env->dbg[RC_DBG_SCAN_ORDER] == 1 ||
+        (small && 4ull * (unsigned long long)env->params.trk.quad_plane_bytes <= RC_ORDER_COST_MIN_TABLE)) {
+        env->params.st.order = nullptr;
+        return RC_OK;
+    }
     const uint32_t period = env->dbg[RC_DBG_SCAN_ORDER] > 1 ? (uint32_t)env->dbg[RC_DBG_SCAN_ORDER] - 1u : (uint32_t)RC_ORDER_PERIOD;
     if (env->params.st.order == nullptr || env->order_age >= period) {
         int32_t *order = (int32_t *)env->order_mem;
-        HIP_TRY(rck_sort_cars(env->params.st.progress, env->n_cars, (uint32_t *)(order + env->n_cars), order, env->stream));
+        if (env->n_cars >= RC_ORDER_MIN_CARS) {
+            HIP_TRY(rck_sort_cars(env->params.st.progress, env->n_cars, (uint32_t *)(order + env->n_cars), order, env->stream));
+        } else {
+            // small batch: every wave slot is taken at once and the rest of the waves follow as slots come free - longest first
+            float *key = (float *)(order + env->n_cars) + RC_ORDER_BUCKETS;
+            HIP_TRY(rck_cost_keys(env->params.out.lidar, env->n_cars, key, env->stream));
+            HIP_TRY(rck_sort_cars(key, env->n_cars, (uint32_t *)(order + env->n_cars), order, env->stream));
+        }
         env->params.st.order = order;
         env->order_age = 0;
     }
@@ -659,8 +671,8 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         if (any_nstep) m += nc * RC_NSTEP_MAX * 4;
         env->params.scan_overrun = (uint32_t *)m;             // (zeroed with the rest)
     }
-    if (n >= RC_ORDER_MIN_CARS) {          // the scan takes the cars in track order (sorted every RC_ORDER_PERIOD observations)
-        HIP_TRY_FREE(hipMalloc(&env->order_mem, (size_t)n * 4 + RC_ORDER_BUCKETS * 4));
+    if (n >= RC_ORDER_COST_MIN_CARS) {     // the scan takes the cars in track order / longest first (sorted every RC_ORDER_PERIOD observations)
+        HIP_TRY_FREE(hipMalloc(&env->order_mem, (size_t)n * 8 + RC_ORDER_BUCKETS * 4));
         env->params.st.order = nullptr;    // (identity until the first sort: set in sort_cars_if_due)
     }
     bind_outputs(env, env->arena);

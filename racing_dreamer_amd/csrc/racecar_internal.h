@@ -89,7 +89,9 @@ struct RcParams {
 #define RC_ORDER_BUCKETS 1024       // counting sort of the cars by progress
 #define RC_ORDER_REGION 256u         // ranks per region handed to one XCD (rc_order_place_kernel)
 #define RC_ORDER_PERIOD 64          // observations between two sorts (cars move centimetres per step)
-#define RC_ORDER_MIN_CARS 16384     // below this the whole batch is in flight at once anyway
+#define RC_ORDER_MIN_CARS 16384     // track order from here on; below, the whole batch is in flight at once anyway, and on maps whose
+#define RC_ORDER_COST_MIN_CARS 1024  // quadrant planes exceed RC_ORDER_COST_MIN_TABLE bytes (columbia: 0.9 MB, no gain; austria: 1.8 MB) the cars are taken
+#define RC_ORDER_COST_MIN_TABLE (5u << 18)   // longest first instead (rc_order_cost_key_kernel); 1.25 MB: measured, see EXPERIMENTS I.11
 #define RC_GROUP_MAX 8
 struct RcGroup {                 // several handles in one launch (rc_step_group)
     const RcParams *params;      // device table, one entry per block
@@ -126,6 +128,7 @@ struct RcSampleWindows {
     uint32_t *failed;
 };
 hipError_t rck_sample_windows(const RcSampleWindows &a, hipStream_t s);
+hipError_t rck_cost_keys(const float *lidar_dev, int n_cars, float *key_dev, hipStream_t s);
 hipError_t rck_sort_cars(const float *progress_dev, int n_cars, uint32_t *counts_dev, int32_t *order_dev, hipStream_t s);
 struct RcRandomActions;
 hipError_t rck_launch_dynamics_group(const RcGroup &g, int cars_per_env, int repeat, const RcRandomActions &ra, hipStream_t s);

@@ -2550,6 +2550,21 @@ __global__ __launch_bounds__(256) void rc_order_place_kernel(const float *__rest
     order[pos] = i;
 }
 
+// The key of the small batches' order: 1 - mean range / 15 m of the car's last scan, i.e. long rays (many trips) first - the
+// waves that start last, when the first have freed their slots, are then the short ones (a wave per car).
+__global__ __launch_bounds__(256) void rc_order_cost_key_kernel(const float *__restrict__ lidar, int n, float *__restrict__ key) {
+    const int car = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (car >= n) return;
+    float s = 0.0f;
+    for (int b = lane; b < RC_N_BEAMS; b += 64) s += lidar[(size_t)car * RC_N_BEAMS + b];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) key[car] = 1.0f - s * (0.999f / (15.0f * RC_N_BEAMS));
+}
+hipError_t rck_cost_keys(const float *lidar_dev, int n_cars, float *key_dev, hipStream_t s) {
+    hipLaunchKernelGGL(rc_order_cost_key_kernel, dim3((unsigned)((n_cars + 3) / 4)), dim3(256), 0, s, lidar_dev, n_cars, key_dev);
+    return hipGetLastError();
+}
+
 hipError_t rck_sort_cars(const float *progress_dev, int n_cars, uint32_t *counts_dev, int32_t *order_dev, hipStream_t s) {
     hipError_t e = hipMemsetAsync(counts_dev, 0, sizeof(uint32_t) * RC_ORDER_BUCKETS, s);
     if (e != hipSuccess) return e;

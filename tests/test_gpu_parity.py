@@ -1025,16 +1025,17 @@ def test_group_step_is_the_handles_stepped_one_by_one():
     a.close(); b.close()
 
 
-def test_the_order_in_which_the_scan_takes_the_cars_changes_nothing():
-    """From 16 384 cars on the scan's waves take the cars sorted by track position (RcStateDev::order: a counting sort every 64
-    observations, for the L2's sake).  Three envs - the production order, car index order (knob 1) and a fresh sort before every
-    observation (knob 2) - give identical outputs step for step, over a reset in the middle."""
+@pytest.mark.parametrize("track,n", [("columbia", 16384), ("austria", 4096)])
+def test_the_order_in_which_the_scan_takes_the_cars_changes_nothing(track, n):
+    """The scan's waves take the cars in an order of their own (RcStateDev::order, a counting sort every 64 observations): from
+    16 384 cars on by track position, for the L2s' sake; below that, on maps with large tables, longest scan first, for the
+    tail's.  Three envs - the production order, car index order (knob 1) and a fresh sort before every observation (knob 2) -
+    give identical outputs step for step, over a reset in the middle."""
     import torch
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
-    n = 16384
     envs = []
     for knob in (0, 1, 2):
-        e = BatchedRaceEnv("columbia", n, 1, auto_reset=True)
+        e = BatchedRaceEnv(track, n, 1, auto_reset=True)
         e.debug_set("scan_order", knob)
         e.reset(mode="random", seed=8)
         envs.append(e)
