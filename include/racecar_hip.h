@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 1
+#define RC_ABI_VERSION 2      /* 2 (round 4): rc_build_id, reset laws of SURVEY H6, outbound ordering of the peer-copy gather */
 #define RC_N_BEAMS 1080
 #define RC_PATCH 64
 #define RC_MAX_CARS 4
@@ -377,6 +377,9 @@ int rc_selftest_reciprocal(int32_t device, uint64_t *n_checked, uint64_t *n_mism
 
 const char *rc_last_error(void);
 int rc_abi_version(void);
+/* Hash (32 hex digits) of the compiler flags and of the contents of every source and header this library was built
+ * from - what racing_dreamer_amd/build.py compares with the tree beside it to decide whether to compile. */
+const char *rc_build_id(void);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ import os
 LIB_DIR = os.path.join(os.path.dirname(__file__), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libracecar_hip.so")
 
+RC_ABI_VERSION = 2          # include/racecar_hip.h
 RC_N_BEAMS = 1080
 RC_PATCH = 64
 RC_MAX_CARS = 4
@@ -111,6 +112,7 @@ SYMBOLS = {
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rc_last_error": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),
+    "rc_build_id": (C.c_char_p, []),
 }
 
 
@@ -135,8 +137,9 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.rc_abi_version() != 1:
-        raise RacecarHipError(f"ABI version mismatch: library reports {lib.rc_abi_version()}, binding expects 1")
+    if lib.rc_abi_version() != RC_ABI_VERSION:
+        raise RacecarHipError(f"ABI version mismatch: {path} reports {lib.rc_abi_version()}, this binding expects "
+                              f"{RC_ABI_VERSION} - rebuild with `python -m racing_dreamer_amd.build --force`")
     _lib = lib
     return lib
 

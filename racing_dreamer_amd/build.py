@@ -28,12 +28,40 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (looked on PATH and in /opt/rocm/bin)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+BUILD_ID_MARK = b"RC_BUILD_ID="
+
+
+def source_hash(csrc: str = CSRC, flags=None) -> str:
+    """sha256 over the flags and the CONTENT of every source and header the library is made of (in a fixed order, each
+    preceded by its name): the identity of a build.  It is compiled into the library (`-DRC_BUILD_ID`, `rc_build_id()`),
+    so whether a library on disk belongs to the sources beside it is a question about contents, not about file times - a
+    tree pushed with a stale `.so` that happens to be newer than its sources is rebuilt."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update("\0".join(FLAGS if flags is None else flags).encode())
+    for name in SOURCES + HEADERS:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(b"\0" + os.path.basename(name).encode() + b"\0" + f.read())
+    return h.hexdigest()[:32]
+
+
+def library_build_id(path: str = LIB_PATH):
+    """The build id a library file carries (the string behind `rc_build_id()`), read from the file's bytes - no dlopen, so
+    asking does not load a stale library into the process.  None if the file is missing or carries none."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return None
+    at = blob.find(BUILD_ID_MARK)
+    if at < 0:
+        return None
+    tail = blob[at + len(BUILD_ID_MARK):at + len(BUILD_ID_MARK) + 32]
+    return tail.decode("ascii", "replace") if len(tail) == 32 and all(c in b"0123456789abcdef" for c in tail) else None
+
+
+def needs_build(lib_path: str = LIB_PATH, csrc: str = CSRC) -> bool:
+    return library_build_id(lib_path) != source_hash(csrc)
 
 
 # Kernels that hand a register to an asynchronous load through inline assembly and wait for it in a LATER assembly
@@ -130,14 +158,14 @@ def check_async_load_registers(asm_text: str, kernels=("rc_raycast_car_kernel", 
     return checked
 
 
-def verify_scan_assembly(verbose: bool = True) -> int:
+def verify_scan_assembly(verbose: bool = True, csrc: str = CSRC) -> int:
     """Compile the kernels to assembly once more (device only) and run check_async_load_registers on it."""
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "kernels.s")
         flags = [f for f in FLAGS if f not in ("-fPIC", "-shared")]
-        cmd = [find_hipcc(), *flags, "-S", "--cuda-device-only", os.path.join(CSRC, SOURCES[0]), "-o", out]
-        r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+        cmd = [find_hipcc(), *flags, "-S", "--cuda-device-only", os.path.join(csrc, SOURCES[0]), "-o", out]
+        r = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-4000:])
             raise subprocess.CalledProcessError(r.returncode, cmd)
@@ -148,15 +176,25 @@ def verify_scan_assembly(verbose: bool = True) -> int:
     return n
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB_PATH
-    os.makedirs(LIB_DIR, exist_ok=True)
-    tmp = LIB_PATH + ".new"
-    cmd = [find_hipcc(), *FLAGS, "-Rpass-analysis=kernel-resource-usage", *[os.path.join(CSRC, s) for s in SOURCES], "-o", tmp]
+LAST_BUILD = {"action": None, "build_id": None}      # what the last build() call did: "compiled" | "reused"
+
+
+def build(force: bool = False, verbose: bool = True, csrc: str = CSRC, lib_path: str = LIB_PATH) -> str:
+    """Compile `csrc` into `lib_path` unless the library there already carries the hash of those sources and the flags
+    (`LAST_BUILD["action"]` says which happened).  The defaults are the package's own tree; the tests build copies."""
+    want = source_hash(csrc)
+    LAST_BUILD.update(action="reused", build_id=want)
+    if not force and library_build_id(lib_path) == want:
+        if verbose:
+            print(f"[racing_dreamer_amd.build] reused {lib_path}: its build id {want} is the hash of the sources and flags", flush=True)
+        return lib_path
+    os.makedirs(os.path.dirname(lib_path), exist_ok=True)
+    tmp = lib_path + ".new"
+    cmd = [find_hipcc(), *FLAGS, f'-DRC_BUILD_ID="{want}"', "-Rpass-analysis=kernel-resource-usage",
+           *[os.path.join(csrc, s) for s in SOURCES], "-o", tmp]
     if verbose:
         print("[racing_dreamer_amd.build]", " ".join(cmd), flush=True)
-    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    r = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True)
     other = [l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not l.startswith(("      |", " ")) and "hip-link" not in l]
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-8000:])
@@ -165,12 +203,17 @@ def build(force: bool = False, verbose: bool = True) -> str:
         print("\n".join(other), file=sys.stderr)
     try:
         check_resource_usage(r.stderr)
-        verify_scan_assembly(verbose)
+        verify_scan_assembly(verbose, csrc)
     except RuntimeError:
         os.remove(tmp)
         raise
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, lib_path)
+    LAST_BUILD.update(action="compiled")
+    if library_build_id(lib_path) != want:
+        raise RuntimeError(f"{lib_path} does not carry the build id it was compiled with ({library_build_id(lib_path)} != {want})")
+    if verbose:
+        print(f"[racing_dreamer_amd.build] compiled {lib_path} (build id {want})", flush=True)
+    return lib_path
 
 
 if __name__ == "__main__":

@@ -558,6 +558,14 @@ void rc_spec_tables(float *beams_1080x2, float *footprint_34x2) {
 const char *rc_last_error(void) { return g_last_error.c_str(); }
 int rc_abi_version(void) { return RC_ABI_VERSION; }
 
+// The identity of this build: racing_dreamer_amd/build.py hashes the flags and the contents of every source and header
+// and passes the result as -DRC_BUILD_ID; the marker in front lets the build find the id in the file without loading it.
+#ifndef RC_BUILD_ID
+#define RC_BUILD_ID "unidentified (built without racing_dreamer_amd/build.py)"
+#endif
+extern "C" __attribute__((used)) const char rc_build_id_string[] = "RC_BUILD_ID=" RC_BUILD_ID;
+const char *rc_build_id(void) { return rc_build_id_string + 12; }
+
 void rc_default_config(rc_config *cfg) {
     if (!cfg) return;
     std::memset(cfg, 0, sizeof(*cfg));

@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported_and_bound(hip_lib):
     for name in declared:
         assert hasattr(hip_lib, name), f"{name} declared in racecar_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "ctypes binding and header disagree"
-    assert hip_lib.rc_abi_version() == 1
+    assert hip_lib.rc_abi_version() == _lib.RC_ABI_VERSION == 2
 
 
 def test_config_struct_matches_header(hip_lib):
@@ -158,3 +158,36 @@ _ZN12_GLOBAL__N_121rc_raycast_car_kernelILi1ELb0ELb0EEEv8RcParamsi:
     # the same instructions in another kernel are nobody's business
     other = ok.replace("rc_raycast_car_kernel", "rc_dynamics_kernel").replace("v_add_f32_e32 v55, 0.5, v55", "v_mov_b32_e32 v51, v49")
     assert build.check_async_load_registers(ok + other) == 1
+
+
+def test_a_changed_source_is_rebuilt_whatever_the_file_times_say(hip_lib, tmp_path):
+    """build.py decides by CONTENT: the library carries the hash of the flags and of every source and header it was made
+    from (`rc_build_id()`).  A copy of the tree whose library is NEWER than its sources is still rebuilt once a comment in a
+    .hip file changes (file times said "up to date" - the round-3 rule), and is reused when nothing changed, however old."""
+    import shutil
+    import time
+    from racing_dreamer_amd import build
+    assert hip_lib.rc_build_id().decode() == build.source_hash() == build.library_build_id()
+    assert not build.needs_build()
+    pkg = tmp_path / "racing_dreamer_amd"
+    shutil.copytree(os.path.join(ROOT, "racing_dreamer_amd", "csrc"), pkg / "csrc")
+    shutil.copytree(os.path.join(ROOT, "include"), tmp_path / "include")
+    lib = pkg / "lib" / "libracecar_hip.so"
+    os.makedirs(lib.parent)
+    shutil.copy(build.LIB_PATH, lib)
+    csrc = str(pkg / "csrc")
+    assert build.source_hash(csrc) == build.source_hash() and not build.needs_build(str(lib), csrc)
+    src = pkg / "csrc" / "racecar_abi.hip"
+    src.write_text(src.read_text() + "\n// a comment: nothing the compiler sees, but not the source this library was built from\n")
+    old = time.time() - 86400
+    os.utime(src, (old, old))                                   # the source now looks a day OLDER than the library
+    assert os.path.getmtime(src) < os.path.getmtime(lib)
+    assert build.needs_build(str(lib), csrc)
+    build.build(verbose=False, csrc=csrc, lib_path=str(lib))
+    assert build.LAST_BUILD["action"] == "compiled"
+    assert build.library_build_id(str(lib)) == build.source_hash(csrc) != build.source_hash()
+    build.build(verbose=False, csrc=csrc, lib_path=str(lib))
+    assert build.LAST_BUILD["action"] == "reused"
+    # a library without an id (or a truncated file) is never taken for current
+    (pkg / "lib" / "junk.so").write_bytes(b"\x7fELF" + b"\0" * 64)
+    assert build.library_build_id(str(pkg / "lib" / "junk.so")) is None and build.needs_build(str(pkg / "lib" / "junk.so"), csrc)
