@@ -9,21 +9,29 @@
 A "step" is one pass of the hot path over one batch: random actions (Philox, on device) ->
 integrator + collision + progress/reward/done + auto-reset -> 1080-beam LiDAR scan, for 65 536 envs
 per GPU (weak scaling), action_repeat 1, so one step = one simulator sub-step (dt = 0.01 s) of every
-env.  For N > 1 every step's trajectory record also goes into the overlapped RCCL all-gather; the
-payload is named in config.workload (`full-u16` by default: the whole record with the LiDAR row as
-uint16 written by the scan - never the LiDAR-less `summary` unless asked for).
-Prints ONE JSON line on rank 0; at N = 1 the line also carries the other single-GPU configurations
-of BASELINE.json (`configs`) and the CPU baseline.
+env.  For N > 1 the headline (`--gather sharded`) is the trajectory store at the granularity
+its consumer reads it: every rank's records go straight into its own device-resident TrajectoryRing,
+every step's 76 B/car summary (pose .. time: the record without the LiDAR row) is all-gathered over
+RCCL, and every 10th step one training batch of 50 windows x 50 steps (dreamer/dream.py:80-83: 100
+batches per 1 000 env steps) is drawn from the rings and all-gathered.  The per-step gathers of whole
+records (`full-u16`, `full`) are timed beside it as secondary legs with their link bound.
+Prints ONE JSON line on rank 0 - whatever happens after the headline leg: every secondary leg runs
+under a deadline and an error guard (LineGuard), and the line is printed with what has been measured
+when one of them fails.  At N = 1 the line also carries the other single-GPU configurations of
+BASELINE.json (`configs`), the scan on the other tracks (`tracks`), the first steps after a reset
+(`fresh_reset`) and the CPU baseline.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import contextlib
 import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,7 +42,12 @@ HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E
 RAYCAST_BYTES_PER_CAR = 4 * 1080 + 16       # lidar row written + (x, y, cos, sin) read, DESIGN.md §5
 STEP_BYTES_PER_CAR = 4 * 1080 + 159         # whole env-step, obs_type=lidar
 PATCH_BYTES_PER_CAR = 4096
-GATHER_MODES = ("full-u16", "full", "summary", "none")
+GATHER_MODES = ("sharded", "full-u16", "full", "summary", "none")
+SIMDS = 1024                     # 256 CUs x 4
+CLOCK_GHZ = 2.4
+VALU_CYCLES_FULL_RATE = 2.35     # issue cost of a full-rate vector instruction with 8 waves per SIMD (tools/ubench/valu_issue4.hip,
+                                 # profiles/r02_c_valu_issue4_ubench.txt); half-rate forms cost 4.3
+BATCH_EVERY, BATCH_WINDOWS, BATCH_LENGTH = 10, 50, 50      # dreamer/dream.py:80-83: batch 50 x 50, 100 train steps per 1 000 env steps
 
 
 def parse_args():
@@ -52,12 +65,17 @@ def parse_args():
                     help="BASELINE.json configs[4]: rank r runs track [columbia, austria, barcelona][r mod 3]")
     ap.add_argument("--obs-type", default="lidar", choices=["lidar", "lidar_occupancy"])
     ap.add_argument("--repeat", type=int, default=1, help="action repeat (sub-steps per step)")
-    ap.add_argument("--gather", default="full-u16", choices=GATHER_MODES,
-                    help="N>1: what the per-step RCCL all-gather carries. full-u16 (default) = the whole transition record "
-                         "with the LiDAR row as uint16 written by the scan's store path (2 236 B/car); full = the fp32 "
-                         "record (4 396 B/car); summary = the record without the LiDAR row (76 B/car, the scans stay "
-                         "sharded in each rank's HBM); none = no collective.  All but `none` are xGMI-bound at this "
-                         "simulation rate: DESIGN.md §6 has the table")
+    ap.add_argument("--gather", default="sharded", choices=GATHER_MODES,
+                    help="N>1: what crosses the links. sharded (default) = records stay in each rank's device-resident "
+                         "TrajectoryRing; per step the 76 B/car summary is all-gathered, every 10th step one training batch "
+                         "of 50 x 50 windows (ShardedReplay; dreamer/dream.py:80-83).  full-u16 = every step's whole "
+                         "transition record with the LiDAR row as uint16 (2 236 B/car); full = the fp32 record "
+                         "(4 396 B/car); summary = the 76 B/car alone; none = no collective.  The per-step gathers of "
+                         "whole records are xGMI-bound by an order of magnitude at this simulation rate: DESIGN.md 6")
+    ap.add_argument("--leg-timeout", type=float, default=150.0,
+                    help="seconds a secondary leg may take before the line is printed with what has been measured and the "
+                         "run ends (rc 0): a leg that hangs - a collective that has never run across devices - must not "
+                         "cost the headline")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N>1: steps per all-gather (each collective carries that many per-step records: same bytes, "
                          "fewer launches; needs staging copies, so 1 - no copy, the collective reads the record in "
@@ -129,14 +147,131 @@ def cpu_baseline(track, cars, obs_type, repeat, n_envs):
     return cb.run(track, cars=cars, occupancy=(obs_type == "lidar_occupancy"), repeat=repeat, n_envs=n_envs)
 
 
+class LineGuard:
+    """Rank 0 prints exactly ONE JSON line, whatever happens after the headline leg.
+
+    `arm(line)` is called once the headline has been measured.  From then on every leg runs inside `with guard.leg(name)`:
+    a deadline is set for it, and a watchdog thread (in every rank) ends the run when the deadline passes or when any rank
+    has reported a failed leg through the job's key-value store: rank 0 prints the line with what has been measured so far
+    plus `aborted: {leg, reason}`, and every rank leaves with exit code 0 - a hung collective cannot be recovered in-process,
+    and a rank that raised has left the others' collective sequence.  SIGTERM (a driver's time-out) prints the line too.
+    Only the headline leg itself, and a failed self-check of the HEADLINE payload, make the run fail.  At N = 1 a failed leg
+    is recorded (`errors`) and the run goes on: there is nobody to fall out of step with."""
+
+    KEY = "rc_bench_abort"
+
+    def __init__(self, rank, world, timeout_s):
+        self.rank, self.world, self.timeout = rank, world, float(timeout_s)
+        self.line, self.store = None, None
+        self.lock = threading.Lock()
+        self.printed = False
+        self.leg_name, self.deadline = None, None
+        self.errors = {}
+        self._stop = False
+        self.armed = False
+
+    def arm(self, line, store=None):
+        self.line, self.store, self.armed = line, store, True
+        threading.Thread(target=self._watch, daemon=True).start()
+        try:
+            signal.signal(signal.SIGTERM, lambda *_: self.finalise("signal", "SIGTERM"))
+        except ValueError:
+            pass
+
+    def _store_reason(self):
+        if self.store is None:
+            return None
+        try:
+            if self.store.check([self.KEY]):
+                return self.store.get(self.KEY).decode(errors="replace")
+        except Exception as exc:                       # the store lives in another process: gone = the job is ending
+            return f"key-value store unreachable ({type(exc).__name__})"
+        return None
+
+    def _watch(self):
+        while not self._stop:
+            time.sleep(0.25)
+            d, name = self.deadline, self.leg_name
+            if d is not None and time.monotonic() > d:
+                self.finalise(name, f"exceeded its deadline of {self.timeout:.0f} s")
+            why = self._store_reason() if self.world > 1 else None
+            if why:
+                time.sleep(0.3)
+                self.finalise(*(why.split("|", 1) if "|" in why else (self.leg_name, why)))
+
+    def finalise(self, leg, reason):
+        with self.lock:
+            if self.rank == 0 and self.line is not None and not self.printed:
+                self.line["aborted"] = {"leg": leg, "reason": reason,
+                                        "note": "the run was ended after the headline leg: everything above was measured; legs that had not run are absent"}
+                if self.errors:
+                    self.line["leg_errors"] = self.errors
+                print(json.dumps(self.line), flush=True)
+                self.printed = True
+            print(f"bench.py: rank {self.rank}: run ended in leg {leg!r}: {reason}", file=sys.stderr, flush=True)
+            sys.stdout.flush()
+            os._exit(0)
+
+    @contextlib.contextmanager
+    def leg(self, name):
+        self.leg_name, self.deadline = name, (time.monotonic() + self.timeout if self.armed else None)
+        hook = os.environ.get("RC_BENCH_FAIL_LEG", "").split(":")          # tests: "<leg>[:<rank>]" raises, "RC_BENCH_HANG_LEG" sleeps
+        hang = os.environ.get("RC_BENCH_HANG_LEG", "").split(":")
+        try:
+            if hook[0] == name and (len(hook) < 2 or int(hook[1]) == self.rank):
+                raise RuntimeError("RC_BENCH_FAIL_LEG")
+            if hang[0] == name and (len(hang) < 2 or int(hang[1]) == self.rank):
+                time.sleep(1e6)
+            yield
+        except Exception as exc:                           # noqa: BLE001 - every failure of a secondary leg is data, not fatal
+            msg = f"{type(exc).__name__}: {exc}"
+            self.errors[name] = msg
+            print(f"bench.py: rank {self.rank}: leg {name!r} failed: {msg}", file=sys.stderr, flush=True)
+            if not self.armed:
+                raise                                      # (not armed: this is the headline itself)
+            if self.world > 1:
+                first = self._store_reason()               # another rank failed first: this exception is its echo (a peer that left)
+                if first and "|" in first:
+                    self.finalise(*first.split("|", 1))
+                try:
+                    if self.store is not None:
+                        self.store.set(self.KEY, f"{name}|rank {self.rank}: {msg}")
+                except Exception:                          # noqa: BLE001
+                    pass
+                time.sleep(2.0)                            # let the others read the reason before this rank's exit breaks their collective
+                self.finalise(name, f"rank {self.rank}: {msg}")
+        finally:
+            self.leg_name, self.deadline = None, None
+
+    def emit(self):
+        with self.lock:
+            self._stop = True
+            self.deadline = None
+            if self.rank == 0 and not self.printed:
+                if self.errors:
+                    self.line["leg_errors"] = self.errors
+                print(json.dumps(self.line), flush=True)
+                self.printed = True
+
+
+def _checksum(t):
+    """Two sums over a record's 32-bit words (plain, and weighted by position), in wrapping int64."""
+    import torch
+    w = t.contiguous().view(-1).view(torch.uint8)
+    w = w[:w.numel() // 4 * 4].view(torch.int32).to(torch.int64)
+    pos = torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 65521 + 1
+    return [int(w.sum().item()), int((w * pos).sum().item())]
+
+
 class Gatherer:
-    """One gather mode of the N > 1 run: where the record lies, how it is sent, what it costs on the links.
+    """One per-step gather mode of the N > 1 run: where the record lies, how it is sent, what it costs on the links.
 
     With one collective per step (`every == 1`) EVERY payload is read in place from a double-buffered source - the compact
     slab pair for `full-u16` (`rotate_compact`), a pair of output arenas for `full` and `summary` (`rc_set_arena`) - so the
-    step that follows a collective writes the OTHER buffer and the collective never reads a record that is being
-    overwritten (the header of rc_gather_trajectory demands exactly that of its caller).  `every > 1` goes through
-    TrajectoryGather's staging copies."""
+    step that follows a collective writes the OTHER buffer, and the step after that - which rewrites the source - is queued
+    behind the collective's completion (every transport: torch's work.wait(), rc_gather_wait, rc_gather_p2p_wait put the
+    env's stream behind collective k before collective k + 1 is issued).  `every > 1` goes through TrajectoryGather's
+    staging copies."""
 
     def __init__(self, env, mode, every, via, dist_mod):
         import torch
@@ -149,7 +284,7 @@ class Gatherer:
         elif getattr(env, "compact", None) is not None:
             env.disable_compact()               # this leg's scan does not write the uint16 rows, its step does not copy the summary
         self.in_place = every == 1 or via != "torch"
-        self.arenas, self._k, self._sent, self._last_dst = None, 0, 0, None
+        self.arenas, self._k, self._sent, self._dsts = None, 0, 0, []
         if self.in_place and mode in ("full", "summary"):
             second = torch.zeros(env.arena_nbytes + 64, dtype=torch.uint8, device=env.device)
             pad = (-second.data_ptr()) % 64
@@ -182,11 +317,14 @@ class Gatherer:
         if self.via == "abi":
             # the collective before last wrote dst[k]: order this one behind it, then send the record just produced
             env.gather_wait(host_sync=False)
-            self._last_dst = self.dst[self._sent & 1]
-            env.gather(self.mode, self._last_dst)
+            self._dsts = (self._dsts + [self.dst[self._sent & 1]])[-2:]
+            env.gather(self.mode, self._dsts[-1])
             self._sent += 1
         elif self.via == "p2p":
+            if self._sent:
+                env.gather_p2p_wait(host_sync=False)     # THE RULE (racecar_hip.h): the env's stream behind gather k - 1, inbound and outbound
             env.gather_p2p(self.mode)
+            self._sent += 1
         else:
             self.tg.launch(self._source())
         if self.mode == "full-u16":
@@ -195,54 +333,58 @@ class Gatherer:
             self._k ^= 1
             env.set_arena(self.arenas[self._k])
 
+    def step(self, k, repeat=None):
+        self.env.step_random(seed=1, step=k, repeat=repeat)       # actions drawn inside the dynamics kernel (Philox, on device)
+        self.after_step()
+
     def wait(self):
         if self.via == "abi":
             self.env.gather_wait(host_sync=True)
         elif self.via == "p2p":
-            self.env.gather_p2p_wait(host_sync=True)
+            if self._sent:
+                self.env.gather_p2p_wait(host_sync=True)
         else:
             self.tg.wait()
 
-    @staticmethod
-    def _checksum(t):
-        """Two sums over the record's 32-bit words (plain, and weighted by position), in wrapping int64."""
+    def _gathered(self, back):
         import torch
-        w = t.contiguous().view(torch.int32).to(torch.int64)
-        pos = torch.arange(w.numel(), device=w.device, dtype=torch.int64) % 65521 + 1
-        return [int(w.sum().item()), int((w * pos).sum().item())]
+        if self.via == "abi":
+            return self._dsts[-1 - back].view(self.world, -1)
+        if self.via == "p2p":
+            return torch.from_numpy(self.env.gathered_p2p_host(back=back))
+        return self.tg.recent(back)
 
-    def check(self, step, k0, dist_mod):
+    def check(self, k0, dist_mod):
         """Self-check of the collective on whatever hardware this run is on: three steps in the timed loop's own rhythm (each
-        followed by its collective, the next step launched behind it into the other buffer of the pair), one more step to
-        overwrite what a late read would see, then every rank compares EVERY rank's shard of the last gathered record with the
-        checksum that rank took of the record before it was sent.  Returns {"ok", "ranks", ...}; the same on all ranks."""
-        import torch
+        followed by its collective, the next step launched behind it into the other buffer of the pair) and one more step,
+        which REWRITES the source of the second record.  Then every rank compares every rank's shard of the last TWO gathered
+        records with the checksums their senders took before sending: the last one, whose source is still untouched, and
+        the one before it, whose source has been overwritten since - a collective that read its source late shows there.
+        Returns {"ok", "ranks", ...}; the same on all ranks."""
         if not self.in_place:
             return {"ok": None, "skipped": "staged batches (--gather-every > 1)"}
-        mine = None
+        sums = []
         for j in range(3):
-            step(k0 + j)
-            mine = self._checksum(self._source())
+            self.env.step_random(seed=1, step=k0 + j)
+            sums.append(_checksum(self._source()))
             if j == 2 and os.environ.get("RC_BENCH_CORRUPT_GATHER") == str(dist_mod.get_rank()):
                 self._source()[5] ^= 1           # tests: this check must see a single flipped bit in one rank's record
             self.after_step()
-        step(k0 + 3)
+        self.env.step_random(seed=1, step=k0 + 3)
         self.wait()
         self.env.sync()
-        if self.via == "abi":
-            got = self._last_dst.view(self.world, -1)
-        elif self.via == "p2p":
-            got = torch.from_numpy(self.env.gathered_p2p_host())
-        else:
-            got = self.tg.wait()
-        sums = [None] * self.world
-        dist_mod.all_gather_object(sums, mine)
-        bad = [r for r in range(self.world) if self._checksum(got[r]) != sums[r]]
+        all_sums = [None] * self.world
+        dist_mod.all_gather_object(all_sums, sums)
+        bad = []
+        for back, j in ((0, 2), (1, 1)):
+            got = self._gathered(back)
+            bad += [[r, j] for r in range(self.world) if _checksum(got[r][:self.bytes]) != all_sums[r][j]]
         oks = [None] * self.world
         dist_mod.all_gather_object(oks, not bad)
-        out = {"ok": all(oks), "ranks": self.world, "records_in_flight": 3, "bytes_per_rank": self.bytes, "via": self.via}
+        out = {"ok": all(oks), "ranks": self.world, "records_in_flight": 3, "records_verified": 2,
+               "bytes_per_rank": self.bytes, "via": self.via}
         if bad:
-            out["bad_shards_seen_by_this_rank"] = bad
+            out["bad_rank_record_pairs_seen_by_this_rank"] = bad
         return out
 
     def close(self):
@@ -251,6 +393,181 @@ class Gatherer:
         if self.arenas is not None:
             self.env.set_arena(None)
             self._k = 0
+
+
+class ShardedCollector:
+    """The N > 1 headline: the concat of `Collect` -> `save_episodes` -> `load_episodes`
+    (dreamer/wrappers.py:213-219, dreamer/tools.py:235-264) at the granularity its consumer reads it.  Every rank's records
+    go straight into its own `TrajectoryRing` (`rc_set_arena` before each step: no copy); what crosses the links is
+      * every step's 76 B/car summary (pose .. time), `summary_every` steps per collective: each step's summary is copied out
+        of its ring slot into a staging buffer (5 MB) and every `summary_every`-th step ONE all-gather over torch.distributed
+        (nccl = RCCL) carries them - the same bytes per step on the links, a tenth of the launches;
+      * every `batch_every`-th step one training batch, `windows` windows x `length` steps of lidar, action, reward,
+        discount drawn on the device from the ranks' rings (`ShardedReplay.draw`) and all-gathered as ONE packed buffer
+        (`exchange`): the reference's cadence of 100 batches of 50 x 50 per 1 000 env steps (dreamer/dream.py:80-83).
+    Copies and collectives run on a SIDE stream behind one event per step: the env's stream records events and never waits
+    for the links (except before it rewrites a ring slot the side stream has not finished with: `capacity` steps later)."""
+
+    FIELDS = ("lidar", "action", "reward", "discount")
+
+    def __init__(self, env, dist_mod, rank, batch_every=BATCH_EVERY, windows=BATCH_WINDOWS, length=BATCH_LENGTH,
+                 capacity=64, summary_every=1, summary=True):
+        import torch
+        from racing_dreamer_amd.distributed import TrajectoryGather, gather_link_model
+        from racing_dreamer_amd.replay import ShardedReplay, TrajectoryRing
+        self.torch = torch
+        self.env, self.dist, self.mode, self.via = env, dist_mod, "sharded", "torch"
+        self.world = dist_mod.get_world_size()
+        if getattr(env, "compact", None) is not None:
+            env.disable_compact()
+        self.batch_every, self.length, self.capacity = int(batch_every), int(length), int(capacity)
+        self.windows = -(-int(windows) // self.world) * self.world
+        self.ring = TrajectoryRing(env, capacity)
+        self.rep = ShardedReplay(self.ring)
+        self.gen = torch.Generator(device=env.device)
+        self.gen.manual_seed(1234 + rank)
+        self.side = torch.cuda.Stream(device=env.device)
+        self.ev_step = [torch.cuda.Event() for _ in range(capacity)]
+        self.ev_done = [None] * capacity
+        self.ev_batch = torch.cuda.Event()
+        # a training batch is ONE native call into ONE packed buffer (rc_sample_batch) and ONE collective (exchange_packed):
+        # two preallocated buffer pairs take turns, the env's stream waits for the collective of two batches ago before it
+        # draws into that pair again
+        self.layout = env.sample_batch_layout(self.FIELDS, self.windows // self.world, self.length)
+        def aligned(nbytes):
+            raw = torch.empty(nbytes + 64, dtype=torch.uint8, device=env.device)
+            return raw[(-raw.data_ptr()) % 64:][:nbytes]
+        self.batch_src = [aligned(self.layout["total"]) for _ in range(2)]
+        self.batch_dst = [aligned(self.world * self.layout["payload"]) for _ in range(2)]
+        self.batch_done = [None, None]
+        self.off = env.summary_slab.data_ptr() - env._arena_view.data_ptr()
+        self.bytes = int(env.summary_slab.numel()) if summary else 0
+        self.summary_every = int(summary_every)
+        # one collective per step reads the summary IN PLACE from its ring slot (a slot is not rewritten for `capacity` steps,
+        # so several may be in flight); more steps per collective go through staging copies.  A short timed window ends
+        # with the last collective's whole latency in it: the fewer steps it carries, the shorter that tail
+        self.tg = None
+        if summary:
+            self.tg = (TrajectoryGather(env.summary_slab, stage=False, depth=min(8, capacity - 4)) if self.summary_every == 1 else
+                       TrajectoryGather(env.summary_slab, every=self.summary_every, stage=True, depth=2))
+        self.n, self.batches, self.last_batch = 0, 0, None
+        per_car = {"lidar": 4320, "action": 8, "reward": 4, "discount": 4}
+        self.batch_bytes = self.windows // self.world * self.length * sum(per_car[f] for f in self.FIELDS)
+        self.model = gather_link_model(self.bytes + self.batch_bytes // self.batch_every, self.world)
+        self.in_place = True
+        self.includes = (f"records kept in a {capacity}-slot device ring per rank (rc_set_arena, no copy)"
+                         + (f"; every step's 76 B/car summary ({self.bytes} B per rank per step) all-gathered "
+                            + ("in place from its ring slot, one collective per step, several in flight" if self.summary_every == 1 else
+                               f"through staging copies, {self.summary_every} steps per collective") if summary else "; no per-step exchange")
+                         + f"; every {self.batch_every}th step ShardedReplay batch of {self.windows} windows x {self.length} steps "
+                           f"({', '.join(self.FIELDS)}) drawn on the device (rc_sample_windows, rc_gather_rows) and all-gathered as one "
+                           f"packed buffer - {self.batch_bytes} B per rank per batch; copies and collectives on a side stream behind "
+                           f"one event per step, no host read in the loop")
+
+    def _summary(self):
+        return self.ring.slot(self.ring.head)[self.off:self.off + self.bytes]
+
+    def prefill(self, k0):
+        """`length` + 4 untimed records so that windows exist, and one batch to set up its collective."""
+        n = self.length + 4
+        for k in range(n):
+            self.ring.step_random(seed=1, step=k0 + k)
+        self.last_batch = self.rep.sample(self.windows, self.length, fields=self.FIELDS, generator=self.gen)
+        return n
+
+    def _send_summary(self):
+        torch, slot = self.torch, self.ring.head
+        ev = self.ev_step[slot]
+        ev.record(self.env.stream)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.tg.launch(self._summary())
+            done = self.ev_done[slot] or torch.cuda.Event()
+            done.record(self.side)
+            self.ev_done[slot] = done
+
+    def step(self, k, repeat=None):
+        torch = self.torch
+        nxt = (self.ring.head + 1) % self.capacity
+        if self.ev_done[nxt] is not None:                    # the side stream has read what this slot held `capacity` steps ago
+            self.env.stream.wait_event(self.ev_done[nxt])
+        self.ring.step_random(seed=1, step=k, repeat=repeat)
+        if self.tg is not None:
+            self._send_summary()
+        self.n += 1
+        if self.n % self.batch_every == 0:
+            i = self.batches & 1
+            if self.batch_done[i] is not None:
+                self.env.stream.wait_event(self.batch_done[i])
+            buf, _ = self.rep.draw_packed(self.windows, self.length, fields=self.FIELDS, generator=self.gen, out=self.batch_src[i],
+                                          layout=self.layout)                      # env's stream: a memset and two launches
+            self.ev_batch.record(self.env.stream)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ev_batch)
+                self.last_batch = self.rep.exchange_packed(buf, self.layout, out=self.batch_dst[i])     # views [world, windows / world, ...]
+                done = self.batch_done[i] or torch.cuda.Event()
+                done.record(self.side)
+                self.batch_done[i] = done
+            self.batches += 1
+
+    def wait(self):
+        with self.torch.cuda.stream(self.side):
+            if self.tg is not None:
+                self.tg.wait()
+        self.env.stream.wait_stream(self.side)
+
+    def check(self, k0, dist_mod):
+        """Three steps in the loop's own rhythm, each followed by its summary hand-over, and one more; the collective is then
+        flushed and every rank compares every rank's shard of ALL THREE gathered records with the checksums their senders
+        took before sending - and every rank's rows of one gathered training batch with the checksum their owner holds of
+        the same rows."""
+        out = {"ok": True, "ranks": self.world, "via": "torch"}
+        bad = []
+        self.wait()
+        if self.tg is not None:
+            sums = []
+            for j in range(3):
+                self.ring.step_random(seed=1, step=k0 + j)
+                sums.append(_checksum(self._summary()))
+                if j == 2 and os.environ.get("RC_BENCH_CORRUPT_GATHER") == str(dist_mod.get_rank()):
+                    self._summary()[5] ^= 1          # tests: this check must see a single flipped bit in one rank's record
+                self._send_summary()
+            self.ring.step_random(seed=1, step=k0 + 3)
+            self.wait()
+            self.env.sync()
+            all_sums = [None] * self.world
+            dist_mod.all_gather_object(all_sums, sums)
+            if self.summary_every == 1:
+                bad += [[r, 2 - back] for back in range(3) for r in range(self.world)
+                        if _checksum(self.tg.recent(back)[r]) != all_sums[r][2 - back]]
+            else:
+                got = self.tg.recent(0)                      # [world, 3 snapshots, bytes]
+                bad += [[r, j] for r in range(self.world) for j in range(3) if _checksum(got[r, j]) != all_sums[r][j]]
+            out.update(records_in_flight=3, records_verified=3, bytes_per_rank=self.bytes)
+        buf, _ = self.rep.draw_packed(self.windows, self.length, fields=self.FIELDS, generator=self.gen, layout=self.layout)
+        batch = self.rep.exchange_packed(buf, self.layout)
+        self.env.sync()
+        self.torch.cuda.synchronize()
+        me = dist_mod.get_rank()
+        local = self.ring.unpack(buf, self.layout)           # what this rank drew, before it went through the collective
+        mine = {f: _checksum(local[f]) for f in self.FIELDS + ("meta",)}
+        owners = [None] * self.world
+        dist_mod.all_gather_object(owners, mine)
+        bad_rows = [[r, f] for r in range(self.world) for f in self.FIELDS + ("meta",) if _checksum(batch[f][r]) != owners[r][f]]
+        out["batch_windows_without_a_start"] = int(batch["failed"].sum().item())
+        oks = [None] * self.world
+        dist_mod.all_gather_object(oks, not bad and not bad_rows)
+        out.update(ok=all(oks), batch_rows_verified=self.windows, batch_bytes_per_rank=self.batch_bytes)
+        if bad:
+            out["bad_rank_record_pairs_seen_by_this_rank"] = bad
+        if bad_rows:
+            out["bad_batch_rows_seen_by_this_rank"] = bad_rows
+        return out
+
+    def close(self):
+        self.wait()
+        self.env.sync()
+        self.ring.detach()
 
 
 def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="random", settle=150):
@@ -339,6 +656,15 @@ def time_mixed_tracks(names, envs, steps, warmup, settle=150):
                          "step_achieved": step_bytes / (ms * 1e-3) / 1e9, "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
 
+def time_track(track_name, envs, steps, warmup, settle):
+    """The scan on another track at the headline's batch size (SURVEY.md 8d asked for the worst case, VERDICT r3 for the
+    range across tracks): ms per step, the scan's launch-attached time and its fraction of the HBM roofline."""
+    c = time_config(f"{envs} envs, {track_name}, 1080-beam lidar", track_name, envs, 1, "lidar", steps, warmup, settle=settle)
+    return {"track": track_name, "envs": envs, "ms_per_step": c["ms_per_step"], "env_steps_per_s": c["env_steps_per_s"],
+            "raycast_ms": c["kernels_ms"].get("rc_raycast_kernel"), "raycast_frac": c["roofline"].get("raycast_frac"),
+            "dynamics_ms": c["kernels_ms"].get("rc_dynamics_kernel")}
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -356,6 +682,7 @@ def main():
     dev = local_rank % max(torch.cuda.device_count(), 1)      # ranks > GPUs only in --backend gloo functional tests
     torch.cuda.set_device(dev)
     comm_ranks = None
+    store = None
     if distributed:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
@@ -365,6 +692,11 @@ def main():
         one = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(one)
         comm_ranks = int(one.item())
+        try:
+            store = dist.distributed_c10d._get_default_store()
+        except Exception:                                      # noqa: BLE001 - without it a failed leg is still caught by the deadline
+            store = None
+    guard = LineGuard(rank, world if distributed else 1, args.leg_timeout)
 
     from racing_dreamer_amd import _lib as L
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
@@ -382,8 +714,26 @@ def main():
         name, _, val = kv.partition("=")
         env.debug_set(name, int(val))
     env.reset(mode="random", seed=0)
-    # the synthetic data is a random-action rollout that HAS SETTLED: right after a reset every car stands on the centre line
-    # looking along the track (longer rays, a scan 5 % slower than in the spread of poses a long run is made of)
+    # the first steps after a reset, timed on their own (N = 1): what `--settle 0` would put into the timed window
+    fresh = None
+    if not distributed and not args.no_configs:
+        n_fresh = 20
+        env.reset_kernel_times()
+        env.set_profiling(True, kernels=[L.K_RAYCAST])
+        env.sync()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n_fresh):
+            env.step_random(seed=3, step=k)
+        env.sync()
+        torch.cuda.synchronize()
+        dtf = time.perf_counter() - t0
+        env.set_profiling(False)
+        fresh = {"steps": n_fresh, "ms_per_step": dtf / n_fresh * 1e3, "env_steps_per_s": shard.num_envs * n_fresh / dtf,
+                 "raycast_ms": round(env.kernel_times()["rc_raycast_kernel"]["avg_ms"], 4),
+                 "note": "the first 20 steps after reset(mode='random'), no settling, host-timed with the scan's launch timers on"}
+        env.reset(mode="random", seed=0)
+    # the synthetic data is a random-action rollout that HAS SETTLED
     for k in range(args.settle):
         env.step_random(seed=2, step=k)
     env.sync()
@@ -409,9 +759,27 @@ def main():
         env.p2p_teardown()
         env._p2p_mode = None
 
-    def make_gatherer(mode):
+    class Plain:
+        """No collective: the simulation alone."""
+        mode, via, bytes, in_place = "none", None, 0, True
+        includes = "no collective, no uint16 rows, no summary copy: the simulation alone"
+
+        def step(self, k, repeat=None):
+            env.step_random(seed=1, step=k, repeat=repeat)
+
+        def wait(self):
+            pass
+
+        def close(self):
+            pass
+
+    def make_collector(mode):
         if mode == "none":
-            return None
+            if getattr(env, "compact", None) is not None:
+                env.disable_compact()
+            return Plain()
+        if mode == "sharded":
+            return ShardedCollector(env, dist, rank)
         if via == "p2p":                        # buffers and mappings are made once; later legs only switch the payload
             first = getattr(env, "_p2p_mode", None) is None
             blob = env.p2p_setup(mode, rank, world)
@@ -421,16 +789,9 @@ def main():
                 env.p2p_connect(blobs)
         return Gatherer(env, mode, every, via, dist)
 
-    gather = make_gatherer(gather_mode)
-
     # the rollout loop works on the env's own stream (no cross-stream event waits between the step's kernels and
     # the collective's dependency on them); `barrier()` synchronises the whole device
     torch.cuda.set_stream(env.stream)
-
-    def one_step(k, repeat=None, g=None):
-        env.step_random(seed=1, step=k, repeat=repeat)        # actions drawn inside the dynamics kernel (Philox, on device)
-        if g is not None:
-            g.after_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -439,277 +800,289 @@ def main():
         torch.cuda.synchronize()
 
     def finish(g):
-        if g is not None:
-            g.wait()
+        g.wait()
         env.sync()
 
+    def max_over_ranks(seconds):
+        if not distributed:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(g, k0, n, repeat=None):
+        """n steps of collector g between barriers; seconds = MAX over ranks."""
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(n):
+            g.step(k0 + k, repeat=repeat)
+        t1 = time.perf_counter()
+        finish(g)
+        t2 = time.perf_counter()
+        barrier()
+        t3 = time.perf_counter()
+        if os.environ.get("RC_BENCH_TRACE_TIMED"):           # where a timed region's wall time goes (analysis; tools/fixed_cost.sh)
+            print(f"bench.py: rank {rank}: timed[{getattr(g, 'mode', '?')}, {n} steps] enqueue {(t1 - t0) * 1e3:.3f} ms, "
+                  f"drain {(t2 - t1) * 1e3:.3f} ms, closing barrier {(t3 - t2) * 1e3:.3f} ms", file=sys.stderr, flush=True)
+        return max_over_ranks(t3 - t0)
+
+    # ------------------------------------------------------------------ the headline leg (a failure here fails the run)
+    step_no = 0
+    gather = make_collector(gather_mode)
+    if gather_mode == "sharded":
+        step_no += gather.prefill(step_no)
     for k in range(args.warmup):
-        one_step(k, g=gather)
+        gather.step(step_no + k)
+    step_no += args.warmup
     finish(gather)
     env.reset_kernel_times()
     # start / stop timestamps attached to every launch of the DOMINANT kernel (the scan) on the stream it runs on;
     # timing the two small kernels as well would cost the timed region 6 us per step, so they get a pass of their
     # own after it
     env.set_profiling(True, kernels=[L.K_RAYCAST])
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        one_step(args.warmup + k, g=gather)
-    finish(gather)
-    barrier()
-    dt = time.perf_counter() - t0
+    dt = timed(gather, step_no, args.steps)
+    step_no += args.steps
     env.set_profiling(False)
     ktimes = env.kernel_times()
     scan_symbol = env.scan_kernel_name()
     # the other kernels of the step: a short untimed pass with all timers on
     env.reset_kernel_times()
     env.set_profiling(True, kernels=[L.K_PATCH, L.K_DYNAMICS])
-    for k in range(min(args.steps, 50)):
-        one_step(args.warmup + args.steps + k, g=gather)
+    n_pass = min(args.steps, 50)
+    for k in range(n_pass):
+        gather.step(step_no + k)
+    step_no += n_pass
     finish(gather)
     env.set_profiling(False)
     for name, v in env.kernel_times().items():
         if name != "rc_raycast_kernel":
             ktimes[name] = v
-    step_no = args.warmup + 2 * args.steps
-
-    # secondary figure: the reference's own setting, action_repeat 4 with the scan once per agent step
-    # (dreamer/dream.py:55) - a quarter of the steps, same barriers, same payload as the headline
-    r4_steps = max(args.steps // 4, 5)
-    barrier()
-    t1 = time.perf_counter()
-    for k in range(r4_steps):
-        one_step(step_no + k, repeat=4, g=gather)
-    finish(gather)
-    barrier()
-    dt4 = time.perf_counter() - t1
-    step_no += r4_steps
-    headline_bytes = gather.bytes if gather is not None else 0
-    headline_in_place = gather.in_place if gather is not None else True
-    gather_checks = {}
-    if gather is not None:
-        if not args.no_gather_check:
-            gather_checks[gather_mode] = gather.check(lambda k: env.step_random(seed=1, step=k), step_no, dist)
-            step_no += 4
-        gather.close()
-
-    # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
-    # sequence): what the headline's choice of payload costs, measured rather than argued.  Each leg sets the env up for
-    # its own payload only (`includes` says what its step carried); `none` is the pure simulation rate.
-    mode_legs, leg_includes = {}, {}
-    if distributed and not args.no_gather_modes:
-        n_leg = max(args.steps // 4, 5)
-        for m in GATHER_MODES:
-            if m == gather_mode:
-                continue
-            if m == "none" and getattr(env, "compact", None) is not None:
-                env.disable_compact()
-            g = make_gatherer(m)
-            leg_includes[m] = g.includes if g is not None else "no collective, no uint16 rows, no summary copy: the simulation alone"
-            for k in range(3):
-                one_step(step_no + k, g=g)
-            finish(g)
-            barrier()
-            t1 = time.perf_counter()
-            for k in range(n_leg):
-                one_step(step_no + 3 + k, g=g)
-            finish(g)
-            barrier()
-            mode_legs[m] = [time.perf_counter() - t1, n_leg]
-            step_no += 3 + n_leg
-            if g is not None:
-                if not args.no_gather_check:
-                    gather_checks[m] = g.check(lambda k: env.step_random(seed=1, step=k), step_no, dist)
-                    step_no += 4
-                g.close()
-    if getattr(env, "_p2p_mode", None) is not None:
-        p2p_close()
-
-    # N > 1: the payload DESIGN.md 6 recommends instead of per-step records - every rank keeps its records in a
-    # device-resident ring and what crosses the links is the TRAINING BATCH: ShardedReplay.sample(50 windows x 50 steps)
-    # once per step (far more often than a learner asks for one)
-    batch_leg = None
-    if distributed and not args.no_gather_modes:
-        from racing_dreamer_amd.replay import ShardedReplay, TrajectoryRing
-        if getattr(env, "compact", None) is not None:
-            env.disable_compact()
-        length, cap = 50, 64
-        batch = -(-50 // world) * world
-        ring = TrajectoryRing(env, cap)
-        for k in range(length + 4):                   # fill: a window needs `length` records
-            ring.step_random(seed=1, step=step_no + k)
-        step_no += length + 4
-        rep = ShardedReplay(ring)
-        gen = torch.Generator(device=env.device)
-        gen.manual_seed(1234 + rank)
-        fields = ("lidar", "action", "reward", "discount")
-        for k in range(3):                            # warm-up: the sampler's kernels, the collectives' first use per dtype and size
-            ring.step_random(seed=1, step=step_no + k)
-            out = rep.sample(batch, length, fields=fields, generator=gen)
-        step_no += 3
-        batch_bytes = sum(int(out[f].numel() * out[f].element_size()) for f in fields) // world
-        n_leg = max(args.steps // 4, 5)
-        env.sync()
-        barrier()
-        t1 = time.perf_counter()
-        for k in range(n_leg):
-            ring.step_random(seed=1, step=step_no + k)
-            rep.sample(batch, length, fields=fields, generator=gen)
-        env.sync()
-        barrier()
-        batch_leg = [time.perf_counter() - t1, n_leg, batch_bytes, batch, length]
-        step_no += n_leg
-        ring.detach()
-        del rep, ring
-
-    # secondary figure: cars driven along the track at speed by the reference's follow-the-gap law (its other prefill
-    # policy, dreamer/dream.py:211-216) instead of crawling under random actions: rank 0 only, single-GPU runs only
-    ftg = None
-    if world == 1 and not args.no_cpu_baseline_ftg:
-        mean_range_random = float(env.views["lidar"].float().mean().item())
-        env.reset(mode="random", seed=0)
-        for k in range(150):                      # let the cars settle on the racing line
-            env.follow_the_gap_reference()
-            env.step(None)
-        env.sync()
-        env.reset_kernel_times()
-        env.set_profiling(True, kernels=[L.K_RAYCAST, L.K_FTG])
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        n_ftg = max(args.steps // 4, 5)
-        for k in range(n_ftg):
-            env.follow_the_gap_reference()
-            env.step(None)
-        env.sync()
-        torch.cuda.synchronize()
-        dtf = time.perf_counter() - t2
-        env.set_profiling(False)
-        kt = env.kernel_times()
-        ftg = {"env_steps_per_s": args.envs * n_ftg * args.repeat / dtf, "steps": n_ftg,
-               "raycast_ms": round(kt["rc_raycast_kernel"]["avg_ms"], 4),
-               "agent_kernel_ms": round(kt["rc_ftg_kernel"]["avg_ms"], 4),
-               "mean_range_m": float(env.views["lidar"].float().mean().item()),
-               "mean_speed_m_s": float(env.views["speed"].float().mean().item()),
-               "mean_range_m_random_actions": mean_range_random,
-               "note": "same envs driven by rc_follow_the_gap_reference - the law of the reference's own follow-the-gap node "
-                       "(ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent - after 150 settling steps "
-                       "(cars at 4 m/s instead of crawling under random actions); includes the agent's kernel"}
-
-    if distributed:
-        times = [dt, dt4] + [v[0] for v in mode_legs.values()] + ([batch_leg[0]] if batch_leg else [])
-        tmax = torch.tensor(times, dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        times = [float(v) for v in tmax.tolist()]
-        dt, dt4 = times[0], times[1]
-        for (m, v), t in zip(mode_legs.items(), times[2:]):
-            v[0] = t
-        if batch_leg:
-            batch_leg[0] = times[-1]
 
     total_envs = args.envs * world
-    env_steps = total_envs * args.steps * args.repeat
-    value = env_steps / dt
+    value = total_envs * args.steps * args.repeat / dt
     n_cars = shard.num_envs * args.cars
-    out = None
-    if rank == 0:
-        ray = ktimes["rc_raycast_kernel"]
-        ray_s = ray["avg_ms"] * 1e-3
-        achieved = RAYCAST_BYTES_PER_CAR * n_cars / ray_s / 1e9 if ray_s > 0 else 0.0
-        # HBM traffic and instruction counts of the scan are PMC figures: they cannot be collected inside this run (the
-        # counters need rocprofv3 passes of their own), so they are quoted from the committed profile of the SAME
-        # workload (track, batch, obs_type, default scan) and are null for any other - `traffic_source` says which file
-        traffic = valu = traffic_source = None
-        tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        key = f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}"
-        if os.path.exists(tp) and args.raycast_variant is None and not args.debug_knob and scan_symbol.endswith("false, false>"):
-            with open(tp) as f:
-                prof = json.load(f)
-            traffic = prof.get(key)
-            valu = prof.get("_valu_wave_insts", {}).get(key)
-            if traffic is not None:
-                traffic_source = prof.get("_source", "profiles/hbm_traffic.json") + " (builder-run rocprofv3 --pmc passes of this workload; not measured in this run)"
-        if not distributed:
-            gather_txt = "no collective (one rank)"
-        elif gather_mode == "none":
-            gather_txt = "NO trajectory gather (--gather none)"
-        else:
-            how = {"torch": "RCCL all-gather through torch.distributed", "abi": "RCCL all-gather through rc_gather_trajectory",
-                   "p2p": "direct peer copies through rc_gather_trajectory_p2p (hipIpc, one copy stream per peer)"}[via]
-            gather_txt = (f"every step's trajectory record gathered on every rank as `{gather_mode}` ({headline_bytes} B per GPU "
-                          f"per step, {'read in place from a double-buffered source' if headline_in_place else 'from staging copies'}, "
-                          f"one gather per {every} step{'s' if every > 1 else ''}, {how}, overlapped with the "
-                          f"following step; the gathered buffer is overwritten two gathers later - no consumer in this benchmark)")
-        out = {
-            "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
-            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32",
-            "data": f"synthetic (random-action rollout, {args.settle} untimed settling steps after reset, then the warm-up)",
-            "config": {
-                "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
-                            f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
-                            f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
-                            f"auto-reset, action_repeat {args.repeat}; {gather_txt}",
-                "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
-                "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
-                "obs_type": args.obs_type, "action_repeat": args.repeat, "settle_steps": args.settle,
-                "parallelism": f"env-sharded x{world}", "gather": gather_mode, "gather_via": via if distributed else None,
-                # the size of the job as the communicator reports it (sum over ranks of 1 through the backend's own
-                # all-reduce; ncclCommCount of the C-ABI's communicator when that transport is used)
-                "rccl_ranks": comm_ranks if (distributed and args.backend == "nccl") else None,
-                "comm_backend": args.backend if distributed else None, "comm_ranks": comm_ranks, "abi_comm_ranks": abi_ranks,
-            },
-            "roofline": {
-                "bound": "hbm", "kernel": scan_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
-                "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
-                "rays_per_s": n_cars * 1080 / ray_s if ray_s > 0 else 0.0,
-                # what actually bounds the scan: wave-level VALU instructions per launch from the PMC
-                # profile, and the rate they retire at per SIMD (1 024 SIMDs) at the duration measured here
-                "valu_wave_insts_per_launch": valu,
-                "valu_insts_per_simd_per_us": (valu / 1024 / (ray_s * 1e6)) if (valu and ray_s > 0) else None,
-                "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by the instruction stream "
-                        "of the grid traversal, not by HBM (SURVEY.md §8d); the >= 40 % HBM target is NOT met; DESIGN.md §4.2",
-            },
-            "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
-            "action_repeat_4": {"env_steps_per_s": total_envs * r4_steps * 4 / dt4,
-                                "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
-                                "note": "same workload with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55)"},
-        }
+    ray = ktimes["rc_raycast_kernel"]
+    ray_s = ray["avg_ms"] * 1e-3
+    achieved = RAYCAST_BYTES_PER_CAR * n_cars / ray_s / 1e9 if ray_s > 0 else 0.0
+    # HBM traffic and instruction counts of the scan are PMC figures: they cannot be collected inside this run (the
+    # counters need rocprofv3 passes of their own), so they are quoted from the committed profile of the SAME
+    # workload (track, batch, obs_type, default scan) and are null for any other - `traffic_source` says which file
+    traffic = valu = traffic_source = None
+    tp = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    key = f"{track_name}:{shard.num_envs}x{args.cars}:{args.obs_type}"
+    if os.path.exists(tp) and args.raycast_variant is None and not args.debug_knob and scan_symbol.endswith("false, false>"):
+        with open(tp) as f:
+            prof = json.load(f)
+        traffic = prof.get(key)
+        valu = prof.get("_valu_wave_insts", {}).get(key)
+        if traffic is not None:
+            traffic_source = prof.get("_source", "profiles/hbm_traffic.json") + " (builder-run rocprofv3 --pmc passes of this workload; not measured in this run)"
+    if not distributed:
+        gather_txt = "no collective (one rank)"
+    elif gather_mode == "none":
+        gather_txt = "NO trajectory exchange (--gather none)"
+    elif gather_mode == "sharded":
+        gather_txt = ("trajectory store sharded: " + gather.includes + "; the per-step gathers of whole records are the "
+                      "`full-u16` / `full` legs of gather_modes")
+    else:
+        how = {"torch": "RCCL all-gather through torch.distributed", "abi": "RCCL all-gather through rc_gather_trajectory",
+               "p2p": "direct peer copies through rc_gather_trajectory_p2p (hipIpc, one copy stream per peer)"}[via]
+        gather_txt = (f"every step's trajectory record gathered on every rank as `{gather_mode}` ({gather.bytes} B per GPU "
+                      f"per step, {'read in place from a double-buffered source' if gather.in_place else 'from staging copies'}, "
+                      f"one gather per {every} step{'s' if every > 1 else ''}, {how}, overlapped with the "
+                      f"following step; the gathered buffer is overwritten two gathers later - no consumer in this benchmark)")
+    out = {
+        "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
+        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32",
+        "data": f"synthetic (random-action rollout, {args.settle} untimed settling steps after reset, then the warm-up)",
+        "config": {
+            "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
+                        f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
+                        f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
+                        f"auto-reset, action_repeat {args.repeat}; {gather_txt}",
+            "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
+            "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
+            "obs_type": args.obs_type, "action_repeat": args.repeat, "settle_steps": args.settle,
+            "parallelism": f"env-sharded x{world}", "gather": gather_mode,
+            "gather_via": (gather.via if distributed else None), "gather_detail": (gather.includes if distributed else None),
+            # the size of the job as the communicator reports it (sum over ranks of 1 through the backend's own
+            # all-reduce; ncclCommCount of the C-ABI's communicator when that transport is used)
+            "rccl_ranks": comm_ranks if (distributed and args.backend == "nccl") else None,
+            "comm_backend": args.backend if distributed else None, "comm_ranks": comm_ranks, "abi_comm_ranks": abi_ranks,
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": scan_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": RAYCAST_BYTES_PER_CAR * n_cars,
+            "avg_launch_ms": ray["avg_ms"], "launches": ray["launches"],
+            "rays_per_s": n_cars * 1080 / ray_s if ray_s > 0 else 0.0,
+            # what actually bounds the scan (DESIGN.md 4.2): wave-level VALU instructions per launch from the PMC profile
+            # against the issue slots of 1 024 SIMDs over the duration measured here
+            "valu_wave_insts_per_launch": valu,
+            "valu_insts_per_simd_per_us": (valu / SIMDS / (ray_s * 1e6)) if (valu and ray_s > 0) else None,
+            "issue_frac": (valu * VALU_CYCLES_FULL_RATE / (SIMDS * ray_s * CLOCK_GHZ * 1e9)) if (valu and ray_s > 0) else None,
+            "issue_frac_model": f"VALU wave-instructions x {VALU_CYCLES_FULL_RATE} cycles (issue cost of a full-rate instruction, "
+                                f"tools/ubench/valu_issue4.hip; half-rate forms cost 4.3, so this is a lower bound) / ({SIMDS} SIMDs x "
+                                f"kernel cycles at {CLOCK_GHZ} GHz)",
+            "note": "compulsory HBM traffic is ~4.3 KB per car-scan, so the scan is bound by the instruction stream "
+                    "of the grid traversal, not by HBM (SURVEY.md 8d); the >= 40 % HBM target is NOT met; DESIGN.md 4.2",
+        },
+        "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
+    }
+    if fresh is not None:
+        out["fresh_reset"] = fresh
+    if distributed:
+        # cpu_baseline is timed on rank 0 of the N = 1 run only (the driver's contract): the N > 1 line points at it
+        cb = None
+        cbp = os.path.join(ROOT, "profiles", "cpu_baseline_n1.json")
+        if os.path.exists(cbp):
+            with open(cbp) as f:
+                cb = json.load(f)
+        out["cpu_baseline"] = {"measured_in_this_run": False,
+                               "see": "the N = 1 line of this bench (`python bench.py`): the CPU oracle is timed there, on rank 0, "
+                                      "in the same run as the GPU figure; quoted below from the committed N = 1 line",
+                               "quoted": cb}
+    sizes = None
+    if distributed:
+        sizes = {"full": int(env.slab.numel()), "summary": int(env.summary_slab.numel()),
+                 "full-u16": int(env._lib.rc_compact_bytes(env._cfg)), "none": 0}
+        out["gather_modes"] = {gather_mode: dict(getattr(gather, "model", None) or gather_link_model(0, world),
+                                                 ms_per_step=dt / args.steps * 1e3, env_steps_per_s=value, steps=args.steps,
+                                                 headline=True, includes=gather.includes)}
+        if gather_mode == "sharded":
+            out["gather_modes"]["sharded"].update(batches_in_timed_window=gather.batches, batch_every=gather.batch_every,
+                                                  batch_windows=gather.windows, batch_length=gather.length)
+    guard.arm(out if rank == 0 else None, store)
+    if rank == 0 and distributed:
+        print("bench.py headline (the one JSON line on stdout follows at the end of the run): "
+              + json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")} | {"gather": gather_mode}),
+              file=sys.stderr, flush=True)
+
+    # the headline payload's self-check: the only thing after the timed region that can fail the run
+    checks = {}
+    if distributed and gather_mode != "none" and not args.no_gather_check:
+        with guard.leg("headline_check"):        # (an exception or a hang in the check itself ends the run with the line; a MISMATCH fails it)
+            checks[gather_mode] = gather.check(step_no, dist)
+            step_no += 8
+            if rank == 0:
+                out["gather_check"] = dict(ok=checks[gather_mode]["ok"] is not False, payloads=checks)
+    with guard.leg("close_headline"):
+        gather.close()
+        gather = None
+    if checks and checks[gather_mode]["ok"] is False:
+        guard.emit()
+        print(f"bench.py: rank {rank}: a gathered record differs from what its sender sent: {checks}", file=sys.stderr)
         if distributed:
-            # every payload next to its link bound (xGMI full mesh, 7 links x 76.8 GB/s inbound per GPU)
-            sizes = {"full": int(env.slab.numel()), "summary": int(env.summary_slab.numel()),
-                     "full-u16": int(env._lib.rc_compact_bytes(env._cfg)), "none": 0}
-            table = {}
-            for m in GATHER_MODES:
-                e = gather_link_model(sizes[m], world)
-                if m == gather_mode:
-                    e.update(ms_per_step=dt / args.steps * 1e3, env_steps_per_s=value, steps=args.steps, headline=True)
-                elif m in mode_legs:
-                    t, n = mode_legs[m]
-                    e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n,
-                             includes=leg_includes.get(m))
-                table[m] = e
-            if batch_leg:
-                t, n, nbytes, batch, length = batch_leg
-                e = gather_link_model(nbytes, world)
-                e.update(ms_per_step=t / n * 1e3, env_steps_per_s=total_envs * n * args.repeat / t, steps=n,
-                         includes=f"records kept in a {64}-slot device ring per rank (rc_set_arena, no copy); every step "
-                                  f"ShardedReplay.sample({batch} windows x {length} steps: lidar, action, reward, discount) "
-                                  f"all-gathered over torch.distributed - {nbytes} B per rank per sample; windows drawn "
-                                  f"and gathered on the device (rc_sample_windows, rc_gather_rows), one host read of the failure count per sample")
-                table["batch"] = e
-            out["gather_modes"] = table
-        if gather_checks:
-            # every payload's collective checked on THIS hardware: each rank's shard of the last of three in-flight records
-            # equals the checksum its sender took before sending (Gatherer.check)
-            out["gather_check"] = dict(ok=all(c["ok"] is not False for c in gather_checks.values()), payloads=gather_checks)
-        if ftg is not None:
-            out["follow_the_gap"] = ftg
+            dist.barrier()
+        sys.exit(4)
+
+    # ------------------------------------------------------------------ secondary legs, each under the guard
+    # the reference's own setting, action_repeat 4 with the scan once per agent step (dreamer/dream.py:55; SURVEY.md H9)
+    with guard.leg("action_repeat_4"):
+        r4_steps = max(args.steps // 4, 5)
+        g = make_collector("none")
+        dt4 = timed(g, step_no, r4_steps, repeat=4)
+        step_no += r4_steps
+        if rank == 0:
+            out["action_repeat_4"] = {"env_steps_per_s": total_envs * r4_steps * 4 / dt4,
+                                      "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
+                                      "note": "same envs with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55), no exchange"}
+
+    # the headline payload over a window ten times as long: a 20-step window (3 - 5 ms) carries the pipeline's start and
+    # drain and the closing barrier at full weight; this is the steady state next to it
+    if distributed and gather_mode != "none":
+        with guard.leg("steady_state"):
+            n_long = max(10 * args.steps, 200)
+            g = make_collector(gather_mode)
+            if gather_mode == "sharded":
+                step_no += g.prefill(step_no)
+            for k in range(5):
+                g.step(step_no + k)
+            finish(g)
+            t = timed(g, step_no + 5, n_long)
+            step_no += 5 + n_long
+            g.close()
+            if rank == 0:
+                out["gather_modes"][gather_mode]["steady_state"] = {"steps": n_long, "ms_per_step": t / n_long * 1e3,
+                                                                    "env_steps_per_s": total_envs * n_long * args.repeat / t}
+
+    # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
+    # sequence): what the headline's choice costs or saves, measured rather than argued, each next to its link bound
+    # (xGMI full mesh, 7 links x 76.8 GB/s inbound per GPU).  Each leg sets the env up for its own payload only
+    # (`includes` says what its step carried); `none` is the pure simulation rate; `batch` = sharded without the per-step
+    # summary.  Cheapest and most informative first: a leg that fails ends the run with the legs before it in the line.
+    if distributed and not args.no_gather_modes:
+        n_leg = max(args.steps // 4, 5)
+        order = [m for m in ("none", "batch", "sharded", "summary", "full-u16", "full") if m != gather_mode]
+        for m in order:
+            with guard.leg(m):
+                if m == "batch":
+                    g = ShardedCollector(env, dist, rank, summary=False)
+                else:
+                    g = make_collector(m)
+                n_leg = max(args.steps // 4, 5)
+                if m in ("batch", "sharded"):
+                    step_no += g.prefill(step_no)
+                    n_leg = max(n_leg, 2 * g.batch_every)        # (a leg without a batch in it would not be this payload)
+                for k in range(3):
+                    g.step(step_no + k)
+                finish(g)
+                t = timed(g, step_no + 3, n_leg)
+                step_no += 3 + n_leg
+                e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
+                e.update(ms_per_step=t / n_leg * 1e3, env_steps_per_s=total_envs * n_leg * args.repeat / t, steps=n_leg,
+                         includes=g.includes)
+                if m not in ("none",) and not args.no_gather_check:
+                    c = g.check(step_no, dist)
+                    step_no += 8
+                    e["check"] = c
+                    checks[m] = c
+                g.close()
+                if rank == 0:
+                    out["gather_modes"][m] = e
+                    out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
+    if getattr(env, "_p2p_mode", None) is not None:
+        with guard.leg("p2p_close"):
+            p2p_close()
+
+    # secondary figure: cars driven along the track at speed by the reference's follow-the-gap law (its other prefill
+    # policy, dreamer/dream.py:211-216) instead of crawling under random actions: single-GPU runs only
+    if world == 1 and not args.no_cpu_baseline_ftg:
+        with guard.leg("follow_the_gap"):
+            mean_range_random = float(env.views["lidar"].float().mean().item())
+            env.reset(mode="random", seed=0)
+            for k in range(150):                      # let the cars settle on the racing line
+                env.follow_the_gap_reference()
+                env.step(None)
+            env.sync()
+            env.reset_kernel_times()
+            env.set_profiling(True, kernels=[L.K_RAYCAST, L.K_FTG])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            n_ftg = max(args.steps // 4, 5)
+            for k in range(n_ftg):
+                env.follow_the_gap_reference()
+                env.step(None)
+            env.sync()
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t2
+            env.set_profiling(False)
+            kt = env.kernel_times()
+            out["follow_the_gap"] = {
+                "env_steps_per_s": args.envs * n_ftg * args.repeat / dtf, "steps": n_ftg,
+                "raycast_ms": round(kt["rc_raycast_kernel"]["avg_ms"], 4),
+                "agent_kernel_ms": round(kt["rc_ftg_kernel"]["avg_ms"], 4),
+                "mean_range_m": float(env.views["lidar"].float().mean().item()),
+                "mean_speed_m_s": float(env.views["speed"].float().mean().item()),
+                "mean_range_m_random_actions": mean_range_random,
+                "note": "same envs driven by rc_follow_the_gap_reference - the law of the reference's own follow-the-gap node "
+                        "(ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent - after 150 settling steps "
+                        "(cars at 4 m/s instead of crawling under random actions); includes the agent's kernel"}
     env.close()
-    if rank == 0:
-        if world == 1 and not args.no_configs:
+    if rank == 0 and world == 1:
+        if not args.no_configs:
             # BASELINE.json configs[1..3], each a few ms of GPU time (configs[0] is the CPU plumbing case, configs[4]
             # the 8-GPU run: `--gpus 8 --mixed-tracks`)
             cfgs = [("configs[1]: 4 096 envs, columbia, 1080-beam lidar", "columbia", 4096, 1, "lidar", 400, 40, "random"),
@@ -717,21 +1090,33 @@ def main():
                      "lidar_occupancy", 100, 10, "random"),
                     ("configs[3]: 32 768 envs x 2 cars, treitlstrasse_v2, inter-car raycast + collision",
                      "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
-            out["configs"] = [time_config(*c, settle=args.settle) for c in cfgs]
-            out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10, settle=args.settle))
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import cpu_baseline as cb
-            out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
-            out["cpu_baseline"]["single_env"] = cb.run_single_env()      # BASELINE.json configs[0]: the B = 1 CPU step()
-            if not args.no_numpy_baseline:
-                out["cpu_baseline"]["numpy_batch"] = cb.run_numpy_batch(track, n_envs=args.numpy_envs)
-        print(json.dumps(out), flush=True)
+            with guard.leg("configs"):
+                out["configs"] = [time_config(*c, settle=args.settle) for c in cfgs]
+                out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10, settle=args.settle))
+            # the scan across tracks at the headline's batch size: small tables (columbia) to the largest (gbr: 506 MB of
+            # first-trip table) - the range the headline's one track sits in
+            with guard.leg("tracks"):
+                out["tracks"] = [time_track(t, args.envs, 60, 10, args.settle) for t in ("columbia", "barcelona", "gbr") if t != track_name]
+                out["tracks"].insert(0, {"track": track_name, "envs": args.envs, "ms_per_step": out["ms_per_step"],
+                                         "env_steps_per_s": value, "raycast_ms": round(ray["avg_ms"], 4),
+                                         "raycast_frac": achieved / HBM_PEAK_GBS, "headline": True})
+                rm = [t["raycast_ms"] for t in out["tracks"] if t.get("raycast_ms")]
+                out["roofline"]["raycast_ms_range_over_tracks"] = [min(rm), max(rm)]
+                out["roofline"]["frac_range_over_tracks"] = [RAYCAST_BYTES_PER_CAR * args.envs / (max(rm) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                             RAYCAST_BYTES_PER_CAR * args.envs / (min(rm) * 1e-3) / 1e9 / HBM_PEAK_GBS]
+        if not args.no_cpu_baseline:
+            with guard.leg("cpu_baseline"):
+                from oracle import cpu_baseline as cb
+                out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
+                out["cpu_baseline"]["single_env"] = cb.run_single_env()      # BASELINE.json configs[0]: the B = 1 CPU step()
+                if not args.no_numpy_baseline:
+                    out["cpu_baseline"]["numpy_batch"] = cb.run_numpy_batch(track, n_envs=args.numpy_envs)
+    guard.emit()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
-    if any(c["ok"] is False for c in gather_checks.values()):
-        print(f"bench.py: rank {rank}: a gathered record differs from what its sender sent: {gather_checks}", file=sys.stderr)
-        sys.exit(4)
+    if any(c["ok"] is False for c in checks.values()):
+        print(f"bench.py: rank {rank}: a gathered record of a secondary payload differs from what its sender sent: {checks}", file=sys.stderr)
 
 
 if __name__ == "__main__":

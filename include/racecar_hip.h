@@ -278,11 +278,19 @@ int rc_gather_wait(rc_env *env, int32_t host_sync);
  *   rc_gather_trajectory_p2p   sends the last step's record (the source of `mode`, see rc_gather_trajectory; the caller
  *                   double-buffers it the same way) into slot k & 1 of every rank, k = 0, 1, ... counting the calls:
  *                   queued behind the work on the handle's stream, runs on streams of its own;
- *   rc_gather_p2p_wait         orders the handle's stream (host_sync != 0: and the host) behind the arrival of every
- *                   rank's record of the LAST issued gather and returns the slot (*bytes = world x stride): rank r's record
+ *   rc_gather_p2p_wait         orders the handle's stream (host_sync != 0: and the host) behind the COMPLETION of the LAST
+ *                   issued gather - every rank's record has arrived here AND this rank's outbound copies have read their
+ *                   source to the end - and returns the slot (*bytes = world x stride): rank r's record
  *                   - rc_gather_bytes(mode) bytes of it - at r * stride, stride = *bytes / world.  The slot
  *                   stays valid until the call that issues the gather after next; a peer that does not take part within
- *                   RC_P2P_TIMEOUT_S (20 s) makes the host-synchronising wait return RC_ERR_COMM instead of blocking;
+ *                   RC_P2P_TIMEOUT_S (20 s) makes the host-synchronising wait return RC_ERR_COMM instead of blocking
+ *                   (reported once, the counter then starts again; the slots of that gather and the one before are not
+ *                   valid on any rank - tear the transport down and set it up again).
+ *                   THE RULE FOR THE SOURCE: gather k reads the record in place, asynchronously.  Call
+ *                   rc_gather_p2p_wait(env, 0, ...) BEFORE issuing gather k + 1 - the handle's stream then waits for gather k,
+ *                   so the step after next, which rewrites gather k's source in a double-buffered pair, runs behind it.
+ *                   Without that call nothing orders a later step behind the outbound copies (records may be torn);
+ *   rc_p2p_slot     the slot of the last issued gather (back = 0) or of the one before it (back = 1), without waiting;
  *   rc_p2p_disconnect          waits for this rank's copies and unmaps the peers' buffers; rc_p2p_teardown frees this rank's
  *                   own.  Exported memory must not be freed while a peer still maps it: EVERY rank disconnects, the caller
  *                   synchronises the ranks (a barrier of its own), THEN the ranks tear down (rc_destroy tears down too).
@@ -292,6 +300,7 @@ int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *e
 int rc_p2p_connect(rc_env *env, const void *exports_world_x_256, size_t bytes);
 int rc_gather_trajectory_p2p(rc_env *env);
 int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size_t *gathered_bytes);
+int rc_p2p_slot(rc_env *env, int32_t back, void **gathered_dev, size_t *gathered_bytes);
 int rc_p2p_disconnect(rc_env *env);
 int rc_p2p_teardown(rc_env *env);
 
@@ -306,7 +315,8 @@ int rc_set_arena(rc_env *env, void *arena, size_t bytes);
  * episode files: dreamer/tools.py:235-264).  ring_base + k * slot_bytes is arena k of a ring filled through rc_set_arena;
  * output row r takes the record of car car_idx[r] in slot slot_idx[r] (device int32 arrays), for every field of
  * field_mask (bit f = rc_field f): section f of the output holds n_rows records of that field back to back, sections in
- * field order, each starting on a 64-byte boundary (rc_gather_rows_bytes = the total).  Queued on the handle's stream. */
+ * field order, each starting on a 64-byte boundary (rc_gather_rows_bytes = the total).  Queued on the handle's stream.
+ * ring_base and slot_bytes must be multiples of 64 (every slot is an arena as rc_set_arena takes it). */
 size_t rc_gather_rows_bytes(rc_env *env, uint32_t field_mask, int32_t n_rows);
 int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const int32_t *slot_idx_dev, const int32_t *car_idx_dev,
                    int32_t n_rows, uint32_t field_mask, void *out_dev, size_t out_bytes);
@@ -322,6 +332,19 @@ int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const 
 int rc_sample_windows(rc_env *env, const void *ring_base, size_t slot_bytes, int32_t capacity, int32_t oldest, int32_t count,
                       int32_t length, int32_t n_windows, uint64_t seed, uint32_t draw, int32_t max_tries, int32_t *slot_idx_dev,
                       int32_t *slot_obs_idx_dev, int32_t *car_idx_dev, int32_t *meta_dev, uint32_t *failed_dev);
+
+/* One training batch in ONE call and ONE buffer: rc_sample_windows + the row gather of both kinds (observation fields
+ * through slot_obs_idx, the others through slot_idx) + the reference's reset row (first row of a window that starts an episode:
+ * action 0, reward 0, discount 1, time 0, progress_total -1; dreamer/wrappers.py:221-226; reset_rows = 0: records as stored).
+ * Layout of out_dev (64-byte aligned): the sections of field_mask's fields in field order, each n_windows * length records,
+ * each 64-byte aligned; meta int32 [n_windows][4] at *meta_offset; a 64-byte block whose first uint32 counts the windows that
+ * found no episode-internal start.  Those *payload_bytes are what a sharded replay store sends (replay.ShardedReplay:
+ * one collective per batch); the sampler's row indices follow as scratch, rc_sample_batch_bytes = the total to allocate.
+ * A memset and two launches on the handle's stream. */
+size_t rc_sample_batch_bytes(rc_env *env, uint32_t field_mask, int32_t n_windows, int32_t length, size_t *payload_bytes, size_t *meta_offset);
+int rc_sample_batch(rc_env *env, const void *ring_base, size_t slot_bytes, int32_t capacity, int32_t oldest, int32_t count, int32_t length,
+                    int32_t n_windows, uint64_t seed, uint32_t draw, int32_t max_tries, uint32_t field_mask, int32_t reset_rows,
+                    void *out_dev, size_t out_bytes);
 
 int rc_sync(rc_env *env);
 void *rc_stream(rc_env *env);      /* the hipStream_t the handle launches on */

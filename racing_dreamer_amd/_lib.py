@@ -78,6 +78,9 @@ SYMBOLS = {
     "rc_gather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_size_t]),
     "rc_sample_windows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
                                     C.c_uint32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rc_sample_batch_bytes": (C.c_size_t, [C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, _P(C.c_size_t), _P(C.c_size_t)]),
+    "rc_sample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64,
+                                  C.c_uint32, C.c_int32, C.c_uint32, C.c_int32, C.c_void_p, C.c_size_t]),
     "rc_sync": (C.c_int, [C.c_void_p]),
     "rc_stream": (C.c_void_p, [C.c_void_p]),
     "rc_set_profiling": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -93,6 +96,7 @@ SYMBOLS = {
     "rc_p2p_connect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_gather_trajectory_p2p": (C.c_int, [C.c_void_p]),
     "rc_gather_p2p_wait": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
+    "rc_p2p_slot": (C.c_int, [C.c_void_p, C.c_int32, _P(C.c_void_p), _P(C.c_size_t)]),
     "rc_p2p_disconnect": (C.c_int, [C.c_void_p]),
     "rc_p2p_teardown": (C.c_int, [C.c_void_p]),
     "rc_device_alloc": (C.c_int, [C.c_void_p, C.c_size_t, _P(C.c_void_p)]),

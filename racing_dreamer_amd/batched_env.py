@@ -338,9 +338,14 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_gather_p2p_wait(self._h, int(bool(host_sync)), C.byref(ptr), C.byref(nb)))
         return ptr.value, nb.value
 
-    def gathered_p2p_host(self) -> np.ndarray:
-        """Host copy of the last gathered slot as uint8 [world, bytes per rank] (synchronising)."""
+    def gathered_p2p_host(self, back: int = 0) -> np.ndarray:
+        """Host copy of the last gathered slot (back = 1: of the gather before it) as uint8 [world, bytes per rank]
+        (synchronising)."""
         ptr, nb = self.gather_p2p_wait(host_sync=True)
+        if back:
+            p2, n2 = C.c_void_p(), C.c_size_t()
+            L.check(self._lib.rc_p2p_slot(self._h, int(back), C.byref(p2), C.byref(n2)))
+            ptr, nb = p2.value, n2.value
         out = np.empty(nb, np.uint8)
         L.check(self._lib.rc_copy_from_device(self._h, ptr, out.ctypes.data, nb))
         # the slot's entries are sized for the largest payload: the current one fills the head of each
@@ -498,6 +503,43 @@ class BatchedRaceEnv:
                                             int(length), int(n_windows), C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(draw) & 0xffffffff),
                                             int(max_tries), out["slots"].data_ptr(), out["slots_obs"].data_ptr(),
                                             out["cars"].data_ptr(), out["meta"].data_ptr(), out["failed"].data_ptr()))
+        self._exit()
+        return out
+
+    def sample_batch_layout(self, names, n_windows: int, length: int) -> Dict[str, object]:
+        """Layout of the ONE buffer `sample_batch` fills (include/racecar_hip.h, rc_sample_batch): field sections in field
+        order (64-byte aligned), then meta int32 [n_windows, 4], then the 64-byte failure block - `payload` bytes in all, what
+        a sharded store exchanges - then the sampler's row indices; `total` bytes to allocate."""
+        names = [n for n in names if n in _FIELD_VIEWS and n != "action_in" and n in self._host_layout]
+        order = sorted(names, key=lambda n: _FIELD_VIEWS[n][0])
+        mask = 0
+        for n in order:
+            mask |= 1 << _FIELD_VIEWS[n][0]
+        payload, meta_off = C.c_size_t(), C.c_size_t()
+        total = int(self._lib.rc_sample_batch_bytes(self._h, mask, int(n_windows), int(length), C.byref(payload), C.byref(meta_off)))
+        if total == 0:
+            raise ValueError(f"no recorded field among {list(names)}")
+        rows, off, fields = int(n_windows) * int(length), 0, {}
+        for n in order:
+            fid, dtype, tail = _FIELD_VIEWS[n]
+            per = self._host_layout[n][1] // self.n_cars
+            fields[n] = (off, per * rows, dtype, tail)
+            off = (off + per * rows + 63) // 64 * 64
+        assert off == meta_off.value, (off, meta_off.value)
+        return {"mask": mask, "total": total, "payload": int(payload.value), "meta": int(meta_off.value), "failed": int(meta_off.value) +
+                (16 * int(n_windows) + 63) // 64 * 64, "fields": fields, "n_windows": int(n_windows), "length": int(length)}
+
+    def sample_batch(self, ring: torch.Tensor, slot_bytes: int, capacity: int, oldest: int, count: int, layout: Dict[str, object],
+                     seed: int, draw: int, reset_rows: bool = True, max_tries: int = 16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`rc_sample_batch`: one training batch - windows drawn, rows gathered, reset rows written - as one call into one
+        packed uint8 buffer (`sample_batch_layout`); returns the buffer (`out`, or a fresh one)."""
+        if out is None:
+            out = torch.empty(layout["total"] + 64, dtype=torch.uint8, device=self.device)
+            out = out[(-out.data_ptr()) % 64:][:layout["total"]]
+        self._enter()
+        L.check(self._lib.rc_sample_batch(self._h, ring.data_ptr(), int(slot_bytes), int(capacity), int(oldest), int(count), layout["length"],
+                                          layout["n_windows"], C.c_uint64(int(seed) & (2 ** 64 - 1)), C.c_uint32(int(draw) & 0xffffffff),
+                                          int(max_tries), layout["mask"], int(bool(reset_rows)), out.data_ptr(), int(out.numel())))
         self._exit()
         return out
 

@@ -175,6 +175,7 @@ struct P2p {
     std::vector<hipStream_t> push;         // one stream per peer (the local copy runs on push[rank])
     hipStream_t ctrl = nullptr;            // release + wait-for-release kernels; arrival waits
     hipEvent_t ev_ready = nullptr, ev_go = nullptr, ev_arrived = nullptr, ev_local = nullptr;
+    std::vector<hipEvent_t> ev_sent;       // per peer: my copy into its slot and the arrival flag behind it have been executed
     uint32_t issued = 0;           // gathers issued so far
     bool connected = false;
     uint32_t *arrived() const { return flags; }
@@ -222,6 +223,7 @@ struct rc_env {
     float *ftg_prev = nullptr;         // rc_follow_the_gap_reference: previous heading per car (NaN = none), allocated on first use
     void *order_mem = nullptr;         // RcStateDev::order + the sort's bucket counters (batches of RC_ORDER_MIN_CARS cars and more)
     uint32_t order_age = 0;            // observations since the cars were last sorted by track position
+    const float *last_scan_rows = nullptr;   // the LiDAR rows the last scan of this handle wrote (the small batches' cost keys)
     // rc_step_group (this handle as the first of a group): the blocks' RcParams as the last launch saw them, on the device
     // and on the host (pinned staging slots taken in turn, each with the event of its copy)
     RcParams *group_dev = nullptr;
@@ -390,8 +392,14 @@ int sort_cars_if_due(rc_env *env) {
             HIP_TRY(rck_sort_cars(env->params.st.progress, env->n_cars, (uint32_t *)(order + env->n_cars), order, env->stream));
         } else {
             // small batch: every wave slot is taken at once and the rest of the waves follow as slots come free - longest first
+            // (keys from the rows the LAST scan wrote: after rc_set_arena `params.out.lidar` is a slot that was written `capacity`
+            // steps ago, or never; with no scan behind it - the first observation - the cars are taken in index order)
+            if (env->last_scan_rows == nullptr) {
+                env->params.st.order = nullptr;
+                return RC_OK;
+            }
             float *key = (float *)(order + env->n_cars) + RC_ORDER_BUCKETS;
-            HIP_TRY(rck_cost_keys(env->params.out.lidar, env->n_cars, key, env->stream));
+            HIP_TRY(rck_cost_keys(env->last_scan_rows, env->n_cars, key, env->stream));
             HIP_TRY(rck_sort_cars(key, env->n_cars, (uint32_t *)(order + env->n_cars), order, env->stream));
         }
         env->params.st.order = order;
@@ -405,6 +413,7 @@ int observe(rc_env *env) {
     int rc_sort = sort_cars_if_due(env);
     if (rc_sort) return rc_sort;
     TIMED(env, RC_K_RAYCAST, rck_launch_raycast(env->params, env->launch, env->stream));
+    env->last_scan_rows = env->params.out.lidar;
     if (env->params.render_patch)
         TIMED(env, RC_K_PATCH, rck_launch_patch(env->params, env->launch, env->stream));
     if (env->compact_slab)      // the scan has written the uint16 rows; the 76 B/car summary follows them
@@ -1083,6 +1092,7 @@ static int group_step(rc_env **envs, int32_t n, const float *actions_dev, int32_
     }
     g.wave_start[n] = waves;
     TIMED(lead, RC_K_RAYCAST, rck_launch_raycast_group(g, lead->cfg.cars_per_env, split, lead->stream));
+    for (int b = 0; b < n; ++b) envs[b]->last_scan_rows = envs[b]->params.out.lidar;
     for (int b = 0; b < n; ++b)
         if (envs[b]->params.render_patch)
             TIMED(envs[b], RC_K_PATCH, rck_launch_patch(envs[b]->params, envs[b]->launch, envs[b]->stream));
@@ -1197,6 +1207,9 @@ int rc_gather_rows(rc_env *env, const void *ring_base, size_t slot_bytes, const 
     if (!env || !ring_base || !slot_idx_dev || !car_idx_dev || !out_dev) return fail(RC_ERR_INVALID, "NULL argument");
     if (n_rows < 1) return fail(RC_ERR_INVALID, "n_rows must be >= 1");
     if (slot_bytes < env->layout.total) return fail(RC_ERR_INVALID, "slot_bytes %zu is smaller than an arena (%zu)", slot_bytes, env->layout.total);
+    // (the row gather moves 16 bytes per lane: every slot must start as rc_set_arena demands of an arena)
+    if (((uintptr_t)ring_base & 63u) != 0 || (slot_bytes & 63u) != 0)
+        return fail(RC_ERR_INVALID, "ring_base (%p) and slot_bytes (%zu) must be multiples of 64", ring_base, slot_bytes);
     if (env->shared_arena) return fail(RC_ERR_INVALID, "rc_gather_rows works on whole arenas, not on a slice handle");
     size_t src[RC_GATHER_MAX_FIELDS], dst[RC_GATHER_MAX_FIELDS], off = 0;
     uint32_t bpc[RC_GATHER_MAX_FIELDS];
@@ -1220,6 +1233,9 @@ int rc_sample_windows(rc_env *env, const void *ring_base, size_t slot_bytes, int
                       int32_t *slot_obs_idx_dev, int32_t *car_idx_dev, int32_t *meta_dev, uint32_t *failed_dev) {
     if (!env || !ring_base || !slot_idx_dev || !slot_obs_idx_dev || !car_idx_dev || !meta_dev || !failed_dev) return fail(RC_ERR_INVALID, "NULL argument");
     if (slot_bytes < env->layout.total) return fail(RC_ERR_INVALID, "slot_bytes %zu is smaller than an arena (%zu)", slot_bytes, env->layout.total);
+    // (the row gather moves 16 bytes per lane: every slot must start as rc_set_arena demands of an arena)
+    if (((uintptr_t)ring_base & 63u) != 0 || (slot_bytes & 63u) != 0)
+        return fail(RC_ERR_INVALID, "ring_base (%p) and slot_bytes (%zu) must be multiples of 64", ring_base, slot_bytes);
     if (env->shared_arena) return fail(RC_ERR_INVALID, "rc_sample_windows works on whole arenas, not on a slice handle");
     if (capacity < 1 || oldest < 0 || oldest >= capacity || count < 1 || count > capacity) return fail(RC_ERR_INVALID, "ring of %d slots, oldest %d, %d filled", capacity, oldest, count);
     if (length < 1 || length > count) return fail(RC_ERR_INVALID, "a window of %d records does not fit the %d records of the ring", length, count);
@@ -1233,6 +1249,80 @@ int rc_sample_windows(rc_env *env, const void *ring_base, size_t slot_bytes, int
     a.slot_idx = slot_idx_dev; a.slot_obs_idx = slot_obs_idx_dev; a.car_idx = car_idx_dev; a.meta = meta_dev; a.failed = failed_dev;
     HIP_TRY(hipSetDevice(env->cfg.device));
     HIP_TRY(rck_sample_windows(a, env->stream));
+    return RC_OK;
+}
+
+// One training batch as ONE packed buffer: field sections (64-byte aligned, field order), meta, the failure counter - the
+// payload a sharded replay store exchanges - then the sampler's row indices (scratch).
+namespace {
+struct BatchLayout { size_t field_off[RC_F_COUNT]; size_t meta, failed, payload, slot, slot_obs, car, total; };
+bool batch_layout(const rc_env *env, uint32_t field_mask, int32_t n_windows, int32_t length, BatchLayout *bl) {
+    const size_t rows = (size_t)n_windows * (size_t)length;
+    size_t off = 0;
+    for (int f = 0; f < RC_F_COUNT; ++f) {
+        bl->field_off[f] = off;
+        if (!((field_mask >> f) & 1u)) continue;
+        if (f == RC_F_ACTION_IN || !env->layout.bytes[f]) return false;
+        off = align_up(off + kFieldBytes[f] * rows, 64);
+    }
+    bl->meta = off;     off = align_up(off + 16u * (size_t)n_windows, 64);
+    bl->failed = off;   off += 64;
+    bl->payload = off;
+    bl->slot = off;     off = align_up(off + 4u * rows, 64);
+    bl->slot_obs = off; off = align_up(off + 4u * rows, 64);
+    bl->car = off;      off = align_up(off + 4u * rows, 64);
+    bl->total = off;
+    return true;
+}
+}  // namespace
+
+size_t rc_sample_batch_bytes(rc_env *env, uint32_t field_mask, int32_t n_windows, int32_t length, size_t *payload_bytes, size_t *meta_offset) {
+    if (!env || n_windows < 1 || length < 1 || field_mask == 0u) return 0;
+    BatchLayout bl;
+    if (!batch_layout(env, field_mask, n_windows, length, &bl)) return 0;
+    if (payload_bytes) *payload_bytes = bl.payload;
+    if (meta_offset) *meta_offset = bl.meta;
+    return bl.total;
+}
+
+int rc_sample_batch(rc_env *env, const void *ring_base, size_t slot_bytes, int32_t capacity, int32_t oldest, int32_t count, int32_t length,
+                    int32_t n_windows, uint64_t seed, uint32_t draw, int32_t max_tries, uint32_t field_mask, int32_t reset_rows,
+                    void *out_dev, size_t out_bytes) {
+    if (!env || !ring_base || !out_dev) return fail(RC_ERR_INVALID, "NULL argument");
+    if (n_windows < 1 || length < 1) return fail(RC_ERR_INVALID, "n_windows and length must be >= 1");
+    BatchLayout bl;
+    if (field_mask == 0u || !batch_layout(env, field_mask, n_windows, length, &bl))
+        return fail(RC_ERR_INVALID, "field mask 0x%x names no field, or one that is not part of a recorded arena in this configuration", field_mask);
+    if (out_bytes < bl.total) return fail(RC_ERR_INVALID, "output too small: %zu < %zu (rc_sample_batch_bytes)", out_bytes, bl.total);
+    if (((uintptr_t)out_dev & 63u) != 0) return fail(RC_ERR_INVALID, "out_dev must be 64-byte aligned");
+    char *out = (char *)out_dev;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    HIP_TRY(hipMemsetAsync(out + bl.failed, 0, 64, env->stream));
+    int rc = rc_sample_windows(env, ring_base, slot_bytes, capacity, oldest, count, length, n_windows, seed, draw, max_tries,
+                               (int32_t *)(out + bl.slot), (int32_t *)(out + bl.slot_obs), (int32_t *)(out + bl.car),
+                               (int32_t *)(out + bl.meta), (uint32_t *)(out + bl.failed));
+    if (rc) return rc;
+    // the observation part of a record: what a terminal row borrows from the row before it
+    const uint32_t obs_fields = (1u << RC_F_LIDAR) | (1u << RC_F_OCCUPANCY) | (1u << RC_F_POSE) | (1u << RC_F_VELOCITY) | (1u << RC_F_SPEED) |
+                                (1u << RC_F_ACCELERATION) | (1u << RC_F_STEERING_ANGLE);
+    size_t src[RC_GATHER_MAX_FIELDS], dst[RC_GATHER_MAX_FIELDS];
+    uint32_t bpc[RC_GATHER_MAX_FIELDS];
+    RcBatchRows br{};
+    br.slot_obs_idx = (const int32_t *)(out + bl.slot_obs); br.meta = (const int32_t *)(out + bl.meta); br.length = length;
+    int n = 0;
+    for (int f = 0; f < RC_F_COUNT; ++f) {
+        if (!((field_mask >> f) & 1u)) continue;
+        src[n] = env->layout.offset[f]; dst[n] = bl.field_off[f]; bpc[n] = (uint32_t)kFieldBytes[f];
+        if ((obs_fields >> f) & 1u) br.obs_mask |= 1u << n;
+        if (reset_rows && (f == RC_F_ACTION || f == RC_F_REWARD || f == RC_F_DISCOUNT || f == RC_F_TIME || f == RC_F_PROGRESS_TOTAL)) {
+            const float v = f == RC_F_DISCOUNT ? 1.0f : (f == RC_F_PROGRESS_TOTAL ? -1.0f : 0.0f);
+            br.reset_mask |= 1u << n;
+            std::memcpy(&br.reset_word[n], &v, 4);
+        }
+        ++n;
+    }
+    HIP_TRY(rck_gather_rows(ring_base, slot_bytes, (const int32_t *)(out + bl.slot), (const int32_t *)(out + bl.car), n_windows * length,
+                            src, dst, bpc, n, out, env->stream, &br));
     return RC_OK;
 }
 
@@ -1442,6 +1532,7 @@ static void p2p_free(rc_env *env) {
     for (hipStream_t st : x->push) if (st) (void)hipStreamDestroy(st);
     if (x->ctrl) (void)hipStreamDestroy(x->ctrl);
     for (hipEvent_t e : {x->ev_ready, x->ev_go, x->ev_arrived, x->ev_local}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : x->ev_sent) if (e) (void)hipEventDestroy(e);
     if (x->dst) (void)hipFree(x->dst);
     if (x->flags) (void)hipFree(x->flags);
     delete x;
@@ -1475,6 +1566,7 @@ int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *e
     x->peer_dst.assign(world, nullptr);
     x->peer_flags.assign(world, nullptr);
     x->push.assign(world, nullptr);
+    x->ev_sent.assign(world, nullptr);
 #define P2P_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { p2p_free(env); return fail(RC_ERR_HIP, "%s failed: %s (payload %zu B x %d ranks)", #expr, hipGetErrorString(_e), n, world); } } while (0)
     P2P_TRY(hipMalloc((void **)&x->dst, 2 * (size_t)world * x->cap));
     // the flags are written by other GPUs' kernels and polled by this one's: uncached memory, so that a poll sees them
@@ -1483,6 +1575,7 @@ int rc_p2p_setup(rc_env *env, int32_t mode, int32_t rank, int32_t world, void *e
     for (int p = 0; p < world; ++p) P2P_TRY(hipStreamCreateWithFlags(&x->push[p], hipStreamNonBlocking));
     P2P_TRY(hipStreamCreateWithFlags(&x->ctrl, hipStreamNonBlocking));
     for (hipEvent_t *e : {&x->ev_ready, &x->ev_go, &x->ev_arrived, &x->ev_local}) P2P_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    for (int p = 0; p < world; ++p) if (p != rank) P2P_TRY(hipEventCreateWithFlags(&x->ev_sent[p], hipEventDisableTiming));
     P2pExport &ex = x->blob;
     std::memset(&ex, 0, sizeof(ex));
     P2P_TRY(hipIpcGetMemHandle(&ex.dst, x->dst));
@@ -1572,10 +1665,15 @@ int rc_gather_trajectory_p2p(rc_env *env) {
         arrived.n = 1; arrived.value = seq;
         arrived.flag[0] = x->peer_flags[p] + x->rank;
         HIP_TRY(rck_p2p_post(arrived, st));
+        HIP_TRY(hipEventRecord(x->ev_sent[p], st));
     }
     // 4. arrival of every peer's shard in my slot: polled on the control stream, behind the release handshake
     HIP_TRY(rck_p2p_wait(x->arrived(), x->world, x->rank, seq, x->timeouts(), RC_P2P_TIMEOUT_S, x->ctrl));
     HIP_TRY(hipStreamWaitEvent(x->ctrl, x->ev_local, 0));
+    // 5. ... and the DEPARTURE of mine: `ev_arrived` stands for "gather k is complete as far as this rank can tell" - the peers'
+    // shards are here AND my outbound copies have read the source to the end - so that a caller who puts its stream behind it
+    // (rc_gather_p2p_wait, host_sync 0) may let the next step but one rewrite the source, as with rc_gather_trajectory
+    for (int p = 0; p < x->world; ++p) if (p != x->rank) HIP_TRY(hipStreamWaitEvent(x->ctrl, x->ev_sent[p], 0));
     HIP_TRY(hipEventRecord(x->ev_arrived, x->ctrl));
     x->issued = seq;
     return RC_OK;
@@ -1594,9 +1692,26 @@ int rc_gather_p2p_wait(rc_env *env, int32_t host_sync, void **gathered_dev, size
         for (int p = 0; p < x->world; ++p) HIP_TRY(hipStreamSynchronize(x->push[p]));
         uint32_t late = 0;
         HIP_TRY(hipMemcpy(&late, x->timeouts(), sizeof(late), hipMemcpyDeviceToHost));
-        if (late != 0) return fail(RC_ERR_COMM, "peer-copy gather: %u flag wait(s) timed out after %.0f s (a peer did not post)", late, (double)RC_P2P_TIMEOUT_S);
+        if (late != 0) {
+            // reported once: the counter starts again (everything queued has run: the streams were synchronised above).  A
+            // release wait that timed out has let its copies go into slots that were never released: the records of this
+            // and of the previous gather are not to be trusted, on any rank - tear the transport down and set it up again
+            HIP_TRY(hipMemset(x->timeouts(), 0, sizeof(uint32_t)));
+            return fail(RC_ERR_COMM, "peer-copy gather: %u flag wait(s) timed out after %.0f s (a peer did not post); the gathered "
+                        "slots are not valid - rc_p2p_teardown and set up again", late, (double)RC_P2P_TIMEOUT_S);
+        }
     }
     if (gathered_dev) *gathered_dev = x->dst + (size_t)((x->issued - 1u) & 1u) * x->world * x->cap;
+    if (gathered_bytes) *gathered_bytes = (size_t)x->world * x->cap;
+    return RC_OK;
+}
+
+int rc_p2p_slot(rc_env *env, int32_t back, void **gathered_dev, size_t *gathered_bytes) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    P2p *x = env->p2p;
+    if (!x) return fail(RC_ERR_INVALID, "rc_p2p_setup has not been called on this handle");
+    if (back < 0 || back > 1 || x->issued < (uint32_t)back + 1u) return fail(RC_ERR_INVALID, "no gather %d before the last one (issued: %u)", back, x->issued);
+    if (gathered_dev) *gathered_dev = x->dst + (size_t)((x->issued - 1u - (uint32_t)back) & 1u) * x->world * x->cap;
     if (gathered_bytes) *gathered_bytes = (size_t)x->world * x->cap;
     return RC_OK;
 }

@@ -133,8 +133,15 @@ hipError_t rck_sort_cars(const float *progress_dev, int n_cars, uint32_t *counts
 struct RcRandomActions;
 hipError_t rck_launch_dynamics_group(const RcGroup &g, int cars_per_env, int repeat, const RcRandomActions &ra, hipStream_t s);
 hipError_t rck_launch_raycast_group(const RcGroup &g, int cars_per_env, int split, hipStream_t s);
+struct RcBatchRows {             // rc_sample_batch: what turns the row gather into the gather of a whole training batch
+    uint32_t obs_mask, reset_mask;                   // by position in the gather's field table
+    uint32_t reset_word[RC_GATHER_MAX_FIELDS];
+    const int32_t *slot_obs_idx, *meta;
+    int32_t length;
+};
 hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *slot_idx, const int32_t *car_idx, int n_rows,
-                           const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s);
+                           const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s,
+                           const RcBatchRows *batch = nullptr);
 #define RC_P2P_MAX_RANKS 64
 #define RC_P2P_TIMEOUT_S 20.0                   // bound of a flag poll (a peer that never posts: an error, not a hung queue)
 struct RcP2pPost {               // one store per lane: flag[p] = value (null entries skipped)

@@ -2480,18 +2480,33 @@ struct RcGatherRows {
     size_t src_off[RC_GATHER_MAX_FIELDS], dst_off[RC_GATHER_MAX_FIELDS];
     uint32_t bpc[RC_GATHER_MAX_FIELDS];
     int32_t n_fields;
+    // rc_sample_batch (one launch for a whole training batch): fields of `obs_mask` (by position in this table) read
+    // slot_obs_idx instead of slot_idx - a terminal row takes its observation from the record before it - and the first row
+    // of a window that starts an episode (meta[4 w + 3]) gets `reset_word` in the fields of `reset_mask`: the reference's
+    // reset row (action 0, reward 0, discount 1, time 0, progress -1: dreamer/wrappers.py:221-226).  length = 0: plain gather
+    uint32_t obs_mask, reset_mask;
+    uint32_t reset_word[RC_GATHER_MAX_FIELDS];
+    const int32_t *slot_obs_idx, *meta;
+    int32_t length;
 };
 __global__ __launch_bounds__(256) void rc_gather_rows_kernel(const char *__restrict__ ring, size_t slot_bytes, const int32_t *__restrict__ slot_idx,
                                                              const int32_t *__restrict__ car_idx, int n_rows, RcGatherRows g, char *__restrict__ out) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= n_rows) return;
     const unsigned lane = threadIdx.x & 63u;
-    const size_t slot = (size_t)slot_idx[row] * slot_bytes;
+    const size_t slot_plain = (size_t)slot_idx[row] * slot_bytes;
+    const size_t slot_obs = g.length > 0 ? (size_t)g.slot_obs_idx[row] * slot_bytes : slot_plain;
     const size_t car = (size_t)car_idx[row];
+    const bool reset_row = g.length > 0 && g.reset_mask != 0u && row % g.length == 0 && g.meta[4 * (row / g.length) + 3] != 0;
     for (int f = 0; f < g.n_fields; ++f) {
         const uint32_t n = g.bpc[f];
+        const size_t slot = ((g.obs_mask >> f) & 1u) ? slot_obs : slot_plain;
         const char *src = ring + slot + g.src_off[f] + car * n;
         char *dst = out + g.dst_off[f] + (size_t)row * n;
+        if (reset_row && ((g.reset_mask >> f) & 1u)) {          // (reset fields are 4 or 8 bytes of float32)
+            for (uint32_t o = lane * 4u; o < n; o += 64u * 4u) *reinterpret_cast<uint32_t *>(dst + o) = g.reset_word[f];
+            continue;
+        }
         if ((n & 15u) == 0u) {                                   // (sections are 64-byte aligned and n is a multiple of 16: aligned vectors)
             for (uint32_t o = lane * 16u; o < n; o += 64u * 16u) *reinterpret_cast<v4u *>(dst + o) = *reinterpret_cast<const v4u *>(src + o);
         } else if ((n & 3u) == 0u) {
@@ -2503,10 +2518,16 @@ __global__ __launch_bounds__(256) void rc_gather_rows_kernel(const char *__restr
 }
 
 hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *slot_idx, const int32_t *car_idx, int n_rows,
-                           const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s) {
+                           const size_t *src_off, const size_t *dst_off, const uint32_t *bpc, int n_fields, void *out, hipStream_t s,
+                           const RcBatchRows *batch) {
     RcGatherRows g{};
     g.n_fields = n_fields;
     for (int f = 0; f < n_fields; ++f) { g.src_off[f] = src_off[f]; g.dst_off[f] = dst_off[f]; g.bpc[f] = bpc[f]; }
+    if (batch != nullptr) {
+        g.obs_mask = batch->obs_mask; g.reset_mask = batch->reset_mask; g.slot_obs_idx = batch->slot_obs_idx; g.meta = batch->meta;
+        g.length = batch->length;
+        for (int f = 0; f < n_fields; ++f) g.reset_word[f] = batch->reset_word[f];
+    }
     hipLaunchKernelGGL(rc_gather_rows_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, (const char *)ring, slot_bytes, slot_idx, car_idx,
                        n_rows, g, (char *)out);
     return hipGetLastError();
@@ -2515,8 +2536,10 @@ hipError_t rck_gather_rows(const void *ring, size_t slot_bytes, const int32_t *s
 // ---- the order in which the scan takes the cars (RcStateDev::order): a counting sort by progress along the track, RC_ORDER_BUCKETS
 // buckets; within a bucket the order is whatever the atomics give - results do not depend on it, every car is scanned on its own.
 __device__ __forceinline__ int order_bucket(float progress) {
-    int b = (int)(progress * (float)RC_ORDER_BUCKETS);
-    return b < 0 ? 0 : (b > RC_ORDER_BUCKETS - 1 ? RC_ORDER_BUCKETS - 1 : b);
+    // a key that is not a number (rows never written) or out of range lands in an end bucket: the order stays a permutation
+    const float k = progress * (float)RC_ORDER_BUCKETS;
+    if (!(k >= 0.0f)) return 0;
+    return k >= (float)(RC_ORDER_BUCKETS - 1) ? RC_ORDER_BUCKETS - 1 : (int)k;
 }
 __global__ __launch_bounds__(256) void rc_order_count_kernel(const float *__restrict__ progress, int n, uint32_t *__restrict__ counts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

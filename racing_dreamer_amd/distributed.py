@@ -47,22 +47,29 @@ class TrajectoryGather:
     ``every`` snapshots taken since the last one (same bytes on the links, 1 / every of the launches); two staging
     buffers take turns, so a collective has ``every`` steps to finish before its buffer is written again.  With
     ``stage=False`` (``every`` must be 1) the collective reads ``slab`` IN PLACE - no copy - and the caller alternates
-    between two source buffers (`BatchedRaceEnv.rotate_compact`, `TrajectoryRing`): the collective of buffer A is
-    waited for before the one of buffer B is issued, i.e. before the step that writes A again is queued.
-    ``consumer(view)``, if given, receives every completed batch (``[world, slab_bytes]`` for ``every == 1``, else
-    ``[world, n_snapshots, slab_bytes]``) before its buffer is reused: the two ``gathered`` buffers take turns too.
-    ``wait()`` flushes a partial batch, waits, and returns the gathered buffer of the last collective.
+    between source buffers (`BatchedRaceEnv.rotate_compact`, a pair of arenas, `TrajectoryRing`).
+    ``depth`` = collectives allowed in flight: before collective k is issued, the caller's stream is put behind
+    collective k - depth.  With the default 1 collective k - 1 has finished before the step that follows launch(k) starts
+    - what a PAIR of source buffers needs; a source that is not rewritten for ``depth + 1`` steps (a ring slot) may use
+    more, and then a collective that runs late does not stall the steps behind it.  ``depth + 1`` gathered buffers take
+    turns.  ``consumer(view)``, if given, receives every completed batch (``[world, slab_bytes]`` for ``every == 1``, else
+    ``[world, n_snapshots, slab_bytes]``) before its buffer is reused.
+    ``wait()`` flushes a partial batch, waits for everything, and returns the gathered buffer of the last collective;
+    ``recent(back)`` the view of the collective `back` issues ago (0 = last; valid for back <= depth).
     """
 
     def __init__(self, slab_like: torch.Tensor, group: Optional[dist.ProcessGroup] = None, every: int = 1,
-                 stage: bool = True, consumer=None):
+                 stage: bool = True, consumer=None, depth: int = 1):
         if every < 1:
             raise ValueError("every must be >= 1")
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
         if not stage and every != 1:
             raise ValueError("in-place gathers (stage=False) carry one record per collective")
         self.group = group
         self.every = int(every)
         self.stage = bool(stage)
+        self.depth = int(depth)
         self.consumer = consumer
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -70,18 +77,17 @@ class TrajectoryGather:
         self.slab_numel = flat.numel()
         self.staging = [torch.empty(self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
                         for _ in range(2)] if stage else None
-        self.gathered2 = [torch.empty(self.world * self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
-                          for _ in range(2)]
-        self._work = None
+        self.gathered_bufs = [torch.empty(self.world * self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
+                              for _ in range(self.depth + 1)]
+        self._pending = []       # [(work or None, view)] oldest first: issued, not yet waited for
+        self._views = []         # views of the last depth + 1 collectives, newest last
         self._cur = 0            # staging buffer being filled
         self._k = 0              # snapshots in it
         self._g = 0              # gathered buffer the NEXT collective writes
-        self._done_view = None   # view of the batch the pending / last collective produces
-        self._last_n = self.every
 
     @property
     def gathered(self) -> torch.Tensor:
-        return self.gathered2[self._g ^ 1]        # the buffer of the most recently issued collective
+        return self.gathered_bufs[(self._g - 1) % len(self.gathered_bufs)]      # the buffer of the most recently issued collective
 
     def launch(self, slab: torch.Tensor) -> None:
         n = self.slab_numel
@@ -97,29 +103,37 @@ class TrajectoryGather:
             self._k = 0
             self._issue(src, k)
 
-    def _finish(self) -> None:
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
-        if self._done_view is not None and self.consumer is not None:
-            self.consumer(self._done_view)
-        self._done_view = None
+    def _retire(self, keep: int) -> None:
+        """Put the caller's stream behind every pending collective but the newest `keep` (work.wait() is a stream wait for
+        the nccl backend, a host wait for gloo)."""
+        while len(self._pending) > keep:
+            work, view = self._pending.pop(0)
+            if work is not None:
+                work.wait()
+            if self.consumer is not None:
+                self.consumer(view)
 
     def _issue(self, src: torch.Tensor, k: int) -> None:
-        self._finish()                       # the previous collective: its source and the OTHER gathered buffer are free again
+        self._retire(self.depth - 1)         # collective k - depth: its source and its gathered buffer are free again
         n = self.slab_numel
-        dst = self.gathered2[self._g][:self.world * k * n]
-        self._g ^= 1
-        self._last_n = k
-        self._done_view = dst.view(self.world, -1) if self.every == 1 else dst.view(self.world, k, -1)
+        dst = self.gathered_bufs[self._g][:self.world * k * n]
+        self._g = (self._g + 1) % len(self.gathered_bufs)
+        view = dst.view(self.world, -1) if self.every == 1 else dst.view(self.world, k, -1)
+        self._views = (self._views + [view])[-(self.depth + 1):]
         if dist.get_backend(self.group) == "gloo" and src.is_cuda:
             # gloo has no device all-gather: stage through the host (functional tests only)
             host = src.cpu()
             out = torch.empty(self.world * host.numel(), dtype=host.dtype)
             dist.all_gather_into_tensor(out, host, group=self.group)
             dst.copy_(out)
+            self._pending.append((None, view))
             return
-        self._work = dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True)
+        self._pending.append((dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True), view))
+
+    def recent(self, back: int = 0) -> torch.Tensor:
+        if not 0 <= back < len(self._views):
+            raise IndexError(f"only the last {len(self._views)} collectives are kept")
+        return self._views[-1 - back]
 
     def wait(self) -> torch.Tensor:
         if self.stage and self._k:           # a partial batch (every rank holds the same number of snapshots)
@@ -128,12 +142,11 @@ class TrajectoryGather:
             self._cur ^= 1
             self._k = 0
             self._issue(src, k)
-        view = self._done_view
-        self._finish()
-        if view is None:
-            g = self.gathered[:self.world * self._last_n * self.slab_numel]
-            view = g.view(self.world, -1) if self.every == 1 else g.view(self.world, self._last_n, -1)
-        return view
+        self._retire(0)
+        if not self._views:
+            g = self.gathered[:self.world * self.every * self.slab_numel]
+            return g.view(self.world, -1) if self.every == 1 else g.view(self.world, self.every, -1)
+        return self._views[-1]
 
 
 SUMMARY_FIELDS = [("pose", 24, torch.float32, (6,)), ("velocity", 24, torch.float32, (6,)),

@@ -103,9 +103,11 @@ class TrajectoryRing:
         """Number of distinct start times of a `length`-step window inside the filled part of the ring."""
         return max(self.count - length + 1, 0)
 
-    def _sample_native(self, batch, length, names, seed, reset_rows, max_tries, check):
+    def _sample_native(self, batch, length, names, seed, reset_rows, max_tries, check, defer=False):
         """The whole draw on the device: `rc_sample_windows` (a wave per window: draw, test the episode boundary, emit the
-        rows) and two `rc_gather_rows` launches; no host round trip unless `check`."""
+        rows) and two `rc_gather_rows` launches; no host round trip unless `check`.  With `defer` only those three launches
+        are queued (on the env's stream) and the small fix-ups - the reference's reset row, the per-window integers - are
+        left to `finish_sample`, which a caller may run on another stream."""
         env = self.env
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
         self._draws = getattr(self, "_draws", 0) + 1
@@ -120,21 +122,57 @@ class TrajectoryRing:
         if rest:
             rows.update(env.gather_rows(self.buffer, self.slot_bytes, w["slots"], w["cars"], rest))
         out = {n: v.view(batch, length, *v.shape[1:]) for n, v in rows.items()}
-        meta = w["meta"]
-        if reset_rows:                      # the reference's reset row (wrappers.py:221-226), without a mask-indexed write
+        out["_meta"], out["_reset_rows"] = w["meta"], reset_rows
+        return out if defer else self.finish_sample(out)
+
+    def finish_sample(self, out: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The fix-ups of a deferred native draw, queued on torch's current stream (the caller orders it behind the draw)."""
+        out = dict(out)
+        meta, reset_rows = out.pop("_meta"), out.pop("_reset_rows")
+        if reset_rows:                      # the reference's reset row (wrappers.py:221-226): one in-place masked fill per field
             first = meta[:, 3] != 0
             for name, value in (("action", 0.0), ("reward", 0.0), ("discount", 1.0), ("time", 0.0), ("progress_total", -1.0)):
                 if name in out:
                     head = out[name][:, 0]
-                    out[name][:, 0] = torch.where(first.view(-1, *([1] * (head.dim() - 1))), torch.full_like(head, value), head)
+                    head.masked_fill_(first.view(-1, *([1] * (head.dim() - 1))), value)
         car = meta[:, 1].long()
-        out["env"], out["car"] = car // env.cars_per_env, car % env.cars_per_env
+        out["env"], out["car"] = car // self.env.cars_per_env, car % self.env.cars_per_env
         out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+        return out
+
+    def sample_packed(self, batch: int, length: int, fields: Optional[Sequence[str]] = None, generator: Optional[torch.Generator] = None,
+                      reset_rows: bool = True, max_tries: int = 16, out: Optional[torch.Tensor] = None, layout=None):
+        """The same draw as `sample(native=True)` as ONE native call into ONE packed buffer (`rc_sample_batch`: a memset and two
+        launches on the env's stream, no torch kernels, no host read): returns (buffer, layout) - `unpack(buffer, layout)`
+        gives the field views.  The form a sharded store sends: `ShardedReplay.exchange_packed`."""
+        if self.window_starts(length) <= 0:
+            raise ValueError(f"ring holds {self.count} records, a window needs {length}")
+        names = [f for f in (fields or DEFAULT_SAMPLE_FIELDS) if f in self.fields]
+        if layout is None:
+            layout = self.env.sample_batch_layout(names, batch, length)
+        oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
+        self._draws = getattr(self, "_draws", 0) + 1
+        seed = generator.initial_seed() if generator is not None else 0x5eed
+        buf = self.env.sample_batch(self.buffer, self.slot_bytes, self.capacity, oldest, self.count, layout, seed, self._draws,
+                                    reset_rows=reset_rows, max_tries=max_tries, out=out)
+        return buf, layout
+
+    @staticmethod
+    def unpack(buf: torch.Tensor, layout, lead=()) -> Dict[str, torch.Tensor]:
+        """Views of a packed batch (`buf` [..., >= payload] uint8, leading axes `lead`): field -> [*lead, windows, length, ...],
+        `meta` int32 [*lead, windows, 4] = (t0, car, terminal, starts an episode), `failed` int32 [*lead] (windows that found
+        no episode-internal start)."""
+        nw, ln = layout["n_windows"], layout["length"]
+        out = {}
+        for name, (off, nb, dtype, tail) in layout["fields"].items():
+            out[name] = buf[..., off:off + nb].view(dtype).view(*lead, nw, ln, *tail)
+        out["meta"] = buf[..., layout["meta"]:layout["meta"] + 16 * nw].view(torch.int32).view(*lead, nw, 4)
+        out["failed"] = buf[..., layout["failed"]:layout["failed"] + 4].view(torch.int32).reshape(tuple(lead))
         return out
 
     def sample(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
                generator: Optional[torch.Generator] = None, reset_rows: bool = True,
-               max_tries: int = 16, native: Optional[bool] = None, check: bool = True) -> Dict[str, torch.Tensor]:
+               max_tries: int = 16, native: Optional[bool] = None, check: bool = True, defer: bool = False) -> Dict[str, torch.Tensor]:
         """`batch` windows of `length` consecutive records of one car each, uniformly over (time, env, car) among
         the windows that stay inside one episode: no fresh record strictly inside, and a fresh LAST record only if it
         is the terminal transition of the window's episode (done = 1, written by auto-reset).  Returns field ->
@@ -150,7 +188,7 @@ class TrajectoryRing:
             native = hasattr(self.env, "sample_windows") and self.buffer.is_cuda
         if native:                          # (the draw comes from Philox on the device, keyed by the generator's seed and a counter)
             seed = generator.initial_seed() if generator is not None else 0x5eed
-            return self._sample_native(batch, length, names, seed, reset_rows, max_tries, check)
+            return self._sample_native(batch, length, names, seed, reset_rows, max_tries, check, defer)
         dev = self.buffer.device
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
         ar = torch.arange(length, device=dev)
@@ -230,30 +268,103 @@ class ShardedReplay:
         self.ring, self.group, self._dist = ring, group, dist
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
-    def sample(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
-               generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
-        """`batch` windows in total (a multiple of the world size), rank r's `batch / world` at rows
-        [r * batch / world, (r + 1) * batch / world); `env` holds this rank's LOCAL env indices, `rank` the owner."""
+    META = ("env", "car", "t0", "terminal")
+
+    def draw(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
+             generator: Optional[torch.Generator] = None, check: bool = True, defer: bool = False) -> Dict[str, torch.Tensor]:
+        """This rank's `batch / world` windows (the local half of `sample`): queued on the env's stream.  `defer` (device
+        rings): only the sampler's three launches are queued there; `exchange` does the small fix-ups on ITS stream."""
         if batch % self.world:
             raise ValueError(f"batch {batch} is not a multiple of the world size {self.world}")
-        local = self.ring.sample(batch // self.world, length, fields=fields, generator=generator)
-        out = {}
-        host_bounce = self._dist.get_backend(self.group) == "gloo"
-        # the four per-window integers travel as one [windows, 4] tensor: one collective instead of four
-        meta_names = ("env", "car", "t0", "terminal")
-        local["_meta"] = torch.stack([local.pop(n).to(torch.int64) for n in meta_names], 1)
+        return self.ring.sample(batch // self.world, length, fields=fields, generator=generator, check=check, defer=defer)
+
+    def exchange(self, local: Dict[str, torch.Tensor], flat: bool = True) -> Dict[str, torch.Tensor]:
+        """All-gather what `draw` returned: ONE collective over one packed byte buffer (every field and the four per-window
+        integers, each section 16-byte aligned), queued on torch's CURRENT stream - a caller may run it on a stream of its
+        own behind an event, so that the env's stream never waits for the links (bench.py's sharded headline does).
+        flat=True: field -> [batch, ...], rank r's windows at rows [r * batch / world, (r + 1) * batch / world) (one copy
+        per field: the collective's output is rank-major).  flat=False: no copy - field -> a VIEW [world, batch / world, ...]
+        of the gathered buffer, and `meta` int32 [world, batch / world, 4] = (t0, car, terminal, first record of an episode)
+        in place of env / car / t0 / terminal / rank."""
+        if "_meta" in local:                                 # a deferred draw: its fix-ups run here, on the current stream
+            reset_rows, meta = local["_reset_rows"], local["_meta"]
+            local = {k: v for k, v in local.items() if not k.startswith("_")}
+            if reset_rows:
+                first = meta[:, 3] != 0
+                for name, value in (("action", 0.0), ("reward", 0.0), ("discount", 1.0), ("time", 0.0), ("progress_total", -1.0)):
+                    if name in local:
+                        head = local[name][:, 0]
+                        head.masked_fill_(first.view(-1, *([1] * (head.dim() - 1))), value)
+        else:
+            local = dict(local)
+            car = local.pop("car").to(torch.int32) + local.pop("env").to(torch.int32) * self.ring.env.cars_per_env
+            term = local.pop("terminal").to(torch.int32)
+            meta = torch.stack([local.pop("t0").to(torch.int32), car, term, torch.zeros_like(term)], 1)
+        per = int(meta.shape[0])
+        batch = per * self.world
+        local["meta"] = meta
+        names, parts, spans, off = [], [], [], 0
         for name, t in local.items():
-            src = t.contiguous()
-            if host_bounce and src.is_cuda:                  # gloo has no device collectives (functional tests only)
-                src = src.cpu()
-            # (collectives know neither uint16 nor bool on every backend: send their bits)
-            wide = src.view(torch.int16) if src.dtype == torch.uint16 else (src.to(torch.uint8) if src.dtype == torch.bool else src)
-            dst = torch.empty((batch,) + tuple(wide.shape[1:]), dtype=wide.dtype, device=wide.device)
-            self._dist.all_gather_into_tensor(dst, wide, group=self.group)          # rank r's rows at r * batch / world
-            dst = dst.view(torch.uint16) if src.dtype == torch.uint16 else (dst.to(torch.bool) if src.dtype == torch.bool else dst)
-            out[name] = dst.to(t.device)
-        meta = out.pop("_meta")
-        for i, n in enumerate(meta_names):
-            out[n] = meta[:, i] != 0 if n == "terminal" else meta[:, i]
-        out["rank"] = torch.arange(self.world, device=out["env"].device).repeat_interleave(batch // self.world)
+            raw = t.contiguous().view(-1).view(torch.uint8)
+            pad = (-raw.numel()) % 16
+            names.append((name, t.dtype, tuple(t.shape[1:])))
+            spans.append((off, raw.numel()))
+            parts.append(raw)
+            if pad:
+                parts.append(raw.new_zeros(pad))
+            off += raw.numel() + pad
+        flat_src = torch.cat(parts)
+        host_bounce = self._dist.get_backend(self.group) == "gloo" and flat_src.is_cuda
+        src = flat_src.cpu() if host_bounce else flat_src           # gloo has no device collectives (functional tests only)
+        gathered = torch.empty(self.world * off, dtype=torch.uint8, device=src.device)
+        self._dist.all_gather_into_tensor(gathered, src, group=self.group)
+        gathered = gathered.to(flat_src.device).view(self.world, off)
+        out = {}
+        for (name, dtype, tail), (o, n) in zip(names, spans):
+            v = gathered[:, o:o + n].view(dtype).view(self.world, per, *tail)
+            out[name] = v.reshape(batch, *tail) if flat else v
+        if not flat:
+            return out
+        meta = out.pop("meta")
+        car = meta[:, 1].long()
+        out["env"], out["car"] = car // self.ring.env.cars_per_env, car % self.ring.env.cars_per_env
+        out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+        if getattr(self, "_rank_rows", None) is None or self._rank_rows.numel() != batch or self._rank_rows.device != flat_src.device:
+            self._rank_rows = torch.arange(self.world, device=flat_src.device).repeat_interleave(per)
+        out["rank"] = self._rank_rows
         return out
+
+    def draw_packed(self, batch: int, length: int, fields: Optional[Sequence[str]] = None, generator: Optional[torch.Generator] = None,
+                    out: Optional[torch.Tensor] = None, layout=None):
+        """This rank's `batch / world` windows as one packed buffer (`TrajectoryRing.sample_packed`): one native call on the
+        env's stream."""
+        if batch % self.world:
+            raise ValueError(f"batch {batch} is not a multiple of the world size {self.world}")
+        return self.ring.sample_packed(batch // self.world, length, fields=fields, generator=generator, out=out, layout=layout)
+
+    def exchange_packed(self, buf: torch.Tensor, layout, out: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """ONE all-gather of the packed payload on torch's current stream; returns views of the gathered buffer
+        (`TrajectoryRing.unpack` with a leading rank axis): field -> [world, batch / world, length, ...]."""
+        n = layout["payload"]
+        src = buf[:n]
+        host_bounce = self._dist.get_backend(self.group) == "gloo" and src.is_cuda
+        if host_bounce:                                       # gloo has no device collectives (functional tests only)
+            got = torch.empty(self.world * n, dtype=torch.uint8)
+            self._dist.all_gather_into_tensor(got, src.cpu(), group=self.group)
+            if out is None:
+                out = got.to(buf.device)
+            else:
+                out[:self.world * n].copy_(got)
+        else:
+            if out is None:
+                out = torch.empty(self.world * n, dtype=torch.uint8, device=buf.device)
+            self._dist.all_gather_into_tensor(out[:self.world * n], src, group=self.group)
+        return TrajectoryRing.unpack(out[:self.world * n].view(self.world, n), layout, lead=(self.world,))
+
+    def sample(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
+               generator: Optional[torch.Generator] = None, check: bool = True) -> Dict[str, torch.Tensor]:
+        """`batch` windows in total (a multiple of the world size), rank r's `batch / world` at rows
+        [r * batch / world, (r + 1) * batch / world); `env` holds this rank's LOCAL env indices, `rank` the owner.
+        check=False drops the one host read per draw (the count of windows that found no episode-internal start): the
+        whole sample is then queued without the host waiting for the device.  = `exchange(draw(...))`."""
+        return self.exchange(self.draw(batch, length, fields=fields, generator=generator, check=check))

@@ -95,6 +95,18 @@ def _worker(rank, world, port, total_envs, q):
     assert final[:, 0].tolist() == [44 + r for r in range(world)]
     with pytest.raises(ValueError):
         TrajectoryGather(slab, every=2, stage=False)
+    # a deeper pipeline over a ring of sources (the N > 1 headline of bench.py: records stay in the rank's ring, `depth`
+    # collectives may be in flight, the results of the last depth + 1 stay readable)
+    deep = TrajectoryGather(slab, stage=False, depth=3)
+    ring = [slab.clone() for _ in range(5)]
+    for k in range(7):
+        b = ring[k % 5]
+        b[0] = 60 + k + rank
+        deep.launch(b)
+    deep.wait()
+    assert [deep.recent(j)[:, 0].tolist() for j in range(4)] == [[66 - j + r for r in range(world)] for j in range(4)]
+    with pytest.raises(IndexError):
+        deep.recent(4)
     views = [slab_field_views(g[r], sh.num_envs, False) for r in range(world)]
     lidar = torch.cat([v["lidar"] for v in views]).numpy()
     reward = torch.cat([v["reward"] for v in views]).numpy()

@@ -64,6 +64,14 @@ def test_bench_single_gpu_contract():
         r = c["roofline"]
         assert c["ms_per_step"] > 0 and 0 < r["step_frac"] < 1 and 0 < r["raycast_frac"] < 1
         assert r["step_bytes"] == c["envs"] * c["cars_per_env"] * (4479 + (4096 if c["obs_type"] == "lidar_occupancy" else 0))
+    # the scan across tracks at the headline's batch size, and the first steps after a reset
+    assert [t["track"] for t in d["tracks"]] == ["columbia", "barcelona", "gbr"] and d["tracks"][0]["headline"] is True
+    assert all(t["raycast_ms"] > 0 and 0 < t["raycast_frac"] < 1 for t in d["tracks"])
+    lo, hi = rf["raycast_ms_range_over_tracks"]
+    assert lo <= rf["avg_launch_ms"] * 1.01 and hi >= lo and len(rf["frac_range_over_tracks"]) == 2
+    assert d["fresh_reset"]["steps"] == 20 and d["fresh_reset"]["raycast_ms"] > 0
+    assert "issue_frac" in rf and rf["issue_frac"] is None          # (PMC figures only for the profiled workload)
+    assert "leg_errors" not in d and "aborted" not in d
 
 
 def test_bench_starts_its_own_ranks():
@@ -75,11 +83,13 @@ def test_bench_starts_its_own_ranks():
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["config"]["comm_ranks"] == 2
     assert d["config"]["comm_backend"] == "gloo" and d["config"]["rccl_ranks"] is None      # (RCCL needs a GPU per rank)
-    assert set(d["gather_modes"]) == {"full-u16", "full", "summary", "none", "batch"}
-    # every payload's collective checked by the run itself: both ranks' shards of the gathered record against the senders' checksums
+    assert set(d["gather_modes"]) == {"sharded", "full-u16", "full", "summary", "none", "batch"}
+    # every payload's collective checked by the run itself: both ranks' shards of the gathered records against the senders' checksums
     gc = d["gather_check"]
-    assert gc["ok"] is True and set(gc["payloads"]) == {"full-u16", "full", "summary"}
+    assert gc["ok"] is True and set(gc["payloads"]) == {"sharded", "batch", "full-u16", "full", "summary"}
     assert all(c["ok"] is True and c["ranks"] == 2 and c["via"] == "torch" for c in gc["payloads"].values())
+    assert gc["payloads"]["sharded"]["records_verified"] == 3 and gc["payloads"]["full"]["records_verified"] == 2
+    assert "aborted" not in d and "leg_errors" not in d
 
 
 def test_bench_sees_one_flipped_bit_in_a_gathered_record():
@@ -91,8 +101,28 @@ def test_bench_sees_one_flipped_bit_in_a_gathered_record():
                        env=dict(os.environ, RC_BENCH_CORRUPT_GATHER="1"))
     assert r.returncode != 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
-    assert d["gather_check"]["ok"] is False and d["gather_check"]["payloads"]["full-u16"]["ok"] is False
+    assert d["gather_check"]["ok"] is False and d["gather_check"]["payloads"]["sharded"]["ok"] is False
     assert "differs from what its sender sent" in r.stderr
+
+
+def test_a_secondary_leg_that_raises_or_hangs_does_not_cost_the_headline():
+    """VERDICT r3 #1a: the legs after the headline have never run across devices.  One of them raising on one rank (the others
+    are then inside a collective it never joins), or hanging, ends the run with rc 0 and the ONE line: the headline, the legs
+    measured before it, and `aborted` naming the leg."""
+    import os
+    base = [sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--envs", "1024"]
+    r = subprocess.run(base, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, RC_BENCH_FAIL_LEG="summary:1"))
+    assert r.returncode == 0, _errtext(r.stderr)
+    d = _json_line(r.stdout)
+    assert d["value"] > 0 and d["config"]["gather"] == "sharded" and d["gather_check"]["payloads"]["sharded"]["ok"] is True
+    assert d["aborted"]["leg"] == "summary" and "RC_BENCH_FAIL_LEG" in d["aborted"]["reason"]
+    assert {"sharded", "none", "batch"} <= set(d["gather_modes"]) and "full" not in d["gather_modes"]
+    r = subprocess.run(base + ["--leg-timeout", "10"], cwd=ROOT, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, RC_BENCH_HANG_LEG="batch:1"))
+    assert r.returncode == 0, _errtext(r.stderr)
+    d = _json_line(r.stdout)
+    assert d["value"] > 0 and d["aborted"]["leg"] == "batch" and "deadline" in d["aborted"]["reason"]
+    assert "none" in d["gather_modes"] and "summary" not in d["gather_modes"]
 
 
 def test_bench_two_ranks_peer_copy_transport():
@@ -101,12 +131,13 @@ def test_bench_two_ranks_peer_copy_transport():
                         "--warmup", "2", "--envs", "2048"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
-    assert d["config"]["gather_via"] == "p2p" and "rc_gather_trajectory_p2p" in d["config"]["workload"]
+    # (the headline stays the sharded store over torch.distributed; the per-step record gathers go over the peer copies)
+    assert d["config"]["gather"] == "sharded" and d["config"]["gather_via"] == "torch"
     gm = d["gather_modes"]
-    assert all(gm[m]["ms_per_step"] > 0 for m in ("full-u16", "full", "summary", "none", "batch"))
+    assert all(gm[m]["ms_per_step"] > 0 for m in ("sharded", "full-u16", "full", "summary", "none", "batch"))
     gc = d["gather_check"]
-    assert gc["ok"] is True and all(gc["payloads"][m]["ok"] is True and gc["payloads"][m]["via"] == "p2p"
-                                    for m in ("full-u16", "full", "summary"))
+    assert gc["ok"] is True and all(gc["payloads"][m]["ok"] is True and gc["payloads"][m]["via"] == "p2p" and
+                                    gc["payloads"][m]["records_verified"] == 2 for m in ("full-u16", "full", "summary"))
 
 
 def test_bench_two_ranks_functional():
@@ -117,13 +148,18 @@ def test_bench_two_ranks_functional():
     assert r.returncode == 0, _errtext(r.stderr)
     d = _json_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["total_envs"] == 4096 and d["scaling"] == "weak"
-    # the headline of an N > 1 run carries the whole record (uint16 LiDAR), and says so; the other payloads are timed beside it
-    assert d["config"]["gather"] == "full-u16" and "full-u16" in d["config"]["workload"] and "cpu_baseline" not in d
+    # the headline of an N > 1 run is the sharded trajectory store (summary per step + a 50 x 50 batch every 10th step), and
+    # says so; the per-step gathers of whole records are timed beside it; the CPU baseline is a pointer to the N = 1 line
+    assert d["config"]["gather"] == "sharded"
+    assert "sharded" in d["config"]["workload"] and "ShardedReplay" in d["config"]["gather_detail"]
+    assert d["cpu_baseline"]["measured_in_this_run"] is False and "N = 1" in d["cpu_baseline"]["see"]
     gm = d["gather_modes"]
-    assert set(gm) == {"full-u16", "full", "summary", "none", "batch"} and gm["full-u16"]["headline"] is True
+    assert set(gm) == {"sharded", "full-u16", "full", "summary", "none", "batch"} and gm["sharded"]["headline"] is True
+    assert gm["sharded"]["batch_every"] == 10 and gm["sharded"]["batch_windows"] == 50 and gm["sharded"]["batch_length"] == 50
     # the pure-simulation leg really is that: nothing of the uint16 record is produced in it
     assert "simulation alone" in gm["none"]["includes"] and "in place" in gm["full"]["includes"]
-    assert gm["batch"]["bytes_per_gpu_per_step"] == 25 * 50 * (1080 * 4 + 8 + 4 + 4)
+    assert gm["batch"]["bytes_per_gpu_per_step"] == 25 * 50 * (1080 * 4 + 8 + 4 + 4) // 10       # one batch every 10th step
+    assert gm["sharded"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 76 + gm["batch"]["bytes_per_gpu_per_step"], rel=0.05)
     assert gm["full-u16"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 2236, rel=0.01)
     assert gm["full"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 4396, rel=0.01)
     assert gm["summary"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 76, rel=0.05)

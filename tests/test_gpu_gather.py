@@ -345,7 +345,21 @@ def _replay_rank(rank, world, port, q):
             mid = (oldest + t0 + 1) % ring.capacity         # the middle row: never an episode boundary, never rewritten
             ok &= bool(torch.equal(batch["lidar"][mine][j, 1].cpu(), ring.fields["lidar"][mid, e, 0].cpu()))
             ok &= float(batch["time"][mine][j, 1]) == float(ring.fields["time"][mid, e, 0])
-        q.put((rank, ok, {k: v.cpu().numpy() for k, v in batch.items()}))
+        # the same exchange as ONE native draw into ONE packed buffer and ONE collective (what bench.py's sharded headline sends)
+        rep = ShardedReplay(ring)
+        buf, lay = rep.draw_packed(8, 3, fields=("lidar", "reward", "time", "fresh", "done"), generator=g)
+        pk = rep.exchange_packed(buf, lay)
+        torch.cuda.synchronize()
+        ok &= pk["lidar"].shape == (world, 4, 3, 1080) and pk["meta"].shape == (world, 4, 4) and int(pk["failed"].sum()) == 0
+        local = TrajectoryRing.unpack(buf, lay)
+        for n in ("lidar", "reward", "time", "fresh", "done", "meta"):
+            ok &= bool(torch.equal(pk[n][rank], local[n]))
+        for j in range(4):
+            t0, car = int(pk["meta"][rank, j, 0]), int(pk["meta"][rank, j, 1])
+            mid = (oldest + t0 + 1) % ring.capacity
+            ok &= bool(torch.equal(pk["lidar"][rank, j, 1].cpu(), ring.fields["lidar"][mid, car, 0].cpu()))
+        packed_sum = {n: float(pk[n].double().sum()) for n in ("lidar", "reward", "time", "meta")}
+        q.put((rank, ok, {k: v.cpu().numpy() for k, v in batch.items()} | {"_packed_" + n: np.float64(v) for n, v in packed_sum.items()}))
         env.close()
     except Exception as e:          # noqa: BLE001
         q.put((rank, False, repr(e)))

@@ -237,4 +237,24 @@ def test_windows_drawn_on_the_device_are_the_rows_they_say_and_uniform():
     assert bool(ok[a["t0"], a["env"], a["car"]].all())
     with pytest.raises(Exception, match="does not fit"):
         env.sample_windows(ring.buffer, ring.slot_bytes, 16, oldest, 16, 17, 4, 1, 1)
+    # the same draw as ONE native call into ONE packed buffer (rc_sample_batch: the sampler, both kinds of row gather and
+    # the reset rows in a memset and two launches): identical fields, identical meta
+    ring._draws = 100
+    ref = ring.sample(batch, length, fields=fields, generator=g)
+    ring._draws = 100
+    buf, lay = ring.sample_packed(batch, length, fields=fields, generator=g)
+    pk = TrajectoryRing.unpack(buf, lay)
+    torch.cuda.synchronize()
+    assert lay["payload"] < lay["total"] == buf.numel() and int(pk["failed"]) == 0
+    for name in fields:
+        assert torch.equal(pk[name], ref[name]), name
+    assert torch.equal(pk["meta"][:, 0].long(), ref["t0"]) and torch.equal(pk["meta"][:, 1].long(), ref["env"] * 2 + ref["car"])
+    assert torch.equal(pk["meta"][:, 2] != 0, ref["terminal"]) and int((pk["meta"][:, 3] != 0).sum()) > 20
+    raw, _ = ring.sample_packed(64, length, fields=("reward", "discount"), generator=g, reset_rows=False)
+    rawv = TrajectoryRing.unpack(raw, env.sample_batch_layout(("reward", "discount"), 64, length))
+    torch.cuda.synchronize()
+    starts = rawv["meta"][:, 3] != 0
+    assert bool(starts.any()) and bool((rawv["discount"][starts, 0] == 0.0).any())        # records as stored: the previous episode's terminal row
+    with pytest.raises(Exception, match="output too small"):
+        env.sample_batch(ring.buffer, ring.slot_bytes, 16, oldest, 16, lay, 1, 1, out=torch.empty(lay["total"] - 64, dtype=torch.uint8, device="cuda"))
     env.close()
