@@ -50,6 +50,10 @@
 #define PATCH_STEP_Q16 204800.0f   /* 3.125 cells per pixel in 16.16 fixed point */
 #define BALL_GAP 12
 #define GRID_LEAD 8
+#define SPAWN_CLEAR_R 40         /* cells searched around a centre-line point for the nearest non-drivable cell */
+#define SPAWN_MARGIN 0.60f       /* [m] footprint's farthest corner (0.474) + the two half cell diagonals (0.071) */
+#define SPAWN_W_MAX 1.5f
+#define HEADING_JITTER 0.35f
 #define NSTEP_MAX 16
 #define PI_F 3.14159274101257324f
 #define TWO_PI_F 6.28318548202514648f
@@ -64,6 +68,7 @@ typedef struct {
     const float *foot;       /* [34][2]                                     */
     int32_t h, w, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
+    const float *spawn_w;    /* [n] lateral room of a random start at centre-line point i (oc_spawn_width) */
 } oc_track;
 
 typedef struct {
@@ -151,20 +156,86 @@ void oc_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t 
     }
 }
 
+/* Lateral room of a random start (racecar_oracle.py, spawn_width): d2 = squared cell distance from the point's cell to the
+ * nearest cell that is not drivable (outside the grid included) within SPAWN_CLEAR_R cells, (R + 1)^2 if none;
+ * w = clamp(isqrt(d2) * res - SPAWN_MARGIN, 0, SPAWN_W_MAX). */
+void oc_spawn_width(const oc_track *t, float *out) {
+    const int R = SPAWN_CLEAR_R;
+    for (int i = 0; i < t->n_centerline; ++i) {
+        int ix, iy;
+        cell_of(t, t->centerline[4 * i], t->centerline[4 * i + 1], &ix, &iy);
+        int d2 = (R + 1) * (R + 1);
+        if (!inb(t, ix, iy)) d2 = 0;
+        else
+            for (int dy = -R; dy <= R; ++dy)
+                for (int dx = -R; dx <= R; ++dx) {
+                    const int jx = ix + dx, jy = iy + dy;
+                    const int blocked = !inb(t, jx, jy) || !t->drv[(size_t)jy * t->w + jx];
+                    if (blocked && dx * dx + dy * dy < d2) d2 = dx * dx + dy * dy;
+                }
+        int k = 0;
+        while ((k + 1) * (k + 1) <= d2) ++k;
+        out[i] = clampf((float)k * t->res - SPAWN_MARGIN, 0.0f, SPAWN_W_MAX);
+    }
+}
+
+static inline float unit_pm1(uint32_t w) { return ((float)(w >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f; }   /* [-1, 1), exact */
+
+static int obb_overlap_pose(const float *pa, const float *pb) {          /* pose = x, y, theta, sin, cos */
+    const float cta = pa[4], sta = pa[3], ctb = pb[4], stb = pb[3];
+    const float ax = pa[0] + BOX_CX * cta, ay = pa[1] + BOX_CX * sta;
+    const float bx = pb[0] + BOX_CX * ctb, by = pb[1] + BOX_CX * stb;
+    const float dx = bx - ax, dy = by - ay;
+    const float c = fabsf(cta * ctb + sta * stb);
+    const float s = fabsf(sta * ctb - cta * stb);
+    const float ra = BOX_HL + (BOX_HL * c + BOX_HW * s);
+    const float rb = BOX_HW + (BOX_HL * s + BOX_HW * c);
+    int sep = fabsf(dx * cta + dy * sta) > ra;
+    sep |= fabsf(dy * cta - dx * sta) > rb;
+    sep |= fabsf(dx * ctb + dy * stb) > ra;
+    sep |= fabsf(dy * ctb - dx * stb) > rb;
+    return !sep;
+}
+
+/* Reset law (H6; racecar_oracle.py, _reset_envs): bin from word 0; car a at bin idx0 - a * BALL_GAP, moved sideways by
+ * u * spawn_w and turned by v * HEADING_JITTER; if two proposed cars overlap, all cars of the env take the centre-line poses. */
 static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
     const int A = c->cars_per_env, n = t->n_centerline;
-    uint32_t r[4] = {c->first_env + (uint32_t)e, s->episode[e], 0u, 0u};
-    philox4x32(r, c->seed_lo, c->seed_hi);
+    uint32_t r[3][4];
+    for (int k = 0; k < 1 + A / 2; ++k) {
+        r[k][0] = c->first_env + (uint32_t)e; r[k][1] = s->episode[e]; r[k][2] = (uint32_t)k; r[k][3] = 0u;
+        philox4x32(r[k], c->seed_lo, c->seed_hi);
+    }
     s->episode[e] += 1u;
-    const int idx0 = c->reset_mode == 0 ? BALL_GAP * (A - 1) + GRID_LEAD : (int)(((uint64_t)r[0] * (uint64_t)n) >> 32);
+    const int jitter = c->reset_mode != 0;
+    const int idx0 = !jitter ? BALL_GAP * (A - 1) + GRID_LEAD : (int)(((uint64_t)r[0][0] * (uint64_t)n) >> 32);
+    float centre[4][5], prop[4][5];
     for (int a = 0; a < A; ++a) {
-        const int i = e * A + a;
         int idx = (idx0 - a * BALL_GAP) % n;
         if (idx < 0) idx += n;
-        s->x[i] = t->centerline[4 * idx];
-        s->y[i] = t->centerline[4 * idx + 1];
-        s->theta[i] = t->centerline[4 * idx + 2];
-        sincos32(s->theta[i], &s->st[i], &s->ct[i]);
+        float *ce = centre[a], *pr = prop[a];
+        ce[0] = t->centerline[4 * idx]; ce[1] = t->centerline[4 * idx + 1]; ce[2] = t->centerline[4 * idx + 2];
+        sincos32(ce[2], &ce[3], &ce[4]);
+        if (!jitter) { for (int k = 0; k < 5; ++k) pr[k] = ce[k]; continue; }
+        const uint32_t wu = a == 0 ? r[0][1] : r[1 + (a - 1) / 2][2 * ((a - 1) % 2)];
+        const uint32_t wv = a == 0 ? r[0][2] : r[1 + (a - 1) / 2][2 * ((a - 1) % 2) + 1];
+        const float off = unit_pm1(wu) * t->spawn_w[idx];
+        pr[0] = ce[0] - off * ce[3];
+        pr[1] = ce[1] + off * ce[4];
+        float th = ce[2] + unit_pm1(wv) * HEADING_JITTER;
+        th = th > PI_F ? th - TWO_PI_F : th;
+        th = th < -PI_F ? th + TWO_PI_F : th;
+        pr[2] = th;
+        sincos32(th, &pr[3], &pr[4]);
+    }
+    int clash = 0;
+    if (jitter)
+        for (int a = 0; a < A; ++a)
+            for (int b = a + 1; b < A; ++b) clash |= obb_overlap_pose(prop[a], prop[b]);
+    for (int a = 0; a < A; ++a) {
+        const int i = e * A + a;
+        const float *p = clash ? centre[a] : prop[a];
+        s->x[i] = p[0]; s->y[i] = p[1]; s->theta[i] = p[2]; s->st[i] = p[3]; s->ct[i] = p[4];
         float pr = progress_at(t, s->x[i], s->y[i]);
         pr = pr < 0.0f ? 0.0f : pr;
         s->progress[i] = pr;

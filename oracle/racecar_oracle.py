@@ -91,6 +91,12 @@ PATCH_WINDOW_I = 110
 PATCH_STEP_Q16 = f32(204800.0)   # 3.125 cells per pixel in 16.16 fixed point
 BALL_GAP_BINS = 12               # 1.2 m between cars of one env at reset
 GRID_LEAD_BINS = 8               # grid mode: the last car starts 0.8 m after the start line
+# `random` / `random_ball` (dreamer/dream.py:105-108): a pose on the track with clearance, heading along it.
+SPAWN_CLEAR_R = 40               # cells searched around a centre-line point for the nearest non-drivable cell (2 m)
+SPAWN_MARGIN = f32(0.60)         # [m] kept between the rear-axle point and that cell's centre: the footprint's farthest corner
+                                 # (0.474 m) + the two half cell diagonals (0.071 m) the cell-centre distance cannot see
+SPAWN_W_MAX = f32(1.5)           # [m] cap of the lateral offset
+HEADING_JITTER = f32(0.35)       # [rad] the heading is drawn within +- this of the track's direction
 PI = f32(3.14159274101257324)
 TWO_PI = f32(6.28318548202514648)
 INF = f32(np.inf)
@@ -399,6 +405,32 @@ class OracleRaceEnv:
         self.mode = RESET_GRID
 
     # ------------------------------------------------------------------ helpers
+    def spawn_width(self):
+        """float32 [n_centerline]: how far a `random` start may be moved sideways from centre-line point i - exact integer
+        arithmetic: d2 = squared distance in cells from the point's cell to the nearest cell that is not drivable (the grid's
+        outside included) in the window of +- SPAWN_CLEAR_R cells, at most (R + 1)^2; w = clamp(isqrt(d2) * res - SPAWN_MARGIN,
+        0, SPAWN_W_MAX).  The Euclidean distance map is 1-Lipschitz, so a rear-axle point within w of the centre-line point
+        keeps SPAWN_MARGIN to every wall whatever the heading: no start touches a wall."""
+        if getattr(self, "_spawn_w", None) is not None:
+            return self._spawn_w
+        R = SPAWN_CLEAR_R
+        ix, iy = self._cell(self.centerline[:, 0], self.centerline[:, 1])
+        blocked = np.pad(~self.drv, R + 1, constant_values=True)
+        off = np.arange(-R, R + 1)
+        dist2 = (off[:, None] ** 2 + off[None, :] ** 2).astype(np.int64)
+        d2 = np.full(len(ix), (R + 1) ** 2, np.int64)
+        inside = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
+        for k in np.nonzero(inside)[0]:
+            win = blocked[iy[k] + 1:iy[k] + 2 * R + 2, ix[k] + 1:ix[k] + 2 * R + 2]
+            if win.any():
+                d2[k] = min(int(dist2[win].min()), (R + 1) ** 2)
+        d2[~inside] = 0
+        k = np.floor(np.sqrt(d2.astype(np.float64))).astype(np.int64)
+        k = np.where((k + 1) ** 2 <= d2, k + 1, np.where(k * k > d2, k - 1, k))           # exact integer square root
+        w = clamp32(k.astype(f32) * self.res - SPAWN_MARGIN, f32(0.0), SPAWN_W_MAX)
+        self._spawn_w = w.astype(f32)
+        return self._spawn_w
+
     def _cell(self, wx, wy):
         gx = (wx - self.org_x) * self.inv_res
         gy = (wy - self.org_y) * self.inv_res
@@ -419,24 +451,65 @@ class OracleRaceEnv:
         return self.outputs()
 
     def _reset_envs(self, envs):
+        """Reset law (H6).  `grid`: the cars on the centre line behind the start, BALL_GAP_BINS apart.  `random` (one car) and
+        `random_ball` (several): one Philox draw per env picks a centre-line bin uniformly over the lap; car a stands at bin
+        idx0 - a * BALL_GAP_BINS, moved SIDEWAYS by u * w (u uniform in [-1, 1), w = that bin's spawn_width: the clearance the
+        track leaves there) and turned by v * HEADING_JITTER off the track's direction (v uniform in [-1, 1)) - "a random pose
+        on the track with a minimum wall distance, heading along the track" (SURVEY.md H6 and appendix A); the cars of an env
+        lie within a ball of 1.2 (A - 1) m + the track's width around the drawn point ("sample in random points close within
+        a ball", dreamer/dream.py:105-108).  Should two of the proposed cars overlap (rectangle test of H5), ALL cars of that
+        env take the centre-line poses instead (u = v = 0), which never overlap.  Words: Philox(global env id, episode, k, 0):
+        k = 0 -> (bin, u_0, v_0, -), k = 1 -> (u_1, v_1, u_2, v_2), k = 2 -> (u_3, v_3, -, -)."""
         if envs.size == 0:
             return
         cfg, n_cl = self.cfg, len(self.centerline)
         g = (envs + cfg.first_env).astype(np.uint64).astype(u32)
-        r0, _, _, _ = philox4x32(g, self.episode[envs], u32(0), u32(0),
-                                 self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF)
+        k0, k1 = self.seed & 0xFFFFFFFF, (self.seed >> 32) & 0xFFFFFFFF
+        words = [philox4x32(g, self.episode[envs], u32(0), u32(0), k0, k1)]
+        for call in range(1, 1 + (self.A - 1 + 1) // 2):
+            words.append(philox4x32(g, self.episode[envs], u32(call), u32(0), k0, k1))
+        r0 = words[0][0]
         self.episode[envs] += u32(1)
-        if self.mode == RESET_GRID:
+        jitter = self.mode != RESET_GRID
+        if not jitter:
             idx0 = np.full(envs.size, BALL_GAP_BINS * (self.A - 1) + GRID_LEAD_BINS, np.int64)
         else:
             idx0 = ((r0.astype(u64) * u64(n_cl)) >> u64(32)).astype(np.int64)
+        unit = lambda w: (w >> u32(8)).astype(f32) * f32(5.9604644775390625e-8) * f32(2.0) - f32(1.0)     # [-1, 1), exact
+        width = self.spawn_width()
+        centre, proposed = [], []
+        for a in range(self.A):
+            idx = (idx0 - a * BALL_GAP_BINS) % n_cl
+            cx, cy, th = self.centerline[idx, 0], self.centerline[idx, 1], self.centerline[idx, 2]
+            st0, ct0 = sincos32(th)
+            centre.append((cx, cy, th, st0, ct0))
+            if not jitter:
+                proposed.append(centre[-1])
+                continue
+            wu, wv = (words[0][1], words[0][2]) if a == 0 else (words[1 + (a - 1) // 2][2 * ((a - 1) % 2)],
+                                                                words[1 + (a - 1) // 2][2 * ((a - 1) % 2) + 1])
+            off = unit(wu) * width[idx]
+            x = cx - off * st0
+            y = cy + off * ct0
+            th2 = th + unit(wv) * HEADING_JITTER
+            th2 = np.where(th2 > PI, th2 - TWO_PI, th2)
+            th2 = np.where(th2 < -PI, th2 + TWO_PI, th2)
+            st2, ct2 = sincos32(th2)
+            proposed.append((x, y, th2, st2, ct2))
         for a in range(self.A):
             cars = envs * self.A + a
-            idx = (idx0 - a * BALL_GAP_BINS) % n_cl
-            self.x[cars] = self.centerline[idx, 0]
-            self.y[cars] = self.centerline[idx, 1]
-            self.theta[cars] = self.centerline[idx, 2]
-            self.st[cars], self.ct[cars] = sincos32(self.theta[cars])
+            self.x[cars], self.y[cars], self.theta[cars], self.st[cars], self.ct[cars] = proposed[a]
+        if jitter and self.A > 1:
+            clash = np.zeros(envs.size, bool)
+            for a in range(self.A):
+                for b in range(a + 1, self.A):
+                    clash |= self._obb_overlap(envs * self.A + a, envs * self.A + b) != 0
+            for a in range(self.A):
+                cars = (envs * self.A + a)[clash]
+                for arr, val in zip((self.x, self.y, self.theta, self.st, self.ct), centre[a]):
+                    arr[cars] = val[clash]
+        for a in range(self.A):
+            cars = envs * self.A + a
             ix, iy = self._cell(self.x[cars], self.y[cars])
             p = self._lookup(self.progress_grid, ix, iy, f32(-1.0))
             p = np.where(p < f32(0.0), f32(0.0), p)

@@ -109,8 +109,11 @@ __device__ __forceinline__ int obb_overlap(const Car &a, const Car &b) {
 struct Spawn { float x, y, th, ct, st, pr; int cp; };
 
 // The spawn table (RcTrackDev::spawn): per centerline index the pose, sin / cos of its heading (the spec's sincos32),
-// the progress value of its cell and its checkpoint - computed once per track ON THE DEVICE with the very functions a
-// reset would call, so a reset is one 32-byte gather with no arithmetic behind it.
+// the progress value of its cell, its checkpoint and the lateral room a random start has there - computed once per track ON
+// THE DEVICE with the very functions a reset would call, so the centre-line part of a reset is one 32-byte gather with no
+// arithmetic behind it.  Lateral room (oracle: spawn_width): d2 = squared cell distance from the point's cell to the nearest
+// cell that is not drivable (outside the grid included) in the window of +- RCS_SPAWN_CLEAR_R cells, at most (R + 1)^2;
+// w = clamp(isqrt(d2) * res - RCS_SPAWN_MARGIN, 0, RCS_SPAWN_W_MAX) - integers up to the last two operations.
 __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float4 *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= t.n_centerline) return;
@@ -121,25 +124,96 @@ __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float
     pr = pr < 0.0f ? 0.0f : pr;
     int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
     cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
+    int ix, iy;
+    cell_of(t, x, y, ix, iy);
+    const int R = RCS_SPAWN_CLEAR_R;
+    int d2 = (R + 1) * (R + 1);
+    if (!((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)) {
+        d2 = 0;
+    } else {
+        for (int dy = -R; dy <= R; ++dy)
+            for (int dx = -R; dx <= R; ++dx) {
+                const int jx = ix + dx, jy = iy + dy;
+                const bool inside = (unsigned)jx < (unsigned)t.w && (unsigned)jy < (unsigned)t.h;
+                const bool blocked = !inside || bit_at(t.drv_words, t.pitch, jx, jy) == 0;
+                const int q = dx * dx + dy * dy;
+                d2 = (blocked && q < d2) ? q : d2;
+            }
+    }
+    int k = 0;
+    while ((k + 1) * (k + 1) <= d2) ++k;
+    const float w = clampf((float)k * t.res - RCS_SPAWN_MARGIN, 0.0f, RCS_SPAWN_W_MAX);
     out[2 * i] = make_float4(x, y, th, cs);
-    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp), 0.0f);
+    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp), w);
 }
 
+__device__ __forceinline__ float unit_pm1(uint32_t w) { return ((float)(w >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f; }   // [-1, 1), exact
+
+__device__ __forceinline__ int obb_overlap_spawn(const Spawn &a, const Spawn &b) {
+    Car ca, cb;
+    ca.x = a.x; ca.y = a.y; ca.ct = a.ct; ca.st = a.st;
+    cb.x = b.x; cb.y = b.y; cb.ct = b.ct; cb.st = b.st;
+    return obb_overlap(ca, cb);
+}
+
+// The reset law (H6; oracle: _reset_envs).  `grid`: the cars on the centre line behind the start.  `random` / `random_ball`:
+// word 0 of Philox(global env id, episode, 0, 0) picks a centre-line bin uniformly over the lap; car a stands at bin
+// idx0 - a * BALL_GAP, moved sideways by u * w (w: the bin's lateral room) and turned by v * RCS_HEADING_JITTER off the
+// track's direction; (u, v) = words 1, 2 of call 0 for car 0, words (0, 1) / (2, 3) of call 1 + (a - 1) / 2 for the others.
+// If two proposed cars overlap, ALL cars of the env take the centre-line poses.
 template <int A>
 __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t ep, Spawn (&sp)[A]) {
     const RcTrackDev &t = p.trk;
     const uint32_t g = p.first_env + (uint32_t)e;
-    const rcd::u32x4 r = rcd::philox4x32(g, ep, 0u, 0u, p.seed_lo, p.seed_hi);
+    const bool jitter = p.reset_mode != 0;
+    rcd::u32x4 r[1 + A / 2];
+    r[0] = rcd::philox4x32(g, ep, 0u, 0u, p.seed_lo, p.seed_hi);
+    if (jitter) {
+#pragma unroll
+        for (int k = 1; k < 1 + A / 2; ++k) r[k] = rcd::philox4x32(g, ep, (uint32_t)k, 0u, p.seed_lo, p.seed_hi);
+    }
     const int n = t.n_centerline;
-    const int idx0 = p.reset_mode == 0 ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r.x, (uint32_t)n);
+    const int idx0 = !jitter ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r[0].x, (uint32_t)n);
+    Spawn centre[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
         int idx = (idx0 - a * RCS_BALL_GAP_BINS) % n;
         if (idx < 0) idx += n;
         const float4 s0 = t.spawn[2 * idx], s1 = t.spawn[2 * idx + 1];
-        Spawn &c = sp[a];
+        Spawn &c = centre[a];
         c.x = s0.x; c.y = s0.y; c.th = s0.z; c.ct = s0.w;
         c.st = s1.x; c.pr = s1.y; c.cp = __float_as_int(s1.z);
+        sp[a] = c;
+        if (jitter) {
+            const rcd::u32x4 &q = r[a == 0 ? 0 : 1 + (a - 1) / 2];
+            const uint32_t wu = a == 0 ? q.y : (((a - 1) & 1) ? q.z : q.x);
+            const uint32_t wv = a == 0 ? q.z : (((a - 1) & 1) ? q.w : q.y);
+            const float off = unit_pm1(wu) * s1.w;
+            Spawn &j = sp[a];
+            j.x = c.x - off * c.st;
+            j.y = c.y + off * c.ct;
+            float th = c.th + unit_pm1(wv) * RCS_HEADING_JITTER;
+            th = th > RCS_PI ? th - RCS_TWO_PI : th;
+            th = th < -RCS_PI ? th + RCS_TWO_PI : th;
+            j.th = th;
+            sincos32(th, j.st, j.ct);
+            float pr = progress_at(t, j.x, j.y);
+            pr = pr < 0.0f ? 0.0f : pr;
+            j.pr = pr;
+            const int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
+            j.cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
+        }
+    }
+    if (A > 1 && jitter) {
+        int clash = 0;
+#pragma unroll
+        for (int a = 0; a < A; ++a)
+#pragma unroll
+            for (int b = a + 1; b < A; ++b) clash |= obb_overlap_spawn(sp[a], sp[b]);
+        if (clash) {
+#pragma unroll
+            for (int a = 0; a < A; ++a) sp[a] = centre[a];
+        }
     }
 }
 

@@ -25,6 +25,10 @@
 #define RCS_PATCH_STEP_Q16 204800.0f   // 3.125 cells per pixel in 16.16 fixed point
 #define RCS_BALL_GAP_BINS 12      // 1.2 m between the cars of one env at reset
 #define RCS_GRID_LEAD_BINS 8      // grid mode: the last car starts 0.8 m after the start line
+#define RCS_SPAWN_CLEAR_R 40      // random starts: cells searched around a centre-line point for the nearest non-drivable cell
+#define RCS_SPAWN_MARGIN 0.60f    // [m] the footprint's farthest corner (0.474) + the two half cell diagonals (0.071)
+#define RCS_SPAWN_W_MAX 1.5f      // [m] cap of the lateral offset
+#define RCS_HEADING_JITTER 0.35f  // [rad] heading within +- this of the track's direction
 #define RCS_N_FOOTPRINT 34
 #define RCS_FOOT_STEP 0.05f      // pitch of the footprint lattice [m] (12 x 7 nodes, rear axle at node (2, 3))
 #define RCS_PI 3.14159274101257324f

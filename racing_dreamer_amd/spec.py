@@ -49,6 +49,13 @@ RESET_GRID, RESET_RANDOM, RESET_RANDOM_BALL = 0, 1, 2
 RESET_MODES = {"grid": RESET_GRID, "random": RESET_RANDOM, "random_ball": RESET_RANDOM_BALL}
 BALL_GAP_BINS = 12            # centerline bins (0.1 m each) between cars           (free)
 GRID_LEAD_BINS = 8            # grid reset: last car 0.8 m after the start line     (free)
+# `random` / `random_ball`: a pose on the track with a minimum wall distance, heading along the track (SURVEY.md H6;
+# "sample in random points close within a ball", dream.py:105-108): centre-line bin uniform over the lap, lateral offset
+# uniform within the room the track leaves at that bin, heading within +- HEADING_JITTER of the track's direction
+SPAWN_CLEAR_R = 40            # cells searched for the nearest non-drivable cell (2 m)       (free)
+SPAWN_MARGIN = 0.60           # [m] footprint's farthest corner 0.474 + two half cell diagonals 0.071  (derived)
+SPAWN_W_MAX = 1.5             # [m] cap of the lateral offset                                   (free)
+HEADING_JITTER = 0.35         # [rad]                                                           (free)
 
 # --- action remap (dreamer/dream.py:138) ---------------------------------------------
 ACTION_LOW = (0.005, -1.0)

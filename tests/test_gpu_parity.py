@@ -1050,3 +1050,32 @@ def test_the_order_in_which_the_scan_takes_the_cars_changes_nothing(track, n):
                 assert torch.equal(outs[0][name], outs[1][name]) and torch.equal(outs[0][name], outs[2][name]), (k, name)
     for e in envs:
         e.close()
+
+
+def test_random_starts_at_full_size_are_all_different_and_touch_nothing():
+    """H6 on the device at BASELINE's sizes: 65 536 single-car envs on austria - every start pose differs from every other
+    (794 centre-line poses were shared by 65 536 envs) and equals the C port's; 32 768 x 2 cars on treitlstrasse_v2
+    in `random_ball`: the two cars of an env stand within a ball, apart; one step with the brakes on finds no contact."""
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    from racing_dreamer_amd import spec
+    for track_name, n, cars, mode in (("austria", 65536, 1, "random"), ("treitlstrasse_v2", 32768, 2, "random_ball")):
+        t = load_track(track_name)
+        env = BatchedRaceEnv(t, n, cars, auto_reset=True)
+        ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution,
+                                  ro.OracleConfig(num_envs=n, cars_per_env=cars, auto_reset=True), threads=8)
+        pose = env.reset(mode=mode, seed=3)["pose"].cpu().numpy()
+        want = np.asarray(ora.reset(mode=spec.RESET_MODES[mode], seed=3)["pose"]).reshape(n, cars, 6)
+        assert np.array_equal(pose, want)
+        assert len(np.unique(pose.reshape(n, -1), axis=0)) == n
+        if cars == 2:
+            gap = np.linalg.norm(pose[:, 0, :2] - pose[:, 1, :2], axis=1)
+            assert gap.min() > 0.3 and gap.max() < 1.2 + 2 * 1.5
+        act = torch.zeros((n, cars, 2), device="cuda")
+        act[..., 0] = -1.0
+        out = env.step(act)
+        assert int(out["wall_collision"].sum()) == 0 and int(out["opponent_collision"].sum()) == 0 and int(out["done"].sum()) == 0
+        assert torch.equal(out["pose"].cpu(), torch.from_numpy(pose))
+        env.close()

@@ -35,12 +35,18 @@ def test_constants_agree():
         ("PROGRESS_REWARD", spec.PROGRESS_REWARD, ro.PROGRESS_REWARD, c["PROGRESS_REWARD"]),
         ("PATCH_CELLS", spec.PATCH_WINDOW_CELLS / spec.PATCH, ro.PATCH_CELLS, c["PATCH_CELLS"]),
         ("PATCH_WINDOW", spec.PATCH_CROP_HALF, ro.PATCH_WINDOW, c["PATCH_WINDOW"]),
+        ("SPAWN_MARGIN", spec.SPAWN_MARGIN, ro.SPAWN_MARGIN, c["SPAWN_MARGIN"]),
+        ("SPAWN_W_MAX", spec.SPAWN_W_MAX, ro.SPAWN_W_MAX, c["SPAWN_W_MAX"]),
+        ("HEADING_JITTER", spec.HEADING_JITTER, ro.HEADING_JITTER, c["HEADING_JITTER"]),
     ]
     for name, host, ora, cval in triples:
         assert f(host) == f(ora) == f(cval) == f(dev[name]), name
     assert spec.N_CHECKPOINTS == ro.N_CHECKPOINTS == int(c["N_CP"]) == int(dev["N_CHECKPOINTS"])
     assert spec.BALL_GAP_BINS == ro.BALL_GAP_BINS == int(c["BALL_GAP"]) == int(dev["BALL_GAP_BINS"])
     assert spec.GRID_LEAD_BINS == ro.GRID_LEAD_BINS == int(c["GRID_LEAD"]) == int(dev["GRID_LEAD_BINS"])
+    assert spec.SPAWN_CLEAR_R == ro.SPAWN_CLEAR_R == int(c["SPAWN_CLEAR_R"]) == int(dev["SPAWN_CLEAR_R"])
+    # the margin covers the footprint's farthest corner from the rear axle plus what a cell-centre distance cannot see
+    assert spec.SPAWN_MARGIN >= np.hypot(spec.X_FRONT, spec.HALF_W) + 2 * 0.05 * np.sqrt(0.5) + 0.05
     assert spec.N_BEAMS == ro.N_BEAMS == 1080 and spec.N_FOOTPRINT == int(dev["N_FOOTPRINT"]) == 34
     assert f(dev["PI"]) == ro.PI and f(dev["TWO_PI"]) == ro.TWO_PI
 
