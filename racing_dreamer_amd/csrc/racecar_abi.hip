@@ -667,7 +667,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         any_nstep |= a < cfg->cars_per_env && env->params.car_task[a] == RC_TASK_N_STEP_PROGRESS;
     }
     env->params.n_steps = cfg->n_steps;
-    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6 + 16) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0) + 64;
+    const size_t state_bytes = nc * (10 * 4 + 2 * 4 + 6 + 16 + 16) + ne * 12 + (any_nstep ? nc * RC_NSTEP_MAX * 4 : 0) + 64;
     HIP_TRY_FREE(hipMalloc(&env->state_mem, state_bytes));
     HIP_TRY_FREE(hipMemsetAsync(env->state_mem, 0, state_bytes, env->stream));
     HIP_TRY_FREE(hipMalloc((void **)&env->mask_dev, ne));
@@ -675,6 +675,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
         char *m = (char *)env->state_mem;
         RcStateDev &s = env->params.st;
         s.scan_pose = (float4 *)m; m += nc * 16;                // first: 16-byte aligned
+        s.patch_pose = (int4 *)m; m += nc * 16;
         float **fp[] = {&s.x, &s.y, &s.theta, &s.ct, &s.st, &s.v, &s.delta, &s.omega, &s.accel, &s.progress};
         for (float **f : fp) { *f = (float *)m; m += nc * 4; }
         s.lap = (int32_t *)m; m += nc * 4;
@@ -953,7 +954,8 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
         // small track loaded after a large one would make the large one's launches fail
         static std::map<int, size_t> lds_limit;
         size_t &lim = lds_limit[env->cfg.device];
-        const size_t need = std::min<size_t>(160 * 1024, std::max(std::max(tt->lds_bytes, tt->lds_bytes_skip), tt->lds_bytes_packed));
+        const size_t need = std::min<size_t>(160 * 1024, std::max(std::max(std::max(tt->lds_bytes, tt->lds_bytes_skip), tt->lds_bytes_packed),
+                                                                  rc_patch_padded_bytes(h, w)));
         if (need > lim || lim == 0) {
             HIP_TRY(rck_set_lds_limits(std::max(need, lim)));
             lim = std::max(need, lim);

@@ -52,6 +52,9 @@ struct RcStateDev {              // persistent per-car / per-env simulator state
     uint32_t *episode;              // per env
     float4 *scan_pose;              // [n_cars] (x, y, cos, sin) once more, packed: the scan fetches a car's state with ONE
                                     // scalar 16-byte load (four separate words cost it a second serial round trip)
+    int4 *patch_pose;               // [n_cars] what the lidar_occupancy render needs of a car, as integers: (start cell x, start cell
+                                    // y + 1, the pixel step a, b in 16.16) or x = RC_PATCH_SKIP for an all-zero patch (first
+                                    // observation of an episode, diverged pose) - written next to scan_pose when the render is on
     float *nstep_hist;              // [n_cars][RC_NSTEP_MAX] total progress at sub-step s in slot s % n_steps; null unless
                                     // some car runs RC_TASK_N_STEP_PROGRESS
     const int32_t *order;           // [n_cars] the order in which the scan's waves take the cars: sorted by track position every
@@ -86,6 +89,17 @@ struct RcParams {
     uint32_t *scan_overrun;      // device counter: waves of the BOUNDED scan build that used up a round's trip budget
 };
 
+#define RC_PATCH_SKIP 0x7fffffff
+// The render's bitmap in LDS with a border of RC_PATCH_PAD zero cells on every side (a tap lies at most 110 sqrt 2 = 155.6 cells
+// from the car's cell, + 1 for the row offset of the start cell): a car that stands inside the grid then needs no clamp on any
+// tap.  Used when two such images fit one CU's 160 KB (columbia 49 KB, treitlstrasse_v2 56 KB, austria 79 KB; barcelona's
+// 169 KB does not: that track keeps the unpadded bitmap and clamps).  Bytes of the padded image, 0 if it is not used.
+#define RC_PATCH_PAD 160
+static inline size_t rc_patch_padded_bytes(int h, int w) {
+    const size_t pitch_words = ((size_t)w + 2 * RC_PATCH_PAD + 31) / 32, rows = (size_t)h + 2 * RC_PATCH_PAD;
+    const size_t bytes = (pitch_words * 4 * rows + 15) / 16 * 16;
+    return bytes <= 80 * 1024 ? bytes : 0;
+}
 #define RC_ORDER_BUCKETS 1024       // counting sort of the cars by progress
 #define RC_ORDER_REGION 256u         // ranks per region handed to one XCD (rc_order_place_kernel)
 #define RC_ORDER_PERIOD 64          // observations between two sorts (cars move centimetres per step)

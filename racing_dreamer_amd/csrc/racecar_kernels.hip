@@ -57,6 +57,20 @@ struct Car {
     int wall, opp, wrong, done, trunc, fresh;
 };
 
+// What rc_patch_car_kernel needs of a car (RcStateDev::patch_pose): the start cell, the pixel step of the 64 x 64 patch in
+// 16.16 cells (heading = + column, 3.125 cells per pixel) - or the mark of an all-zero patch: the first observation of an
+// episode (dreamer/wrappers.py:413) and a car tens of thousands of cells off the grid (a diverged state sees nothing; it also
+// keeps the fixed-point taps in range).  Computed by whoever writes the pose (one lane per car), so that the render, one wave
+// per car, starts from ONE scalar 16-byte load and spends no vector instruction on wave-uniform values.
+__device__ __forceinline__ int4 patch_pose_of(const RcTrackDev &t, float x, float y, float ct, float st, int fresh) {
+    int icx, icy;
+    cell_of(t, x, y, icx, icy);
+    icy += 1;
+    const bool sane = (unsigned)(icx + 16384) < 32768u && (unsigned)(icy + 16384) < 32768u;
+    const int a = (int)__builtin_rintf(ct * RCS_PATCH_STEP_Q16), b = (int)__builtin_rintf(st * RCS_PATCH_STEP_Q16);
+    return make_int4((fresh != 0 || !sane) ? RC_PATCH_SKIP : icx, icy, a, b);
+}
+
 // Footprint perimeter vs occupancy (H5): the 34 border points of the 12 x 7 body lattice (0.05 m pitch, rear axle at
 // lattice node (2, 3)) in 16.16 fixed-point cell coordinates - oracle/racecar_oracle.py, _wall_hit.  With the lattice
 // vectors e = rne(65536 k (cos, sin)) and f = (-e.y, e.x) a point is two integer multiply-adds of the rear-axle
@@ -267,6 +281,7 @@ __device__ __forceinline__ void store_state_and_obs(const RcParams &p, int e, co
         p.st.wall[i] = c.wall; p.st.opp[i] = c.opp; p.st.wrong[i] = c.wrong;
         p.st.done[i] = c.done; p.st.trunc[i] = c.trunc; p.st.fresh[i] = c.fresh;
         p.st.scan_pose[i] = make_float4(c.x, c.y, c.ct, c.st);
+        if (p.render_patch) p.st.patch_pose[i] = patch_pose_of(p.trk, c.x, c.y, c.ct, c.st, c.fresh);
         // observation of the current state (post auto-reset)
         float *pose = p.out.pose + 6 * i, *vel = p.out.velocity + 6 * i;
         pose[0] = c.x; pose[1] = c.y; pose[2] = 0.0f; pose[3] = 0.0f; pose[4] = 0.0f; pose[5] = c.th;
@@ -1821,108 +1836,118 @@ __device__ __forceinline__ uint32_t select_mask(unsigned long long m, uint32_t a
     return r;
 }
 
+// (Round 4: every operand that used to be wave-uniform - the pixel step, the grid limits, the window - sits in a VECTOR
+// register: on gfx950 a vector instruction with a scalar-register operand issues at half rate (4.3 cycles against 2.35,
+// tools/ubench/valu_issue4.hip), and the render is bound by exactly that - profiles/r04_a_pmc_patch_kernel_round3_build.txt:
+// 47.1 M wave-level vector instructions per 65 536 cars, 97.6 % lane use, 58 % of the wave-cycles spent waiting to issue;
+// 4.85 LDS cycles per byte gather of which 2.8 are bank conflicts, but the LDS pipe is only 40 % busy.)
 __device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) {
     uint32_t r;
-    asm("v_min_u32 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    asm("v_min_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ uint32_t mad_hi16_s(uint32_t y, uint32_t pitch, uint32_t c) {         // (y >> 16) * pitch + c, pitch scalar
+    uint32_t r;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(y), "s"(pitch), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t lshl_or_v(uint32_t a, uint32_t sh, uint32_t c) {              // (a << sh) | c as ONE instruction
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(sh), "v"(c));
+    return r;
+}
+struct PatchConst {          // per car, all in vector registers (see above)
+    int a, b;                // pixel step
+    uint32_t xmax, ymax;     // last cell of the grid, 16.16 + 0xffff
+    uint32_t wx, wy, span;   // the reference's crop window: origin and extent - 1 ulp
+    uint32_t zero_addr;      // LDS address of the all-zero word behind the bitmap
+    uint32_t three, one;     // the widths of the two bit-field extracts
+    uint32_t sixteen;
+    uint32_t sh[4];          // 0, 8, 16, 24: where a pixel goes in its word
+};
 
 // One 16-pixel run: taps (X, Y) += (a, b).  CLAMP: coordinates are forced into the grid first - a tap left of / below
 // the grid has a negative coordinate, i.e. a huge unsigned one, and clamps like one beyond the far edge to the last
 // column / row, which is never drivable (rc_load_track clears the bitmap's outermost ring; so does the oracle).
+// Per pixel: add, add (full rate), shift (full), multiply-add (half), bit index (half), LDS byte read, bit extract (half),
+// pack (half, 3 of 4 pixels) = 6.75 vector instructions, 3.75 of them half rate: 16 cycles of a SIMD's issue.
 template <bool CLAMP>
-__device__ __forceinline__ void patch_run(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
-                                          uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t (&words)[4]) {
+__device__ __forceinline__ void patch_run(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, const PatchConst &k,
+                                          uint32_t pitch_b, uint32_t (&words)[4]) {
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, xmax) : (uint32_t)X;
-        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, ymax) : (uint32_t)Y;
-        const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19);                  // iy * pitch + ix / 8
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, k.xmax) : (uint32_t)X;
+        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, k.ymax) : (uint32_t)Y;
+        const uint32_t addr = mad_hi16_s(yc, pitch_b, xc >> 19);                  // iy * pitch + ix / 8
         const uint32_t byte = lds[addr];
-        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, 16, 3), 1);              // bit ix % 8
-        words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
-        X += a;
-        Y += b;
+        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, k.sixteen, k.three), k.one);   // bit ix % 8
+        if ((i & 3) == 0) words[i >> 2] = bit;
+        else words[i >> 2] = lshl_or_v(bit, k.sh[i & 3], words[i >> 2]);
+        X += k.a;
+        Y += k.b;
+    }
+}
+
+// The same with every tap tested against the crop window (the corner runs of a car whose window corner cuts them).
+template <bool CLAMP>
+__device__ __forceinline__ void patch_run_tested(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, const PatchConst &k,
+                                                 uint32_t pitch_b, uint32_t (&words)[4]) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        // inside the window <=> both window-relative coordinates (unsigned: below the window = huge) are <= 220 cells - 1 ulp
+        const uint32_t far = max((uint32_t)X - k.wx, (uint32_t)Y - k.wy);
+        const bool ok = far <= k.span;
+        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, k.xmax) : (uint32_t)X;
+        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, k.ymax) : (uint32_t)Y;
+        const uint32_t addr = mad_hi16_s(yc, pitch_b, xc >> 19);
+        const uint32_t byte = lds[ok ? addr : k.zero_addr];
+        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, k.sixteen, k.three), k.one);
+        if ((i & 3) == 0) words[i >> 2] = bit;
+        else words[i >> 2] = lshl_or_v(bit, k.sh[i & 3], words[i >> 2]);
+        X += k.a;
+        Y += k.b;
     }
 }
 
 // ---- lidar_occupancy, ONE WAVE PER CAR -----------------------------------------------------------------------------
-// (Round 3.  The round-2 kernel, four waves per car, is in the history: EXPERIMENTS.md I.1 has the A/B.)
-// Same taps, same results; what changed is who renders what.  The round-2 kernel gave a car to four waves of 64 runs
-// (16 pixels each): every wave paid the per-car setup - three dependent global round trips for pose, flag and heading,
-// four 32-bit multiplies, the window tests: a third of its instructions - and the wave that held the four corner blocks
-// ran the tested loop (14 instructions per pixel instead of 7) for ALL of its 64 runs, while its 16-byte pieces of the
-// first and last 16 rows reached HBM as partial lines (1.27 x the algorithmic bytes).  Here a wave renders a whole car:
-// * the car is wave-uniform, so pose and heading arrive in ONE scalar 16-byte load (the packed copy the scan uses) next
-//   to the flag word, and the setup is paid once per 4 096 pixels;
-// * a lane renders four runs, one per 16-row group g, and a store instruction writes group g of every lane: lanes
-//   4 i .. 4 i + 3 hold the four pieces of row 16 g + i, so every store covers whole 64-byte lines (16 rows = 1 KB of
-//   consecutive bytes) - no line is split between waves or between instructions;
+// (Round 3 gave a car to one wave - EXPERIMENTS.md I.1; round 4 took the wave-uniform work out of the vector unit.)
+// * the car arrives as ONE scalar 16-byte load of integers (RcStateDev::patch_pose, written by the kernel that moved the car):
+//   start cell, pixel step, or the mark of an all-zero patch; the window tests, the tap of pixel (0, 0) and the store base are
+//   scalar arithmetic; the vector unit only walks pixels;
+// * a lane renders four runs of 16 pixels, one per 16-row group g, and a store instruction writes group g of every lane:
+//   lanes 4 i .. 4 i + 3 hold the four pieces of row 16 g + i, so every store covers whole 64-byte lines (16 rows = 1 KB
+//   of consecutive bytes) - no line is split between waves or between instructions (HBM writes = 1.00 x the pixels);
 // * only the 64 runs in the corner blocks (rows 0-15 and 48-63, columns 0-15 and 48-63) can be cut by the reference's
-//   220-cell crop window (they lie within 15.8 pixels of two patch edges whatever the heading).  In group 0 they are
-//   the lanes with l & 3 in {0, 3}; group 3 stores its pieces in the order 1, 0, 3, 2 (column block (l & 3) ^ 1: still
-//   whole lines per instruction), so there they are the lanes with l & 3 in {1, 2}: EVERY lane owns exactly one corner
-//   run.  Each lane renders its corner run in one slot (the tested loop, taken only if some run of the wave is in fact
-//   cut) and its three other runs with the test-free loop; two selects per word put the results back in group order.
-//   4 096 pixels of a cut car cost 16 (13 + 3 x 7) instructions per lane instead of 16 (14 + 3 x 7) per lane of FOUR
-//   waves of which one ran 64 tested runs: 8.5 against 8.75 per pixel, plus the setup once instead of four times.
-// The non-corner slots keep the end-tap test of the round-2 kernel as a safety net (a wave-uniform branch to a rolled
-// per-tap loop that is never taken if the 15.8-pixel bound holds).
-template <bool CLAMP>
-__device__ __forceinline__ void patch_run_tested(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
-                                                 uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t wx, uint32_t wy,
-                                                 uint32_t span_fix, uint32_t zero_addr, uint32_t (&words)[4]) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        // inside the window <=> both window-relative coordinates (unsigned: below the window = huge) are <= 220 cells - 1 ulp
-        const uint32_t far = max((uint32_t)X - wx, (uint32_t)Y - wy);
-        const unsigned long long ok = cmp_le_u32(far, span_fix);
-        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, xmax) : (uint32_t)X;
-        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, ymax) : (uint32_t)Y;
-        const uint32_t addr = mad_hi16(yc, pitch_b, xc >> 19);
-        const uint32_t byte = lds[select_mask(ok, addr, zero_addr)];
-        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, 16, 3), 1);
-        words[k >> 2] = lshl_or(bit, 8 * (k & 3), words[k >> 2]);
-        X += a;
-        Y += b;
-    }
-}
-
-// the rolled form of the same (the safety net of the non-corner slots: code size, not speed)
-__device__ __forceinline__ void patch_run_rolled(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, int a, int b,
-                                                 uint32_t pitch_b, uint32_t xmax, uint32_t ymax, uint32_t wx, uint32_t wy,
-                                                 uint32_t span_fix, uint32_t zero_addr, uint32_t (&words)[4]) {
-#pragma unroll 1
-    for (int w4 = 0; w4 < 4; ++w4) {
-        uint32_t acc = 0u;
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const bool ok = max((uint32_t)X - wx, (uint32_t)Y - wy) <= span_fix;
-            const uint32_t xc = min((uint32_t)X, xmax), yc = min((uint32_t)Y, ymax);
-            const uint32_t addr = (yc >> 16) * pitch_b + (xc >> 19);
-            const uint32_t byte = lds[ok ? addr : zero_addr];
-            acc |= ((byte >> ((xc >> 16) & 7u)) & 1u) << (8 * k);
-            X += a;
-            Y += b;
-        }
-        words[w4] = acc;
-    }
-}
-
+//   220-cell crop window.  In group 0 they are the lanes with l & 3 in {0, 3}; group 3 stores its pieces in the order
+//   1, 0, 3, 2 (column block (l & 3) ^ 1: still whole lines per instruction), so there they are the lanes with l & 3 in
+//   {1, 2}: EVERY lane owns exactly one corner run and renders it in one slot - with the tested loop only if some corner
+//   run of the wave is in fact cut (its two end taps outside the window, which is convex) - and its three other runs with
+//   the test-free loop.  That those cannot be cut is a property of the pixel step alone: a tap of a run outside the corner
+//   blocks lies at most 31.5 |a| + 15.5 |b| (or the same with a and b exchanged) from the start cell on either axis, and
+//   the SCALAR unit checks that bound against the window per car (it holds for every unit heading: 35.1 x 3.125 = 109.7
+//   < 110 cells); a car that failed it would take the tested loop in all four slots.
+struct PatchImage {          // the bitmap as it lies in LDS (wave-uniform): plain, or with the zero border of RC_PATCH_PAD cells
+    uint32_t pitch_b, w_cells, h_cells, zero_addr;
+};
 template <bool CLAMP, bool NT>
-__device__ __forceinline__ void patch_car(const RcParams &p, const unsigned car, const unsigned lane, const int icx, const int icy,
-                                          const int a, const int b) {
-    const RcTrackDev &t = p.trk;
+__device__ __forceinline__ void patch_car(const RcParams &p, const PatchImage &img, const unsigned car, const unsigned lane, const int icx,
+                                          const int icy, const int a, const int b, const bool all_tested) {
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
     const lds_u8_ptr lds_bytes = (lds_u8_ptr)(uint32_t)0;                // the bitmap starts at LDS address 0 (rck_set_lds_limits)
-    const uint32_t pitch_b = (uint32_t)t.pitch * 4u;
-    const uint32_t xmax = ((uint32_t)(t.w - 1) << 16) | 0xffffu, ymax = ((uint32_t)(t.h - 1) << 16) | 0xffffu;
-    const uint32_t zero_addr = (uint32_t)(t.h * t.pitch) * 4u;          // the all-zero word behind the bitmap
+    const uint32_t pitch_b = img.pitch_b;
+    PatchConst k;
+    k.a = pin_vgpr(a); k.b = pin_vgpr(b);
+    k.xmax = pin_vgpr(((img.w_cells - 1u) << 16) | 0xffffu);
+    k.ymax = pin_vgpr(((img.h_cells - 1u) << 16) | 0xffffu);
+    k.zero_addr = pin_vgpr(img.zero_addr);                               // a word that reads 0
     // the reference's [-110, 110) crop window around the start cell, in 16.16
-    const uint32_t wx = (uint32_t)(icx - RCS_PATCH_WINDOW_I) << 16, wy = (uint32_t)(icy - RCS_PATCH_WINDOW_I) << 16;
-    const uint32_t span_fix = ((uint32_t)(2 * RCS_PATCH_WINDOW_I) << 16) - 1u;
-    const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;
+    k.wx = pin_vgpr((uint32_t)(icx - RCS_PATCH_WINDOW_I) << 16);
+    k.wy = pin_vgpr((uint32_t)(icy - RCS_PATCH_WINDOW_I) << 16);
+    k.span = pin_vgpr(((uint32_t)(2 * RCS_PATCH_WINDOW_I) << 16) - 1u);
+    k.three = pin_vgpr(3u); k.one = pin_vgpr(1u); k.sixteen = pin_vgpr(16u);
+    k.sh[0] = 0u; k.sh[1] = pin_vgpr(8u); k.sh[2] = k.sixteen; k.sh[3] = pin_vgpr(24u);
+    const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;      // scalar
     const int rl = (int)(lane >> 2), cb = (int)(lane & 3u);
     const bool corner_first = cb == 0 || cb == 3;          // this lane's corner run is in group 0 (else in group 3)
     // start taps of a run: (row, first column c0)
@@ -1931,9 +1956,16 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const unsigned car,
         Y = mad_i24(c0, b, mad_i24(-row, a, y00));
     };
     auto ends_inside = [&](int X, int Y) {
-        const uint32_t f0 = max((uint32_t)X - wx, (uint32_t)Y - wy);
-        const uint32_t f1 = max((uint32_t)(X + 15 * a) - wx, (uint32_t)(Y + 15 * b) - wy);
-        return max(f0, f1) <= span_fix;
+        const uint32_t f0 = max((uint32_t)X - k.wx, (uint32_t)Y - k.wy);
+        const uint32_t f1 = max((uint32_t)(X + 15 * k.a) - k.wx, (uint32_t)(Y + 15 * k.b) - k.wy);
+        return max(f0, f1) <= k.span;
+    };
+    // CLAMP cars (the window is not wholly inside the grid): a slot whose 64 runs all have BOTH end taps inside the grid - a
+    // rectangle, convex - has every tap inside it and takes the loop without the two clamps per pixel; the others clamp
+    auto slot_in_grid = [&](int X, int Y) {
+        if (!CLAMP) return true;
+        const uint32_t fx = max((uint32_t)X, (uint32_t)(X + 15 * k.a)), fy = max((uint32_t)Y, (uint32_t)(Y + 15 * k.b));
+        return __builtin_amdgcn_ballot_w64(fx > k.xmax || fy > k.ymax) == 0;
     };
     // piece (row, column block) of the car's 4 KB lies at 16-byte index 4 row + block: groups 0 - 2 at 64 g + lane, group 3
     // (pieces in the order 1, 0, 3, 2) at 192 + (lane ^ 1)
@@ -1945,13 +1977,17 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const unsigned car,
         else *dst = px;
     };
     // slot A: the corner run - group 0 piece cb for the lanes with cb in {0, 3}, group 3 piece cb ^ 1 for the others
-    uint32_t wa[4] = {0u, 0u, 0u, 0u}, wb[4] = {0u, 0u, 0u, 0u};
+    uint32_t wa[4], wb[4];
     {
         int X, Y;
         start(corner_first ? rl : 48 + rl, corner_first ? 16 * cb : 16 * (cb ^ 1), X, Y);
         // the end taps of every corner run inside the window, which is convex: so is every tap of the wave
-        if (__builtin_amdgcn_ballot_w64(!ends_inside(X, Y)) == 0) patch_run<CLAMP>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, wa);
-        else patch_run_tested<CLAMP>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, wx, wy, span_fix, zero_addr, wa);
+        if (!all_tested && __builtin_amdgcn_ballot_w64(!ends_inside(X, Y)) == 0) {
+            if (slot_in_grid(X, Y)) patch_run<false>(lds_bytes, X, Y, k, pitch_b, wa);
+            else patch_run<CLAMP>(lds_bytes, X, Y, k, pitch_b, wa);
+        } else {
+            patch_run_tested<CLAMP>(lds_bytes, X, Y, k, pitch_b, wa);
+        }
     }
     // slot B: the lane's piece of the OTHER outer group (columns 16 - 47: never cut); then groups 1 and 2
 #pragma unroll 1
@@ -1960,9 +1996,10 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const unsigned car,
         const int c0 = (s == 0 && corner_first) ? 16 * (cb ^ 1) : 16 * cb;
         int X, Y;
         start(row, c0, X, Y);
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        if (__builtin_amdgcn_ballot_w64(!ends_inside(X, Y)) == 0) patch_run<CLAMP>(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, w);
-        else patch_run_rolled(lds_bytes, X, Y, a, b, pitch_b, xmax, ymax, wx, wy, span_fix, zero_addr, w);
+        uint32_t w[4];
+        if (all_tested) patch_run_tested<CLAMP>(lds_bytes, X, Y, k, pitch_b, w);
+        else if (slot_in_grid(X, Y)) patch_run<false>(lds_bytes, X, Y, k, pitch_b, w);
+        else patch_run<CLAMP>(lds_bytes, X, Y, k, pitch_b, w);
         if (s == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) wb[i] = w[i];
@@ -1981,34 +2018,44 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const unsigned car,
 }
 
 template <bool NT>
-__global__ __launch_bounds__(1024) void rc_patch_car_kernel(RcParams p) {
+__global__ __launch_bounds__(1024) void rc_patch_car_kernel(RcParams p, int padded_bytes) {
     extern __shared__ uint32_t lds_words[];
     const RcTrackDev &t = p.trk;
-    stage_bitmap(lds_words, t.drv_words, t.h * t.pitch + 1);        // + the all-zero word behind the bitmap (rc_load_track)
+    const int pad = padded_bytes > 0 ? RC_PATCH_PAD : 0;
+    PatchImage img;
+    if (pad) {
+        // the bitmap inside a border of `pad` zero cells (pad = 5 words: rows keep their word alignment)
+        const int pw = (t.w + 2 * pad + 31) / 32, rows = t.h + 2 * pad;
+        uint4 *d4 = reinterpret_cast<uint4 *>(lds_words);
+        const uint4 z4 = {0u, 0u, 0u, 0u};
+        for (int i = threadIdx.x; i < (padded_bytes >> 4); i += blockDim.x) d4[i] = z4;
+        __syncthreads();
+        for (int i = threadIdx.x; i < t.h * t.pitch; i += blockDim.x) {
+            const int row = i / t.pitch, word = i - row * t.pitch;
+            if (word < pw - pad / 32) lds_words[(row + pad) * pw + pad / 32 + word] = t.drv_words[i];
+        }
+        img.pitch_b = (uint32_t)pw * 4u; img.w_cells = (uint32_t)(pw * 32); img.h_cells = (uint32_t)rows; img.zero_addr = 0u;
+    } else {
+        stage_bitmap(lds_words, t.drv_words, t.h * t.pitch + 1);        // + the all-zero word behind the bitmap (rc_load_track)
+        img.pitch_b = (uint32_t)t.pitch * 4u; img.w_cells = (uint32_t)t.w; img.h_cells = (uint32_t)t.h;
+        img.zero_addr = (uint32_t)(t.h * t.pitch) * 4u;
+    }
     __syncthreads();
     const unsigned lane = threadIdx.x & 63u;
     const unsigned waves = gridDim.x * (blockDim.x >> 6);
     typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
     // cars are dealt to the waves of the grid in turn (a wave's cars are `waves` apart: neighbouring waves write
-    // neighbouring patches).  The car is wave-uniform, so its state - x, y, cos, sin in one 16-byte load from the packed
-    // copy the scan uses, and the flag word - comes through the SCALAR unit: vector loads share one in-order counter with
-    // the stores, and every car would start by waiting for the previous car's 4 KB to be acknowledged.  (Inline assembly
-    // with its own wait: the compiler takes the loads for vector ones because the kernel also stores.)
+    // neighbouring patches).  The car is wave-uniform, so its header comes through the SCALAR unit: vector loads share one
+    // in-order counter with the stores, and every car would start by waiting for the previous car's 4 KB to be
+    // acknowledged.  (Inline assembly with its own wait: the compiler takes the load for a vector one because the kernel
+    // also stores.)
     for (unsigned car = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)); car < (unsigned)p.n_cars;
          car = __builtin_amdgcn_readfirstlane(car + waves)) {
-        typedef float v4f_t __attribute__((ext_vector_type(4)));
-        v4f_t sp;
-        uint32_t fresh_word;
-        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(sp), "=&s"(fresh_word) : "s"(p.st.scan_pose + car), "s"(reinterpret_cast<const uint32_t *>(p.st.fresh) + (car >> 2)) : "memory");
-        const uint32_t fresh = (fresh_word >> (8u * (car & 3u))) & 255u;
-        int icx, icy;
-        cell_of(t, sp.x, sp.y, icx, icy);
-        icx = __builtin_amdgcn_readfirstlane(icx);
-        icy = __builtin_amdgcn_readfirstlane(icy) + 1;
-        // a car tens of thousands of cells away from the grid (a diverged state) sees nothing; it also keeps X, Y in range
-        const bool sane = (unsigned)(icx + 16384) < 32768u && (unsigned)(icy + 16384) < 32768u;
-        if (fresh != 0u || !sane) {              // reset observation is all zeros, dreamer/wrappers.py:413
+        typedef int v4i_t __attribute__((ext_vector_type(4)));
+        v4i_t h;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(h) : "s"(p.st.patch_pose + car) : "memory");
+        const int a = h.z, b = h.w;
+        if (h.x == RC_PATCH_SKIP) {              // reset observation is all zeros, dreamer/wrappers.py:413; a diverged car sees nothing
             v4u_t *out = reinterpret_cast<v4u_t *>(p.out.patch) + (size_t)car * 256u + lane;
             const v4u_t z = {0u, 0u, 0u, 0u};
 #pragma unroll
@@ -2018,13 +2065,18 @@ __global__ __launch_bounds__(1024) void rc_patch_car_kernel(RcParams p) {
             }
             continue;
         }
-        const int a = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(sp.z * RCS_PATCH_STEP_Q16));
-        const int b = __builtin_amdgcn_readfirstlane((int)__builtin_rintf(sp.w * RCS_PATCH_STEP_Q16));
-        // window inside the grid (a property of the car)?  then no tap can leave the grid and nothing is clamped
-        const int lx = icx - RCS_PATCH_WINDOW_I, ly = icy - RCS_PATCH_WINDOW_I, span = 2 * RCS_PATCH_WINDOW_I - 1;
-        const bool inside = lx >= 0 && ly >= 0 && lx + span <= t.w - 1 && ly + span <= t.h - 1;
-        if (inside) patch_car<false, NT>(p, car, lane, icx, icy, a, b);
-        else patch_car<true, NT>(p, car, lane, icx, icy, a, b);
+        // No tap can leave the image, and nothing is clamped, if the crop window lies inside the grid - or, with the zero border,
+        // if the car's own cell does (the border is wider than any tap is far)
+        const int lx = h.x - RCS_PATCH_WINDOW_I, ly = h.y - RCS_PATCH_WINDOW_I, span = 2 * RCS_PATCH_WINDOW_I - 1;
+        const bool inside = pad ? ((unsigned)h.x < (unsigned)t.w && (unsigned)(h.y - 1) < (unsigned)t.h)
+                                : (lx >= 0 && ly >= 0 && lx + span <= t.w - 1 && ly + span <= t.h - 1);
+        const int icx = h.x + pad, icy = h.y + pad;            // the start cell in the image's coordinates
+        // runs outside the corner blocks stay inside the window: |offset| <= (63 |a| + 31 |b|) / 2 + 1 on either axis (and with a, b exchanged)
+        const int aa = a < 0 ? -a : a, ab = b < 0 ? -b : b;
+        const int reach = (63 * (aa > ab ? aa : ab) + 31 * (aa > ab ? ab : aa)) / 2 + 2;
+        const bool all_tested = reach > RCS_PATCH_WINDOW_I * 65536 - 2;
+        if (inside) patch_car<false, NT>(p, img, car, lane, icx, icy, a, b, all_tested);
+        else patch_car<true, NT>(p, img, car, lane, icx, icy, a, b, all_tested);
     }
 }
 
@@ -2409,6 +2461,7 @@ __global__ __launch_bounds__(256) void rc_set_pose_kernel(RcParams p, const floa
     sincos32(th, sn, cs);
     p.st.x[i] = x; p.st.y[i] = y; p.st.theta[i] = th; p.st.st[i] = sn; p.st.ct[i] = cs;
     p.st.scan_pose[i] = make_float4(x, y, cs, sn);
+    if (p.render_patch) p.st.patch_pose[i] = patch_pose_of(p.trk, x, y, cs, sn, 0);
     p.st.fresh[i] = 0;
     p.out.fresh[i] = 0;
     float *pose = p.out.pose + 6 * i;
@@ -2888,11 +2941,13 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s) {
     // persistent 16-wave workgroups, the bitmap staged once per workgroup; as many as stay resident
-    const int per_cu = li.lds_bytes <= 80 * 1024 ? 2 : 1;
+    const int padded = (li.patch_variant & 4) ? 0 : (int)rc_patch_padded_bytes(p.trk.h, p.trk.w);      // (4: experiment, the unpadded bitmap)
+    const size_t lds = padded ? (size_t)padded : li.lds_bytes;
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const long long need = ((long long)p.n_cars + 15) / 16, resident = (long long)li.n_cu * per_cu;
     const int blocks = (int)(need < resident ? need : resident);
-    if (li.patch_variant & 2) launch(rc_patch_car_kernel<false>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);     // experiment: plain stores
-    else launch(rc_patch_car_kernel<true>, dim3(blocks), dim3(1024), li.lds_bytes, s, p);
+    if (li.patch_variant & 2) launch(rc_patch_car_kernel<false>, dim3(blocks), dim3(1024), lds, s, p, padded);     // experiment: plain stores
+    else launch(rc_patch_car_kernel<true>, dim3(blocks), dim3(1024), lds, s, p, padded);
     return hipGetLastError();
 }
 
