@@ -472,7 +472,14 @@ class ShardedCollector:
         n = self.length + 4
         for k in range(n):
             self.ring.step_random(seed=1, step=k0 + k)
-        self.last_batch = self.rep.sample(self.windows, self.length, fields=self.FIELDS, generator=self.gen)
+        # one batch through the very path the loop takes (first use of a collective of this size, of the side stream, of the
+        # sampler's kernels: none of that belongs into a timed window)
+        buf, _ = self.rep.draw_packed(self.windows, self.length, fields=self.FIELDS, generator=self.gen, out=self.batch_src[1], layout=self.layout)
+        self.ev_batch.record(self.env.stream)
+        with self.torch.cuda.stream(self.side):
+            self.side.wait_event(self.ev_batch)
+            self.last_batch = self.rep.exchange_packed(buf, self.layout, out=self.batch_dst[1])
+        self.env.stream.wait_stream(self.side)
         return n
 
     def _send_summary(self):
