@@ -725,6 +725,9 @@ def main():
     fresh = None
     if not distributed and not args.no_configs:
         n_fresh = 20
+        for k in range(150):                 # the chip at its working clocks first: what is measured is the poses, not the ramp
+            env.step_random(seed=3, step=1000 + k)
+        env.reset(mode="random", seed=0)
         env.reset_kernel_times()
         env.set_profiling(True, kernels=[L.K_RAYCAST])
         env.sync()
@@ -738,12 +741,9 @@ def main():
         env.set_profiling(False)
         fresh = {"steps": n_fresh, "ms_per_step": dtf / n_fresh * 1e3, "env_steps_per_s": shard.num_envs * n_fresh / dtf,
                  "raycast_ms": round(env.kernel_times()["rc_raycast_kernel"]["avg_ms"], 4),
-                 "note": "the first 20 steps after reset(mode='random'), no settling, host-timed with the scan's launch timers on"}
+                 "note": "the first 20 steps after reset(mode='random') - no settling of the poses; the GPU itself kept busy by 150 steps "
+                         "before that reset - host-timed with the scan's launch timers on"}
         env.reset(mode="random", seed=0)
-    # the synthetic data is a random-action rollout that HAS SETTLED
-    for k in range(args.settle):
-        env.step_random(seed=2, step=k)
-    env.sync()
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     via = args.gather_via
     abi_ranks = None
@@ -838,6 +838,17 @@ def main():
     gather = make_collector(gather_mode)
     if gather_mode == "sharded":
         step_no += gather.prefill(step_no)
+    # The synthetic data is a random-action rollout that HAS SETTLED, and the chip is at its working clocks: `--settle` untimed
+    # steps of the very loop that is timed, right in front of the warm-up.  Two things ride on them: the cars
+    # leave the post-reset poses (long rays), and the GPU leaves the power state an idle spell puts it into - after 0.5 s
+    # without work (a ring allocation, a collective's set-up) the scan runs up to 30 % slower for about 25 ms
+    # (profiles/r04_l_idle_ramp.txt).  Every secondary leg does the same (`preheat`).
+    def preheat(g, k0, n=None):
+        n = args.settle if n is None else n
+        for k in range(n):
+            g.step(k0 + k)
+        return n
+    step_no += preheat(gather, step_no)
     for k in range(args.warmup):
         gather.step(step_no + k)
     step_no += args.warmup
@@ -990,6 +1001,7 @@ def main():
     with guard.leg("action_repeat_4"):
         r4_steps = max(args.steps // 4, 5)
         g = make_collector("none")
+        step_no += preheat(g, step_no, 40)
         dt4 = timed(g, step_no, r4_steps, repeat=4)
         step_no += r4_steps
         if rank == 0:
@@ -1005,11 +1017,10 @@ def main():
             g = make_collector(gather_mode)
             if gather_mode == "sharded":
                 step_no += g.prefill(step_no)
-            for k in range(5):
-                g.step(step_no + k)
+            step_no += preheat(g, step_no)
             finish(g)
-            t = timed(g, step_no + 5, n_long)
-            step_no += 5 + n_long
+            t = timed(g, step_no, n_long)
+            step_no += n_long
             g.close()
             if rank == 0:
                 out["gather_modes"][gather_mode]["steady_state"] = {"steps": n_long, "ms_per_step": t / n_long * 1e3,
@@ -1033,11 +1044,10 @@ def main():
                 if m in ("batch", "sharded"):
                     step_no += g.prefill(step_no)
                     n_leg = max(n_leg, 2 * g.batch_every)        # (a leg without a batch in it would not be this payload)
-                for k in range(3):
-                    g.step(step_no + k)
+                step_no += preheat(g, step_no)
                 finish(g)
-                t = timed(g, step_no + 3, n_leg)
-                step_no += 3 + n_leg
+                t = timed(g, step_no, n_leg)
+                step_no += n_leg
                 e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
                 e.update(ms_per_step=t / n_leg * 1e3, env_steps_per_s=total_envs * n_leg * args.repeat / t, steps=n_leg,
                          includes=g.includes)
