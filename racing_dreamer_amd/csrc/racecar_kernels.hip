@@ -1851,10 +1851,24 @@ __device__ __forceinline__ uint32_t mad_hi16_s(uint32_t y, uint32_t pitch, uint3
     asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(y), "s"(pitch), "v"(c));
     return r;
 }
-__device__ __forceinline__ uint32_t lshl_or_v(uint32_t a, uint32_t sh, uint32_t c) {              // (a << sh) | c as ONE instruction
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(sh), "v"(c));
-    return r;
+// byte BYTE of acc = low byte of (v >> sh), the other bytes of acc kept: extraction and packing of a pixel in ONE instruction
+// (sub-dword addressing writes the result into the byte lane; the bits above the wanted one are cleared once per word)
+template <int BYTE>
+__device__ __forceinline__ uint32_t shr_into_byte(uint32_t acc, uint32_t sh, uint32_t v) {
+    if (BYTE == 0) {
+        asm("v_lshrrev_b32 %0, %1, %2" : "=v"(acc) : "v"(sh), "v"(v));
+    } else if (BYTE == 1) {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(sh), "v"(v));
+    } else if (BYTE == 2) {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(sh), "v"(v));
+    } else {
+        asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(acc) : "v"(sh), "v"(v));
+    }
+    return acc;
+}
+template <int I>
+__device__ __forceinline__ void patch_put(uint32_t (&words)[4], uint32_t sh, uint32_t v) {
+    words[I >> 2] = shr_into_byte<I & 3>(words[I >> 2], sh, v);
 }
 struct PatchConst {          // per car, all in vector registers (see above)
     int a, b;                // pixel step
@@ -1863,50 +1877,50 @@ struct PatchConst {          // per car, all in vector registers (see above)
     uint32_t zero_addr;      // LDS address of the all-zero word behind the bitmap
     uint32_t three, one;     // the widths of the two bit-field extracts
     uint32_t sixteen;
-    uint32_t sh[4];          // 0, 8, 16, 24: where a pixel goes in its word
+    uint32_t ones;           // 0x01010101: bit 0 of every pixel byte
 };
 
 // One 16-pixel run: taps (X, Y) += (a, b).  CLAMP: coordinates are forced into the grid first - a tap left of / below
 // the grid has a negative coordinate, i.e. a huge unsigned one, and clamps like one beyond the far edge to the last
 // column / row, which is never drivable (rc_load_track clears the bitmap's outermost ring; so does the oracle).
-// Per pixel: add, add (full rate), shift (full), multiply-add (half), bit index (half), LDS byte read, bit extract (half),
-// pack (half, 3 of 4 pixels) = 6.75 vector instructions, 3.75 of them half rate: 16 cycles of a SIMD's issue.
+// Per pixel: add, add, shift, multiply-add, bit index, LDS byte read, shift-into-its-byte-lane (sub-dword addressing: the
+// extract and the pack in one instruction), + one mask per word = 6.25 vector instructions.
+template <bool CLAMP, bool TESTED, int I>
+struct PatchStep {
+    static __device__ __forceinline__ void run(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, const PatchConst &k,
+                                               uint32_t pitch_b, uint32_t (&words)[4]) {
+        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, k.xmax) : (uint32_t)X;
+        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, k.ymax) : (uint32_t)Y;
+        uint32_t addr = mad_hi16_s(yc, pitch_b, xc >> 19);                        // iy * pitch + ix / 8
+        if (TESTED) {
+            // inside the window <=> both window-relative coordinates (unsigned: below the window = huge) are <= 220 cells - 1 ulp
+            const uint32_t far = max((uint32_t)X - k.wx, (uint32_t)Y - k.wy);
+            addr = far <= k.span ? addr : k.zero_addr;
+        }
+        const uint32_t byte = lds[addr];
+        patch_put<I>(words, bfe_u32(xc, k.sixteen, k.three), byte);              // byte I & 3 of its word = byte >> (ix % 8)
+        PatchStep<CLAMP, TESTED, I + 1>::run(lds, X + k.a, Y + k.b, k, pitch_b, words);
+    }
+};
+template <bool CLAMP, bool TESTED>
+struct PatchStep<CLAMP, TESTED, 16> {
+    static __device__ __forceinline__ void run(const __attribute__((address_space(3))) uint8_t *, int, int, const PatchConst &k, uint32_t,
+                                               uint32_t (&words)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) words[j] &= k.ones;                            // keep bit 0 of every byte
+    }
+};
 template <bool CLAMP>
 __device__ __forceinline__ void patch_run(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, const PatchConst &k,
                                           uint32_t pitch_b, uint32_t (&words)[4]) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, k.xmax) : (uint32_t)X;
-        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, k.ymax) : (uint32_t)Y;
-        const uint32_t addr = mad_hi16_s(yc, pitch_b, xc >> 19);                  // iy * pitch + ix / 8
-        const uint32_t byte = lds[addr];
-        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, k.sixteen, k.three), k.one);   // bit ix % 8
-        if ((i & 3) == 0) words[i >> 2] = bit;
-        else words[i >> 2] = lshl_or_v(bit, k.sh[i & 3], words[i >> 2]);
-        X += k.a;
-        Y += k.b;
-    }
+    PatchStep<CLAMP, false, 0>::run(lds, X, Y, k, pitch_b, words);
 }
 
 // The same with every tap tested against the crop window (the corner runs of a car whose window corner cuts them).
 template <bool CLAMP>
 __device__ __forceinline__ void patch_run_tested(const __attribute__((address_space(3))) uint8_t *lds, int X, int Y, const PatchConst &k,
                                                  uint32_t pitch_b, uint32_t (&words)[4]) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        // inside the window <=> both window-relative coordinates (unsigned: below the window = huge) are <= 220 cells - 1 ulp
-        const uint32_t far = max((uint32_t)X - k.wx, (uint32_t)Y - k.wy);
-        const bool ok = far <= k.span;
-        const uint32_t xc = CLAMP ? min_u32((uint32_t)X, k.xmax) : (uint32_t)X;
-        const uint32_t yc = CLAMP ? min_u32((uint32_t)Y, k.ymax) : (uint32_t)Y;
-        const uint32_t addr = mad_hi16_s(yc, pitch_b, xc >> 19);
-        const uint32_t byte = lds[ok ? addr : k.zero_addr];
-        const uint32_t bit = bfe_u32(byte, bfe_u32(xc, k.sixteen, k.three), k.one);
-        if ((i & 3) == 0) words[i >> 2] = bit;
-        else words[i >> 2] = lshl_or_v(bit, k.sh[i & 3], words[i >> 2]);
-        X += k.a;
-        Y += k.b;
-    }
+    PatchStep<CLAMP, true, 0>::run(lds, X, Y, k, pitch_b, words);
 }
 
 // ---- lidar_occupancy, ONE WAVE PER CAR -----------------------------------------------------------------------------
@@ -1946,7 +1960,7 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const PatchImage &i
     k.wy = pin_vgpr((uint32_t)(icy - RCS_PATCH_WINDOW_I) << 16);
     k.span = pin_vgpr(((uint32_t)(2 * RCS_PATCH_WINDOW_I) << 16) - 1u);
     k.three = pin_vgpr(3u); k.one = pin_vgpr(1u); k.sixteen = pin_vgpr(16u);
-    k.sh[0] = 0u; k.sh[1] = pin_vgpr(8u); k.sh[2] = k.sixteen; k.sh[3] = pin_vgpr(24u);
+    k.ones = pin_vgpr(0x01010101u);
     const int x00 = ((63 * (-a - b)) >> 1) + icx * 65536, y00 = ((63 * (a - b)) >> 1) + icy * 65536;      // scalar
     const int rl = (int)(lane >> 2), cb = (int)(lane & 3u);
     const bool corner_first = cb == 0 || cb == 3;          // this lane's corner run is in group 0 (else in group 3)
@@ -2007,6 +2021,8 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const PatchImage &i
             store(s, w);
         }
     }
+    // (selecting the ADDRESS instead of the data - one select per store, each instruction then writing half of group 0's and half of
+    // group 3's lines - saves 33 instructions per car and gains nothing: 0.0707 against 0.0701 ms, HBM writes 1.018 x; round 4)
     uint32_t g0[4], g3[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

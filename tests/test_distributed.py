@@ -1,5 +1,7 @@
 """Multi-GPU host logic on CPU: env sharding and the trajectory all-gather over gloo, world_size 2."""
+import json
 import os
+import subprocess
 import socket
 import sys
 
@@ -238,3 +240,44 @@ def test_bench_starts_its_own_ranks_and_reports_their_failure():
     assert r.returncode not in (0, 2), r.stderr[-1500:]          # (2 was round 2's "needs torch.distributed.run")
     # (the launcher ends the second rank as soon as the first has failed: its own message may or may not have been printed)
     assert r.stderr.count("No HIP GPUs are available") >= 1 and "{" not in r.stdout
+
+
+def _run_guard_snippet(body, timeout=60):
+    code = ("import sys, time, json; sys.path.insert(0, %r); import bench\n" % ROOT) + body
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout)
+
+
+def test_line_guard_prints_the_one_line_whatever_a_later_leg_does():
+    """bench.py's LineGuard without a GPU: once armed with the headline, (a) a leg that raises at N = 1 is recorded and the run
+    goes on, the final line carries `leg_errors`; (b) a leg that overruns its deadline ends the process with rc 0 and the line
+    with `aborted`; (c) before it is armed - the headline leg itself - an exception is an exception."""
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 30.0)
+line = {"metric": "m", "value": 1.0}
+g.arm(line)
+with g.leg("configs"):
+    raise RuntimeError("boom")
+with g.leg("tracks"):
+    line["tracks"] = [1, 2]
+g.emit()
+''')
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["value"] == 1.0 and out[0]["tracks"] == [1, 2]
+    assert "boom" in out[0]["leg_errors"]["configs"] and "aborted" not in out[0]
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 1.0)
+g.arm({"metric": "m", "value": 2.0})
+with g.leg("cpu_baseline"):
+    time.sleep(30)
+print("not reached")
+''')
+    assert r.returncode == 0 and "not reached" not in r.stdout, (r.stdout, r.stderr)
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["value"] == 2.0 and out[0]["aborted"]["leg"] == "cpu_baseline" and "deadline" in out[0]["aborted"]["reason"]
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 30.0)
+with g.leg("headline"):
+    raise RuntimeError("the headline itself")
+''')
+    assert r.returncode != 0 and "the headline itself" in r.stderr and not r.stdout.strip()
