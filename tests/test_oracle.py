@@ -370,7 +370,7 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
     out = env.step(act)
     wall, opp = np.asarray(out["wall_collision"]).reshape(n, cars), np.asarray(out["opponent_collision"]).reshape(n, cars)
     assert int(wall.sum()) == 0
-    if track_name != "columbia":            # (columbia's centre line folds at the start line: DESIGN.md 2, known)
+    if track_name != "columbia":            # (columbia's centre line folds in its last four bins: DESIGN.md 2 item 6, known)
         assert int(opp.sum()) == 0
     # a finished env draws a NEW pose (episode counter in the Philox counter)
     env2 = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=64, cars_per_env=cars))
