@@ -1804,35 +1804,19 @@ __global__ __launch_bounds__(256) void rc_raycast_car_stamps_kernel(RcParams p, 
 // X = X00 + c a + r b, Y = Y00 + c b - r a.  One lane renders 16 adjacent pixels of a row (a quarter row) and stores
 // them as one 16-byte vector; per pixel that is two integer adds, and because the start cell is folded into X and Y the
 // byte address of the tap in the LDS bitmap is one shift and one 16 x 16-bit multiply-add that reads Y's high half
-// directly: add, add, shift, mad, bit index, LDS byte read, bit extract, pack = 7 vector instructions per pixel
-// (20 in the fp32 form this replaces).  The window / grid test is hoisted out of the pixel loop: the valid taps of a
+// directly: add, add, shift, mad, bit index, LDS byte read, shift into the pixel's byte lane = 6 vector instructions per
+// pixel (20 in the fp32 form this replaces).  The window / grid test is hoisted out of the pixel loop: the valid taps of a
 // run lie in the rectangle window-intersected-with-grid, which is convex, so a run whose two end taps are valid
 // is valid throughout - a wave whose 64 runs all pass that test takes the test-free loop; the others (runs that
-// cross a rotated corner of the window or leave the map) take the loop that tests every tap (14 per pixel).
+// cross a rotated corner of the window) take the loop that tests every tap (11 per pixel).
 __device__ __forceinline__ uint32_t bfe_u32(uint32_t v, uint32_t offset, uint32_t width) {       // offset, width mod 32
     uint32_t r;
     asm("v_bfe_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(offset), "v"(width));
     return r;
 }
-__device__ __forceinline__ uint32_t lshl_or(uint32_t a, int sh, uint32_t c) { return (a << sh) | c; }
 __device__ __forceinline__ int mad_i24(int a, int b, int c) {
     int r;
     asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t mad_hi16(uint32_t y, uint32_t pitch, uint32_t c) {           // (y >> 16) * pitch + c
-    uint32_t r;
-    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(y), "s"(pitch), "v"(c));
-    return r;
-}
-__device__ __forceinline__ unsigned long long cmp_le_u32(uint32_t a, uint32_t b) {      // lane mask of a <= b
-    unsigned long long m;
-    asm("v_cmp_le_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "s"(b));
-    return m;
-}
-__device__ __forceinline__ uint32_t select_mask(unsigned long long m, uint32_t a, uint32_t b) {   // m ? a : b
-    uint32_t r;
-    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
     return r;
 }
 
@@ -1972,13 +1956,13 @@ __device__ __forceinline__ void patch_car(const RcParams &p, const PatchImage &i
     auto ends_inside = [&](int X, int Y) {
         const uint32_t f0 = max((uint32_t)X - k.wx, (uint32_t)Y - k.wy);
         const uint32_t f1 = max((uint32_t)(X + 15 * k.a) - k.wx, (uint32_t)(Y + 15 * k.b) - k.wy);
-        return max(f0, f1) <= k.span;
+        return (uint32_t)max(f0, f1) <= k.span;
     };
     // CLAMP cars (the window is not wholly inside the grid): a slot whose 64 runs all have BOTH end taps inside the grid - a
     // rectangle, convex - has every tap inside it and takes the loop without the two clamps per pixel; the others clamp
     auto slot_in_grid = [&](int X, int Y) {
         if (!CLAMP) return true;
-        const uint32_t fx = max((uint32_t)X, (uint32_t)(X + 15 * k.a)), fy = max((uint32_t)Y, (uint32_t)(Y + 15 * k.b));
+        const uint32_t fx = max((uint32_t)X, (uint32_t)(X + 15 * (int)k.a)), fy = max((uint32_t)Y, (uint32_t)(Y + 15 * (int)k.b));
         return __builtin_amdgcn_ballot_w64(fx > k.xmax || fy > k.ymax) == 0;
     };
     // piece (row, column block) of the car's 4 KB lies at 16-byte index 4 row + block: groups 0 - 2 at 64 g + lane, group 3
