@@ -243,15 +243,21 @@ class LineGuard:
         finally:
             self.leg_name, self.deadline = None, None
 
-    def emit(self):
+    def emit(self, shutdown_s=30.0):
+        """Print the line (rank 0, once).  The watchdog stays on for the shutdown that follows - the closing barrier, the
+        process group's destruction: a rank that never arrives there must not turn a finished run into a time-out - and ends
+        the process quietly (rc 0) if that takes longer than `shutdown_s`; `done()` switches it off."""
         with self.lock:
-            self._stop = True
-            self.deadline = None
-            if self.rank == 0 and not self.printed:
+            if self.rank == 0 and not self.printed and self.line is not None:
                 if self.errors:
                     self.line["leg_errors"] = self.errors
                 print(json.dumps(self.line), flush=True)
                 self.printed = True
+            self.leg_name, self.deadline = "shutdown", time.monotonic() + shutdown_s
+
+    def done(self):
+        self._stop = True
+        self.deadline = None
 
 
 def _checksum(t):
@@ -991,7 +997,8 @@ def main():
         gather = None
     if checks and checks[gather_mode]["ok"] is False:
         guard.emit()
-        print(f"bench.py: rank {rank}: a gathered record differs from what its sender sent: {checks}", file=sys.stderr)
+        print(f"bench.py: rank {rank}: a gathered record differs from what its sender sent: {checks}", file=sys.stderr, flush=True)
+        guard.done()                   # (a failed self-check of the headline payload is the one thing that fails the run: exit 4, not 0)
         if distributed:
             dist.barrier()
         sys.exit(4)
@@ -1132,6 +1139,7 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    guard.done()
     if any(c["ok"] is False for c in checks.values()):
         print(f"bench.py: rank {rank}: a gathered record of a secondary payload differs from what its sender sent: {checks}", file=sys.stderr)
 

@@ -259,12 +259,14 @@ with g.leg("configs"):
     raise RuntimeError("boom")
 with g.leg("tracks"):
     line["tracks"] = [1, 2]
-g.emit()
+g.emit(shutdown_s=1.0)
+time.sleep(5)            # a shutdown that hangs (a rank that never reaches the closing barrier): the process ends, rc 0, one line
+print("not reached")
 ''')
     assert r.returncode == 0, r.stderr
     out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(out) == 1 and out[0]["value"] == 1.0 and out[0]["tracks"] == [1, 2]
-    assert "boom" in out[0]["leg_errors"]["configs"] and "aborted" not in out[0]
+    assert "boom" in out[0]["leg_errors"]["configs"] and "aborted" not in out[0] and "not reached" not in r.stdout
     r = _run_guard_snippet('''
 g = bench.LineGuard(0, 1, 1.0)
 g.arm({"metric": "m", "value": 2.0})
