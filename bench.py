@@ -312,7 +312,7 @@ class Gatherer:
         env = self.env
         if self.mode == "full-u16":
             return env.compact
-        view = env._arena_view if self.arenas[self._k] is None else self.arenas[self._k]
+        view = env._arena_view if (self.arenas is None or self.arenas[self._k] is None) else self.arenas[self._k]
         if self.mode == "full":
             return view[:env.slab.numel()]
         off = env.summary_slab.data_ptr() - env._arena_view.data_ptr()
