@@ -38,3 +38,21 @@ gen = torch.Generator(device=env.device); gen.manual_seed(1)
 fields = ("lidar", "action", "reward", "discount")
 if slots >= 52:
     timed("sample(50, 50)         ", lambda k: ring.sample(50, 50, fields=fields, generator=gen), reps=20)
+if slots >= 52:
+    lay = env.sample_batch_layout(fields, 50, 50)
+    out = torch.empty(lay["total"] + 64, dtype=torch.uint8, device=env.device)
+    out = out[(-out.data_ptr()) % 64:][:lay["total"]]
+    timed("sample_packed(50, 50)  ", lambda k: ring.sample_packed(50, 50, fields=fields, generator=gen, out=out, layout=lay), reps=50)
+    import time as _t
+    torch.cuda.synchronize(); t0 = _t.perf_counter()
+    for k in range(200):
+        ring.sample_packed(50, 50, fields=fields, generator=gen, out=out, layout=lay)
+    host = (_t.perf_counter() - t0) / 200 * 1e3
+    torch.cuda.synchronize()
+    print(f"sample_packed: {host:.4f} ms of host time per call (enqueue only)")
+    t0 = _t.perf_counter()
+    for k in range(50):
+        ring.sample(50, 50, fields=fields, generator=gen, check=False)
+    host = (_t.perf_counter() - t0) / 50 * 1e3
+    torch.cuda.synchronize()
+    print(f"sample(check=False): {host:.4f} ms of host time per call (enqueue only)")
