@@ -188,7 +188,20 @@ class TrajectoryRing:
             native = hasattr(self.env, "sample_windows") and self.buffer.is_cuda
         if native:                          # (the draw comes from Philox on the device, keyed by the generator's seed and a counter)
             seed = generator.initial_seed() if generator is not None else 0x5eed
-            return self._sample_native(batch, length, names, seed, reset_rows, max_tries, check, defer)
+            if defer or not hasattr(self.env, "sample_batch"):
+                return self._sample_native(batch, length, names, seed, reset_rows, max_tries, check, defer)
+            # one native call into one packed buffer (rc_sample_batch), then views: 0.017 ms for 50 x 50 windows where the
+            # three launches + torch fix-ups of `_sample_native` take 0.14
+            buf, layout = self.sample_packed(batch, length, fields=names, generator=generator, reset_rows=reset_rows, max_tries=max_tries)
+            out = self.unpack(buf, layout)
+            meta = out.pop("meta")
+            failed = out.pop("failed")
+            if check and int(failed.item()):
+                raise RuntimeError(f"could not find {batch} windows of {length} records without an episode boundary")
+            car = meta[:, 1].long()
+            out["env"], out["car"] = car // self.env.cars_per_env, car % self.env.cars_per_env
+            out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+            return out
         dev = self.buffer.device
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
         ar = torch.arange(length, device=dev)

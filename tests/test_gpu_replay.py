@@ -240,7 +240,7 @@ def test_windows_drawn_on_the_device_are_the_rows_they_say_and_uniform():
     # the same draw as ONE native call into ONE packed buffer (rc_sample_batch: the sampler, both kinds of row gather and
     # the reset rows in a memset and two launches): identical fields, identical meta
     ring._draws = 100
-    ref = ring.sample(batch, length, fields=fields, generator=g)
+    ref = ring.finish_sample(ring.sample(batch, length, fields=fields, generator=g, defer=True))   # the three-launch path + torch fix-ups
     ring._draws = 100
     buf, lay = ring.sample_packed(batch, length, fields=fields, generator=g)
     pk = TrajectoryRing.unpack(buf, lay)
