@@ -163,18 +163,21 @@ class LineGuard:
     def __init__(self, rank, world, timeout_s):
         self.rank, self.world, self.timeout = rank, world, float(timeout_s)
         self.line, self.store = None, None
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()
         self.printed = False
         self.leg_name, self.deadline = None, None
         self.errors = {}
         self._stop = False
+        self._sigterm = False
         self.armed = False
 
     def arm(self, line, store=None):
         self.line, self.store, self.armed = line, store, True
         threading.Thread(target=self._watch, daemon=True).start()
         try:
-            signal.signal(signal.SIGTERM, lambda *_: self.finalise("signal", "SIGTERM"))
+            # the handler runs in the main thread, possibly while that thread is inside emit() / finalise() holding the lock:
+            # it only raises a flag, the watchdog thread prints the line
+            signal.signal(signal.SIGTERM, lambda *_: setattr(self, "_sigterm", True))
         except ValueError:
             pass
 
@@ -191,6 +194,8 @@ class LineGuard:
     def _watch(self):
         while not self._stop:
             time.sleep(0.25)
+            if self._sigterm:
+                self.finalise("signal", "SIGTERM")
             d, name = self.deadline, self.leg_name
             if d is not None and time.monotonic() > d:
                 self.finalise(name, f"exceeded its deadline of {self.timeout:.0f} s")
@@ -412,7 +417,8 @@ class ShardedCollector:
         discount drawn on the device from the ranks' rings (`ShardedReplay.draw`) and all-gathered as ONE packed buffer
         (`exchange`): the reference's cadence of 100 batches of 50 x 50 per 1 000 env steps (dreamer/dream.py:80-83).
     Copies and collectives run on a SIDE stream behind one event per step: the env's stream records events and never waits
-    for the links (except before it rewrites a ring slot the side stream has not finished with: `capacity` steps later)."""
+    for the links - except before it rewrites a ring slot: then it waits for the event behind the RETIREMENT of the collective
+    that read that slot (see `step`)."""
 
     FIELDS = ("lidar", "action", "reward", "discount")
 
@@ -456,6 +462,10 @@ class ShardedCollector:
         if summary:
             self.tg = (TrajectoryGather(env.summary_slab, stage=False, depth=min(8, capacity - 4)) if self.summary_every == 1 else
                        TrajectoryGather(env.summary_slab, every=self.summary_every, stage=True, depth=2))
+        # hand-overs between the one that issues a slot's in-place collective and the first whose event is behind it (see step)
+        self.lag = self.tg.depth if (self.tg is not None and not self.tg.stage) else 0
+        if self.lag + 1 >= capacity:
+            raise ValueError(f"a ring of {capacity} slots cannot keep {self.lag} in-place collectives in flight")
         self.n, self.batches, self.last_batch = 0, 0, None
         per_car = {"lidar": 4320, "action": 8, "reward": 4, "discount": 4}
         self.batch_bytes = self.windows // self.world * self.length * sum(per_car[f] for f in self.FIELDS)
@@ -502,8 +512,16 @@ class ShardedCollector:
     def step(self, k, repeat=None):
         torch = self.torch
         nxt = (self.ring.head + 1) % self.capacity
-        if self.ev_done[nxt] is not None:                    # the side stream has read what this slot held `capacity` steps ago
-            self.env.stream.wait_event(self.ev_done[nxt])
+        # Before slot `nxt` is rewritten, whatever read it `capacity` steps ago must be over.  ev_done[s] is recorded on the side
+        # stream right after the hand-over of slot s, and by then the side stream is only behind the collectives
+        # `TrajectoryGather._retire` waited for: those up to `depth` BEFORE the one just issued (an async collective runs on the
+        # process group's own stream; issuing it does not put the side stream behind it).  An in-place collective reads the ring
+        # slot itself, so the event that covers slot nxt's collective is the one recorded `depth` hand-overs after it (ADVICE r4:
+        # waiting on ev_done[nxt] alone let a rank that runs > capacity - depth steps ahead of a peer overwrite the source of a
+        # pending all-gather).  A staged hand-over copies the slot on the side stream at once: there ev_done[nxt] is the copy.
+        covered = (nxt + self.lag) % self.capacity
+        if self.ev_done[covered] is not None and self.ev_done[nxt] is not None:
+            self.env.stream.wait_event(self.ev_done[covered])
         self.ring.step_random(seed=1, step=k, repeat=repeat)
         if self.tg is not None:
             self._send_summary()

@@ -308,7 +308,10 @@ int rc_p2p_teardown(rc_env *env);
  * another device buffer of at least rc_arena_bytes(), 64-byte aligned; NULL = back to the handle's own arena.
  * Stream-ordered: the next rc_reset / rc_step / rc_set_pose writes there.  This is how a device-resident
  * trajectory ring is filled without copies - the step after Collect.step in the reference
- * (dreamer/wrappers.py:213-219, dreamer/tools.py:235-264): one arena per time slot, rotate before each step. */
+ * (dreamer/wrappers.py:213-219, dreamer/tools.py:235-264): one arena per time slot, rotate before each step.
+ * Lifetime: the arena a step wrote must stay allocated until the NEXT observation has been produced (small batches take
+ * the cars longest-scan-first and read the previous rows for that); after rc_set_arena(env, NULL, 0) nothing of a lent
+ * arena is read again, so that is the call to make before freeing one. */
 int rc_set_arena(rc_env *env, void *arena, size_t bytes);
 
 /* Rows out of a ring of arenas - the window gather of a replay sampler (the reference reads fixed-length windows out of

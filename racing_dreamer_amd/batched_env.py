@@ -467,7 +467,9 @@ class BatchedRaceEnv:
     def gather_rows(self, ring: torch.Tensor, slot_bytes: int, slots: torch.Tensor, cars: torch.Tensor, names) -> Dict[str, torch.Tensor]:
         """`rc_gather_rows`: for every row r the record of car `cars[r]` in ring slot `slots[r]` (int32 device tensors),
         the fields `names`, as one launch.  Returns name -> tensor [rows, ...] (views of one fresh buffer)."""
-        names = [n for n in names if n in _FIELD_VIEWS and n != "action_in" and n in self._host_layout]
+        unknown = [n for n in names if not (n in _FIELD_VIEWS and n != "action_in" and n in self._host_layout)]
+        if unknown:
+            raise ValueError(f"fields {unknown} are not recorded by this env")
         order = sorted(names, key=lambda n: _FIELD_VIEWS[n][0])
         mask = 0
         for n in order:
@@ -510,7 +512,9 @@ class BatchedRaceEnv:
         """Layout of the ONE buffer `sample_batch` fills (include/racecar_hip.h, rc_sample_batch): field sections in field
         order (64-byte aligned), then meta int32 [n_windows, 4], then the 64-byte failure block - `payload` bytes in all, what
         a sharded store exchanges - then the sampler's row indices; `total` bytes to allocate."""
-        names = [n for n in names if n in _FIELD_VIEWS and n != "action_in" and n in self._host_layout]
+        unknown = [n for n in names if not (n in _FIELD_VIEWS and n != "action_in" and n in self._host_layout)]
+        if unknown:
+            raise ValueError(f"fields {unknown} are not recorded by this env")
         order = sorted(names, key=lambda n: _FIELD_VIEWS[n][0])
         mask = 0
         for n in order:

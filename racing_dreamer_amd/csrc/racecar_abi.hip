@@ -1367,8 +1367,14 @@ int rc_reset_kernel_times(rc_env *env) {
 
 int rc_set_arena(rc_env *env, void *arena, size_t bytes) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
-    if (!arena) arena = env->arena;                                   // NULL: back to the handle's own arena
-    else {
+    if (!arena) {
+        arena = env->arena;                                           // NULL: back to the handle's own arena
+        // ... and the caller may free what it had lent (TrajectoryRing.detach does): the rows the last scan wrote - the cost
+        // keys of the small batches' next sort - must not be read from there any more; the sort falls back to index order
+        // until the next scan has written rows of its own
+        const char *own = (const char *)env->arena, *rows = (const char *)env->last_scan_rows;
+        if (rows != nullptr && !(rows >= own && rows < own + env->layout.total)) env->last_scan_rows = nullptr;
+    } else {
         if (bytes < env->layout.total) return fail(RC_ERR_INVALID, "arena too small: %zu < %zu", bytes, env->layout.total);
         if ((uintptr_t)arena % 64) return fail(RC_ERR_INVALID, "arena must be 64-byte aligned");
     }

@@ -44,8 +44,10 @@ class TrajectoryGather:
 
     ``launch(slab)`` hands over one record.  With ``stage=True`` (default) it is first snapshot into a staging buffer,
     so the producer may overwrite it at once, and every ``every``-th call starts ONE asynchronous collective over the
-    ``every`` snapshots taken since the last one (same bytes on the links, 1 / every of the launches); two staging
-    buffers take turns, so a collective has ``every`` steps to finish before its buffer is written again.  With
+    ``every`` snapshots taken since the last one (same bytes on the links, 1 / every of the launches); ``depth + 1``
+    staging buffers take turns: the buffer being filled for collective k + 1 was the source of collective k - depth, which
+    `_issue` retired before it issued collective k (two buffers were enough for depth 1 only: with depth 2 the copies for
+    collective k + 1 went into the source collective k - 1 could still be reading - ADVICE r4).  With
     ``stage=False`` (``every`` must be 1) the collective reads ``slab`` IN PLACE - no copy - and the caller alternates
     between source buffers (`BatchedRaceEnv.rotate_compact`, a pair of arenas, `TrajectoryRing`).
     ``depth`` = collectives allowed in flight: before collective k is issued, the caller's stream is put behind
@@ -76,10 +78,10 @@ class TrajectoryGather:
         flat = slab_like.reshape(-1)
         self.slab_numel = flat.numel()
         self.staging = [torch.empty(self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
-                        for _ in range(2)] if stage else None
+                        for _ in range(self.depth + 1)] if stage else None
         self.gathered_bufs = [torch.empty(self.world * self.every * flat.numel(), dtype=flat.dtype, device=flat.device)
                               for _ in range(self.depth + 1)]
-        self._pending = []       # [(work or None, view)] oldest first: issued, not yet waited for
+        self._pending = []       # [(work or None, view, source)] oldest first: issued, not yet waited for
         self._views = []         # views of the last depth + 1 collectives, newest last
         self._cur = 0            # staging buffer being filled
         self._k = 0              # snapshots in it
@@ -99,7 +101,7 @@ class TrajectoryGather:
         if self._k == self.every:
             k = self._k
             src = self.staging[self._cur][:k * n]
-            self._cur ^= 1
+            self._cur = (self._cur + 1) % len(self.staging)
             self._k = 0
             self._issue(src, k)
 
@@ -107,7 +109,7 @@ class TrajectoryGather:
         """Put the caller's stream behind every pending collective but the newest `keep` (work.wait() is a stream wait for
         the nccl backend, a host wait for gloo)."""
         while len(self._pending) > keep:
-            work, view = self._pending.pop(0)
+            work, view, _src = self._pending.pop(0)
             if work is not None:
                 work.wait()
             if self.consumer is not None:
@@ -126,9 +128,13 @@ class TrajectoryGather:
             out = torch.empty(self.world * host.numel(), dtype=host.dtype)
             dist.all_gather_into_tensor(out, host, group=self.group)
             dst.copy_(out)
-            self._pending.append((None, view))
+            self._pending.append((None, view, src))
             return
-        self._pending.append((dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True), view))
+        self._pending.append((dist.all_gather_into_tensor(dst, src, group=self.group, async_op=True), view, src))
+
+    def pending_sources(self) -> List[torch.Tensor]:
+        """The source buffers of the collectives issued and not yet retired (what nobody may write to now)."""
+        return [src for _w, _v, src in self._pending]
 
     def recent(self, back: int = 0) -> torch.Tensor:
         if not 0 <= back < len(self._views):
@@ -139,7 +145,7 @@ class TrajectoryGather:
         if self.stage and self._k:           # a partial batch (every rank holds the same number of snapshots)
             k, n = self._k, self.slab_numel
             src = self.staging[self._cur][:k * n]
-            self._cur ^= 1
+            self._cur = (self._cur + 1) % len(self.staging)
             self._k = 0
             self._issue(src, k)
         self._retire(0)

@@ -99,6 +99,16 @@ class TrajectoryRing:
         self.env.set_arena(None)
 
     # ------------------------------------------------------------------ reading
+    def _field_names(self, fields: Optional[Sequence[str]]) -> list:
+        """The fields of a draw: the default set narrowed to what this ring records, or exactly what the caller named - a
+        name the ring does not record is an error, not a silently shorter batch."""
+        if fields is None:
+            return [f for f in DEFAULT_SAMPLE_FIELDS if f in self.fields]
+        missing = [f for f in fields if f not in self.fields]
+        if missing:
+            raise ValueError(f"fields {missing} are not recorded by this ring (recorded: {sorted(self.fields)})")
+        return list(fields)
+
     def window_starts(self, length: int) -> int:
         """Number of distinct start times of a `length`-step window inside the filled part of the ring."""
         return max(self.count - length + 1, 0)
@@ -137,7 +147,7 @@ class TrajectoryRing:
                     head.masked_fill_(first.view(-1, *([1] * (head.dim() - 1))), value)
         car = meta[:, 1].long()
         out["env"], out["car"] = car // self.env.cars_per_env, car % self.env.cars_per_env
-        out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+        out["t0"], out["terminal"], out["first"] = meta[:, 0].long(), meta[:, 2] != 0, meta[:, 3] != 0
         return out
 
     def sample_packed(self, batch: int, length: int, fields: Optional[Sequence[str]] = None, generator: Optional[torch.Generator] = None,
@@ -147,7 +157,7 @@ class TrajectoryRing:
         gives the field views.  The form a sharded store sends: `ShardedReplay.exchange_packed`."""
         if self.window_starts(length) <= 0:
             raise ValueError(f"ring holds {self.count} records, a window needs {length}")
-        names = [f for f in (fields or DEFAULT_SAMPLE_FIELDS) if f in self.fields]
+        names = self._field_names(fields)
         if layout is None:
             layout = self.env.sample_batch_layout(names, batch, length)
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
@@ -177,13 +187,14 @@ class TrajectoryRing:
         the windows that stay inside one episode: no fresh record strictly inside, and a fresh LAST record only if it
         is the terminal transition of the window's episode (done = 1, written by auto-reset).  Returns field ->
         [batch, length, ...] (copies, on the ring's device) plus `env`, `car`, `t0` (ring age of the first record,
-        0 = oldest) and `terminal` (bool [batch]: the last row is such a terminal transition).  On a device ring the draw
+        0 = oldest), `terminal` (bool [batch]: the last row is such a terminal transition) and `first` (bool [batch]: the
+        window's first record starts an episode - the row `reset_rows` rewrites).  On a device ring the draw
         itself runs on the device (`native`, default there; `check=False` also drops the one host read of the failure count);
         `native=False` is the tensor-indexing form with torch's generator."""
         nstart = self.window_starts(length)
         if nstart <= 0:
             raise ValueError(f"ring holds {self.count} records, a window needs {length}")
-        names = [f for f in (fields or DEFAULT_SAMPLE_FIELDS) if f in self.fields]
+        names = self._field_names(fields)
         if native is None:
             native = hasattr(self.env, "sample_windows") and self.buffer.is_cuda
         if native:                          # (the draw comes from Philox on the device, keyed by the generator's seed and a counter)
@@ -200,7 +211,7 @@ class TrajectoryRing:
                 raise RuntimeError(f"could not find {batch} windows of {length} records without an episode boundary")
             car = meta[:, 1].long()
             out["env"], out["car"] = car // self.env.cars_per_env, car % self.env.cars_per_env
-            out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+            out["t0"], out["terminal"], out["first"] = meta[:, 0].long(), meta[:, 2] != 0, meta[:, 3] != 0
             return out
         dev = self.buffer.device
         oldest = (self.head + 1) % self.capacity if self.count == self.capacity else 0
@@ -251,8 +262,8 @@ class TrajectoryRing:
                 for name in OBSERVATION_FIELDS:               # the new episode's observation is not this episode's
                     if name in out:
                         out[name][terminal, -1] = out[name][terminal, -2]
+        first = self.fields["fresh"][slots[:, 0], e, c] != 0                   # window starts an episode
         if reset_rows:
-            first = self.fields["fresh"][slots[:, 0], e, c] != 0               # window starts an episode
             if "action" in out:
                 out["action"][first, 0] = 0.0
             if "reward" in out:
@@ -263,7 +274,7 @@ class TrajectoryRing:
                 out["time"][first, 0] = 0.0
             if "progress_total" in out:
                 out["progress_total"][first, 0] = -1.0
-        out["env"], out["car"], out["t0"], out["terminal"] = e, c, t0, terminal
+        out["env"], out["car"], out["t0"], out["terminal"], out["first"] = e, c, t0, terminal, first
         return out
 
 
@@ -281,7 +292,7 @@ class ShardedReplay:
         self.ring, self.group, self._dist = ring, group, dist
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
 
-    META = ("env", "car", "t0", "terminal")
+    META = ("env", "car", "t0", "terminal", "first")
 
     def draw(self, batch: int, length: int, fields: Optional[Sequence[str]] = None,
              generator: Optional[torch.Generator] = None, check: bool = True, defer: bool = False) -> Dict[str, torch.Tensor]:
@@ -312,7 +323,8 @@ class ShardedReplay:
             local = dict(local)
             car = local.pop("car").to(torch.int32) + local.pop("env").to(torch.int32) * self.ring.env.cars_per_env
             term = local.pop("terminal").to(torch.int32)
-            meta = torch.stack([local.pop("t0").to(torch.int32), car, term, torch.zeros_like(term)], 1)
+            first = local.pop("first").to(torch.int32)
+            meta = torch.stack([local.pop("t0").to(torch.int32), car, term, first], 1)
         per = int(meta.shape[0])
         batch = per * self.world
         local["meta"] = meta
@@ -341,7 +353,7 @@ class ShardedReplay:
         meta = out.pop("meta")
         car = meta[:, 1].long()
         out["env"], out["car"] = car // self.ring.env.cars_per_env, car % self.ring.env.cars_per_env
-        out["t0"], out["terminal"] = meta[:, 0].long(), meta[:, 2] != 0
+        out["t0"], out["terminal"], out["first"] = meta[:, 0].long(), meta[:, 2] != 0, meta[:, 3] != 0
         if getattr(self, "_rank_rows", None) is None or self._rank_rows.numel() != batch or self._rank_rows.device != flat_src.device:
             self._rank_rows = torch.arange(self.world, device=flat_src.device).repeat_interleave(per)
         out["rank"] = self._rank_rows

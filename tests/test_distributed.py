@@ -109,6 +109,21 @@ def _worker(rank, world, port, total_envs, q):
     assert [deep.recent(j)[:, 0].tolist() for j in range(4)] == [[66 - j + r for r in range(world)] for j in range(4)]
     with pytest.raises(IndexError):
         deep.recent(4)
+    # staged AND deep (bench.py's ShardedCollector with summary_every > 1 builds exactly this): the staging
+    # buffer a launch copies into is never the source of a collective still in flight, and every batch arrives whole
+    got = []
+    sd = TrajectoryGather(slab, every=2, stage=True, depth=2, consumer=lambda v: got.append(v[:, :, 0].clone()))
+    assert len(sd.staging) == 3
+    for k in range(11):
+        snap = slab.clone()
+        snap[0] = 100 + k + rank
+        busy = {t.untyped_storage().data_ptr() for t in sd.pending_sources()}
+        assert sd.staging[sd._cur].untyped_storage().data_ptr() not in busy
+        sd.launch(snap)
+        assert len(sd.pending_sources()) <= 2
+    sd.wait()
+    flat = [row for v in got for row in v.transpose(0, 1).tolist()]
+    assert flat == [[100 + k + r for r in range(world)] for k in range(11)]
     views = [slab_field_views(g[r], sh.num_envs, False) for r in range(world)]
     lidar = torch.cat([v["lidar"] for v in views]).numpy()
     reward = torch.cat([v["reward"] for v in views]).numpy()
@@ -188,14 +203,21 @@ def _replay_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from test_replay import FakeEnv
     from racing_dreamer_amd.replay import ShardedReplay, TrajectoryRing
-    env = FakeEnv(num_envs=4, cars=1)
+    env = FakeEnv(num_envs=4, cars=1, fresh_at={(3, 1), (5, 2), (4, 3)})
     ring = TrajectoryRing(env, capacity=8)
     ring.reset()
     for _ in range(9):
         ring.step()
         ring.fields["lidar"][ring.head] += 100.0 * rank          # mark this rank's records
     g = torch.Generator().manual_seed(10 + rank)
-    batch = ShardedReplay(ring).sample(batch=12, length=3, generator=g)
+    rep = ShardedReplay(ring)
+    batch = rep.sample(batch=12, length=3, generator=g)
+    # the view form carries the same windows' per-window integers, "starts an episode" included (it was all zeros)
+    local = rep.draw(12, 3, generator=torch.Generator().manual_seed(10 + rank))
+    views = rep.exchange(local, flat=False)
+    assert views["meta"].shape == (world, 6, 4)
+    assert torch.equal(views["meta"][rank, :, 3] != 0, local["first"]) and torch.equal(views["meta"][rank, :, 2] != 0, local["terminal"])
+    assert torch.equal(views["meta"][..., 3] != 0, views["fresh"][:, :, 0] != 0)
     q.put((rank, {k: v.numpy() for k, v in batch.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -219,10 +241,12 @@ def test_sharded_replay_gathers_the_training_batch_not_the_records():
     for k in a:
         assert np.array_equal(a[k], b[k]), k                      # the same global batch on both ranks
     assert a["lidar"].shape == (12, 3, 8) and a["rank"].tolist() == [0] * 6 + [1] * 6
+    assert np.array_equal(a["first"], a["fresh"][:, 0] != 0) and a["first"].any() and not a["first"].all()
     owner = (a["lidar"][:, 0, 0] >= 100.0).astype(int)              # rank 1 marked its records with + 100
     assert owner.tolist() == a["rank"].tolist()
     r = a["reward"]
-    assert np.all(r[:, 1:] - r[:, :-1] == 1.0)                      # windows are consecutive steps
+    assert np.all(r[:, 2] - r[:, 1] == 1.0)                         # windows are consecutive steps ...
+    assert np.all((r[:, 1] - r[:, 0] == 1.0) | a["first"]) and np.all(r[a["first"], 0] == 0.0)    # ... behind a reset row or not
 
 
 def test_bench_starts_its_own_ranks_and_reports_their_failure():

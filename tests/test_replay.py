@@ -115,8 +115,12 @@ def test_windows_never_contain_an_episode_start_after_their_first_record():
     assert torch.all(out["action"][starts, 0] == 0.0) and torch.all(out["reward"][starts, 0] == 0.0)
     assert torch.all(out["discount"][starts, 0] == 1.0)
     assert torch.all(out["action"][~starts] == 0.5) and torch.all(out["discount"][:, 1:] == 0.9)
+    # the flag itself travels with the batch (consumers of ShardedReplay.exchange(flat=False) read meta[..., 3])
+    assert torch.equal(out["first"], starts)
     raw = ring.sample(batch=64, length=4, generator=g, reset_rows=False)
-    assert torch.all(raw["action"] == 0.5)
+    assert torch.all(raw["action"] == 0.5) and torch.equal(raw["first"], raw["fresh"][:, 0] != 0)
+    with pytest.raises(ValueError, match="not recorded"):
+        ring.sample(batch=4, length=4, fields=("lidar", "no_such_field"))
 
 
 def test_terminal_transitions_are_sampled_as_the_last_row_of_a_window():
