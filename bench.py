@@ -740,7 +740,7 @@ def main():
     env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
                          device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
     if args.raycast_variant is not None:
-        L.check(env._lib.rc_set_raycast_variant(env._h, args.raycast_variant))
+        env.set_raycast_variant(args.raycast_variant)      # (variants 0-6: lab kernels, built on this request)
     for kv in args.debug_knob:
         name, _, val = kv.partition("=")
         env.debug_set(name, int(val))

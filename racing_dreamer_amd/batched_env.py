@@ -57,6 +57,14 @@ TASKS = {"maximize_progress": spec.TASK_MAX_PROGRESS, "max_progress": spec.TASK_
          "max_speed": spec.TASK_MAX_SPEED, "n_step_progress": spec.TASK_N_STEP_PROGRESS}
 
 
+def _ensure_lab() -> None:
+    """Build the lab library (scan variants 0-6, the stamps build) if the one on disk does not belong to the sources - the
+    request that `libracecar_lab.so` exists for.  libracecar_hip.so loads it itself, on the first launch of a lab kernel."""
+    from . import build
+    if build.lab_needs_build():
+        build.build_lab(verbose=False)
+
+
 class BatchedRaceEnv:
     def __init__(self, track: Union[str, Track], num_envs: int, cars_per_env: int = 1, obs_type: str = "lidar",
                  action_repeat: int = 1, seed: int = 0, device: int = 0, first_env: int = 0,
@@ -242,7 +250,10 @@ class BatchedRaceEnv:
         """0 = plain traversal, 1 = free-rectangle skipping, 2 = tuned skipping, 3 = tuned + packed block table
         in LDS, 4 = the same reading the table through L1/L2, 5 = per-cell distance table through L1/L2,
         6 = per-cell, per-quadrant free rectangles through L1/L2,
-        7 = the same with one wave per car (default).  All variants return identical results."""
+        7 = the same with one wave per car (default).  All variants return identical results.  Variants 0-6 are not in the
+        shipped library: they live in the lab library (csrc/racecar_lab.hip), which is compiled here on first request."""
+        if int(variant) != 7:
+            _ensure_lab()
         L.check(self._lib.rc_set_raycast_variant(self._h, int(variant)))
 
     # ------------------------------------------------------------------ half-size record + multi-GPU gather
@@ -389,6 +400,7 @@ class BatchedRaceEnv:
             L.check(self._lib.rc_debug_scan_stamps(self._h, None, 0))
             self._stamps = None
             return None
+        _ensure_lab()                    # the instrumented build is a lab kernel
         self._stamps = torch.zeros((n_waves, 32), dtype=torch.int64, device=self.device)
         L.check(self._lib.rc_debug_scan_stamps(self._h, self._stamps.data_ptr(), int(n_waves)))
         return self._stamps

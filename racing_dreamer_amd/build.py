@@ -11,7 +11,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libracecar_hip.so")
 SOURCES = ["racecar_kernels.hip", "racecar_abi.hip"]
-HEADERS = ["racecar_device.h", "racecar_internal.h", "racecar_spec.h", os.path.join("..", "..", "include", "racecar_hip.h")]
+HEADERS = ["racecar_device.h", "racecar_internal.h", "racecar_spec.h", "racecar_scan.h", os.path.join("..", "..", "include", "racecar_hip.h")]
+# The lab library: scan variants 0-6 and the instrumented build of the scan (racecar_lab.hip).  NOT part of the shipped
+# library; built by build_lab() - which tools/ and the variant tests call - and loaded by libracecar_hip.so on first use.
+LAB_PATH = os.path.join(LIB_DIR, "libracecar_lab.so")
+LAB_SOURCES = ["racecar_lab.hip"]
 # -ffp-contract=off: the env spec is "one IEEE fp32 operation per written operator" (DESIGN.md §2);
 # a fused multiply-add would break bit-exact parity with the CPU oracle.
 # -fno-slp-vectorize: packed fp32 (v_pk_*_f32) issues at half rate on gfx950, i.e. buys nothing over two scalar
@@ -31,7 +35,7 @@ def find_hipcc() -> str:
 BUILD_ID_MARK = b"RC_BUILD_ID="
 
 
-def source_hash(csrc: str = CSRC, flags=None) -> str:
+def source_hash(csrc: str = CSRC, flags=None, sources=None) -> str:
     """sha256 over the flags and the CONTENT of every source and header the library is made of (in a fixed order, each
     preceded by its name): the identity of a build.  It is compiled into the library (`-DRC_BUILD_ID`, `rc_build_id()`),
     so whether a library on disk belongs to the sources beside it is a question about contents, not about file times - a
@@ -39,7 +43,7 @@ def source_hash(csrc: str = CSRC, flags=None) -> str:
     import hashlib
     h = hashlib.sha256()
     h.update("\0".join(FLAGS if flags is None else flags).encode())
-    for name in SOURCES + HEADERS:
+    for name in (SOURCES if sources is None else sources) + HEADERS:
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(b"\0" + os.path.basename(name).encode() + b"\0" + f.read())
     return h.hexdigest()[:32]
@@ -74,8 +78,9 @@ NO_SPILL_KERNELS = ("rc_raycast_car_kernel", "rc_raycast_car_stamps_kernel", "rc
 MIN_WAVES_PER_SIMD = {"rc_raycast_car_kernel": 8, "rc_patch_car_kernel": 8}
 
 
-def check_resource_usage(remarks: str) -> None:
+def check_resource_usage(remarks: str, required=("rc_raycast_car_kernel", "rc_patch_car_kernel"), min_waves=None) -> None:
     """Parse `-Rpass-analysis=kernel-resource-usage` remarks; raise if a kernel of NO_SPILL_KERNELS spills."""
+    min_waves = MIN_WAVES_PER_SIMD if min_waves is None else min_waves
     import re
     name, problems, seen = None, [], set()
     for line in remarks.splitlines():
@@ -92,11 +97,11 @@ def check_resource_usage(remarks: str) -> None:
         seen.add(kernel)
         key, val = m.group(1), int(m.group(2))
         if key.startswith("Occupancy"):
-            if val < MIN_WAVES_PER_SIMD.get(kernel, 1):
-                problems.append(f"{name}: {val} waves/SIMD < {MIN_WAVES_PER_SIMD[kernel]}")
+            if val < min_waves.get(kernel, 1):
+                problems.append(f"{name}: {val} waves/SIMD < {min_waves[kernel]}")
         elif key != "SGPRs Spill" and val != 0:
             problems.append(f"{name}: {key} = {val}")
-    missing = [k for k in ("rc_raycast_car_kernel", "rc_patch_car_kernel") if k not in seen]
+    missing = [k for k in required if k not in seen]
     if missing:
         raise RuntimeError(f"resource-usage remarks not found for {missing}: cannot verify that the scan does not spill")
     if problems:
@@ -158,13 +163,13 @@ def check_async_load_registers(asm_text: str, kernels=("rc_raycast_car_kernel", 
     return checked
 
 
-def verify_scan_assembly(verbose: bool = True, csrc: str = CSRC) -> int:
+def verify_scan_assembly(verbose: bool = True, csrc: str = CSRC, source: str = None) -> int:
     """Compile the kernels to assembly once more (device only) and run check_async_load_registers on it."""
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "kernels.s")
         flags = [f for f in FLAGS if f not in ("-fPIC", "-shared")]
-        cmd = [find_hipcc(), *flags, "-S", "--cuda-device-only", os.path.join(csrc, SOURCES[0]), "-o", out]
+        cmd = [find_hipcc(), *flags, "-S", "--cuda-device-only", os.path.join(csrc, source or SOURCES[0]), "-o", out]
         r = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stderr[-4000:])
@@ -216,6 +221,44 @@ def build(force: bool = False, verbose: bool = True, csrc: str = CSRC, lib_path:
     return lib_path
 
 
+def build_lab(force: bool = False, verbose: bool = True, csrc: str = CSRC, lab_path: str = LAB_PATH) -> str:
+    """Compile the lab library (scan variants 0-6, the stamps build) unless the one at `lab_path` already carries the hash of
+    its sources: same flags, same refusals (no spills in a scan kernel, no register touched under an asynchronous load)."""
+    import time
+    want = source_hash(csrc, sources=LAB_SOURCES)
+    if not force and library_build_id(lab_path) == want:
+        if verbose:
+            print(f"[racing_dreamer_amd.build] reused {lab_path}: its build id {want} is the hash of the lab's sources and flags", flush=True)
+        return lab_path
+    os.makedirs(os.path.dirname(lab_path), exist_ok=True)
+    tmp = lab_path + ".new"
+    cmd = [find_hipcc(), *FLAGS, f'-DRC_BUILD_ID="{want}"', "-Rpass-analysis=kernel-resource-usage",
+           *[os.path.join(csrc, s) for s in LAB_SOURCES], "-o", tmp]
+    if verbose:
+        print("[racing_dreamer_amd.build]", " ".join(cmd), flush=True)
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stderr[-8000:])
+        raise subprocess.CalledProcessError(r.returncode, cmd)
+    try:
+        check_resource_usage(r.stderr, required=("rc_raycast_car_stamps_kernel", "rc_raycast_kernel"), min_waves={})
+        verify_scan_assembly(verbose, csrc, source=LAB_SOURCES[0])
+    except RuntimeError:
+        os.remove(tmp)
+        raise
+    os.replace(tmp, lab_path)
+    if verbose:
+        print(f"[racing_dreamer_amd.build] compiled {lab_path} in {time.time() - t0:.1f} s (build id {want})", flush=True)
+    return lab_path
+
+
+def lab_needs_build(lab_path: str = LAB_PATH, csrc: str = CSRC) -> bool:
+    return library_build_id(lab_path) != source_hash(csrc, sources=LAB_SOURCES)
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
     print(LIB_PATH)
+    if "--lab" in sys.argv:
+        print(build_lab(force="--force" in sys.argv))

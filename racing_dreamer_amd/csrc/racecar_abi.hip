@@ -1760,6 +1760,10 @@ int rc_scan_overruns(rc_env *env, uint64_t *count) {
 int rc_debug_scan_stamps(rc_env *env, uint64_t *stamps, int32_t n_waves) {
     if (!env) return fail(RC_ERR_INVALID, "env is NULL");
     if (stamps != nullptr && n_waves <= 0) return fail(RC_ERR_INVALID, "n_waves must be positive");
+    if (stamps != nullptr) {
+        const char *why = rck_lab_unavailable();                   // the instrumented build lives in the lab library
+        if (why != nullptr) return fail(RC_ERR_INVALID, "%s", why);
+    }
     env->launch.scan_stamps = reinterpret_cast<unsigned long long *>(stamps);
     env->launch.scan_stamp_waves = stamps ? n_waves : 0;
     return RC_OK;
@@ -1789,6 +1793,10 @@ int rc_set_raycast_variant(rc_env *env, int32_t variant) {
         return fail(RC_ERR_INVALID, "variants 1/2 need bitmap + free-block table in the 160 KiB LDS; this track is too large");
     if (variant != 7 && env->compact_slab)
         return fail(RC_ERR_INVALID, "the uint16 LiDAR copy (rc_set_compact_slab) is written by variant 7 only");
+    if (variant != 7) {
+        const char *why = rck_lab_unavailable();                   // variants 0-6 live in the lab library (racecar_lab.hip)
+        if (why != nullptr) return fail(RC_ERR_INVALID, "%s", why);
+    }
     env->launch.raycast_variant = variant;
     set_launch_geometry(env);
     return RC_OK;

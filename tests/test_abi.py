@@ -191,3 +191,29 @@ def test_a_changed_source_is_rebuilt_whatever_the_file_times_say(hip_lib, tmp_pa
     # a library without an id (or a truncated file) is never taken for current
     (pkg / "lib" / "junk.so").write_bytes(b"\x7fELF" + b"\0" * 64)
     assert build.library_build_id(str(pkg / "lib" / "junk.so")) is None and build.needs_build(str(pkg / "lib" / "junk.so"), csrc)
+
+
+def test_the_shipped_library_carries_no_lab_kernels(hip_lib):
+    """the superseded scan variants (rc_raycast_kernel<A, 0..6>), the instrumented "stamps" build and the dropped
+    direction-table experiment are not compiled into libracecar_hip.so; they live in libracecar_lab.so (csrc/racecar_lab.hip),
+    built on request with the same flags and the same refusals, found by the shipped library next to itself on first use."""
+    from racing_dreamer_amd import build
+    with open(build.LIB_PATH, "rb") as f:
+        shipped = f.read()
+    for name in (b"rc_raycast_kernelILi", b"28rc_raycast_car_stamps_kernelE", b"rc_build_dir_table_kernel", b"g_dir_table"):     # (mangled: kernel symbols)
+        assert name not in shipped, name
+    assert b"rc_raycast_car_kernelILi1ELb0ELb0E" in shipped                # the scan that is shipped
+    with open(os.path.join(build.CSRC, "racecar_kernels.hip")) as f:
+        text = f.read()
+    assert "RC_EXP_DIR_TABLE" not in text and "cast_ray_dda" not in text
+    lab = build.build_lab(verbose=False)
+    assert not build.lab_needs_build() and build.library_build_id(lab) == build.source_hash(sources=build.LAB_SOURCES)
+    import ctypes
+    h = ctypes.CDLL(lab)
+    for sym in ("rclab_launch_raycast", "rclab_set_lds_limits", "rclab_build_id"):
+        assert hasattr(h, sym), sym
+    with open(lab, "rb") as f:
+        blob = f.read()
+    assert b"rc_raycast_kernelILi1ELi0E" in blob and b"28rc_raycast_car_stamps_kernelE" in blob
+    # the two libraries are identified separately: a change of the lab's source does not make the shipped library stale
+    assert build.source_hash() != build.source_hash(sources=build.LAB_SOURCES)
