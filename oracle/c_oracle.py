@@ -24,7 +24,7 @@ class OcTrack(C.Structure):
     _fields_ = [("occ", _bp), ("ring", _bp), ("drv", _bp), ("progress", _fp), ("centerline", _fp), ("beams", _fp),
                 ("foot", _fp), ("h", C.c_int32), ("w", C.c_int32), ("n_centerline", C.c_int32),
                 ("org_x", C.c_float), ("org_y", C.c_float), ("res", C.c_float), ("inv_res", C.c_float),
-                ("tmax", C.c_float), ("spawn_w", _fp)]
+                ("tmax", C.c_float), ("spawn_w", _fp), ("spawn_safe", _ip)]
 
 
 class OcCfg(C.Structure):
@@ -73,7 +73,9 @@ def load():
         lib.oc_patch_range.argtypes = [P(OcTrack), P(OcState), C.c_void_p, C.c_int, C.c_int]
         lib.oc_random_actions.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.oc_spawn_width.argtypes = [P(OcTrack), C.c_void_p]
-        for f in (lib.oc_reset, lib.oc_step_range, lib.oc_raycast_range, lib.oc_patch_range, lib.oc_random_actions, lib.oc_spawn_width):
+        lib.oc_spawn_safe.argtypes = [P(OcTrack), C.c_void_p]
+        for f in (lib.oc_reset, lib.oc_step_range, lib.oc_raycast_range, lib.oc_patch_range, lib.oc_random_actions, lib.oc_spawn_width,
+                  lib.oc_spawn_safe):
             f.restype = None
         lib.oc_spin.argtypes = [C.c_uint64]
         lib.oc_spin.restype = C.c_uint64
@@ -108,10 +110,13 @@ class COracleEnv:
         self.trk = OcTrack(_ptr(k["occ"], _bp), _ptr(k["ring"], _bp), _ptr(k["drv"], _bp), _ptr(k["progress"], _fp),
                            _ptr(k["centerline"], _fp), _ptr(k["beams"], _fp), _ptr(k["foot"], _fp), self.H, self.W,
                            len(k["centerline"]), np.float32(origin[0]), np.float32(origin[1]),
-                           np.float32(resolution), inv_res, np.float32(ro.MAX_RANGE * inv_res), None)
+                           np.float32(resolution), inv_res, np.float32(ro.MAX_RANGE * inv_res), None, None)
         k["spawn_w"] = np.zeros(len(k["centerline"]), np.float32)      # the C port builds its own table (oc_spawn_width)
         self.lib.oc_spawn_width(C.byref(self.trk), k["spawn_w"].ctypes.data)
         self.trk.spawn_w = _ptr(k["spawn_w"], _fp)
+        k["spawn_safe"] = np.zeros(len(k["centerline"]), np.int32)     # ... and the anchors of multi-car starts (oc_spawn_safe)
+        self.lib.oc_spawn_safe(C.byref(self.trk), k["spawn_safe"].ctypes.data)
+        self.trk.spawn_safe = _ptr(k["spawn_safe"], _ip)
         self.B, self.A = cfg.num_envs, cfg.cars_per_env
         n = self.NC = self.B * self.A
         self.ccfg = OcCfg(self.B, self.A, cfg.first_env & 0xFFFFFFFF, cfg.task, cfg.laps,

@@ -20,6 +20,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define N_BEAMS 1080
@@ -54,6 +55,8 @@
 #define SPAWN_MARGIN 0.60f       /* [m] footprint's farthest corner (0.474) + the two half cell diagonals (0.071) */
 #define SPAWN_W_MAX 1.5f
 #define HEADING_JITTER 0.35f
+#define SPAWN_SAFE_SEARCH 256    /* several cars: bins searched forward for a start whose centre-line poses do not overlap */
+#define MAX_CARS 4
 #define NSTEP_MAX 16
 #define PI_F 3.14159274101257324f
 #define TWO_PI_F 6.28318548202514648f
@@ -69,6 +72,7 @@ typedef struct {
     int32_t h, w, n_centerline;
     float org_x, org_y, res, inv_res, tmax;
     const float *spawn_w;    /* [n] lateral room of a random start at centre-line point i (oc_spawn_width) */
+    const int32_t *spawn_safe; /* [n] where a multi-car start drawn at bin i really goes (oc_spawn_safe) */
 } oc_track;
 
 typedef struct {
@@ -197,6 +201,33 @@ static int obb_overlap_pose(const float *pa, const float *pb) {          /* pose
     return !sep;
 }
 
+/* Where a multi-car start drawn at bin i goes (racecar_oracle.py, spawn_safe): the first bin j among i, i + 1, ...,
+ * i + SPAWN_SAFE_SEARCH - 1 (around the lap) at which the centre-line poses of MAX_CARS cars, BALL_GAP bins apart, do not overlap
+ * pairwise; i itself if there is none. */
+void oc_spawn_safe(const oc_track *t, int32_t *out) {
+    const int n = t->n_centerline;
+    uint8_t *sound = (uint8_t *)malloc((size_t)n);
+    for (int j = 0; j < n; ++j) {
+        float pose[MAX_CARS][5];
+        for (int a = 0; a < MAX_CARS; ++a) {
+            int idx = (j - a * BALL_GAP) % n;
+            if (idx < 0) idx += n;
+            pose[a][0] = t->centerline[4 * idx]; pose[a][1] = t->centerline[4 * idx + 1]; pose[a][2] = t->centerline[4 * idx + 2];
+            sincos32(pose[a][2], &pose[a][3], &pose[a][4]);
+        }
+        int clash = 0;
+        for (int a = 0; a < MAX_CARS; ++a)
+            for (int b = a + 1; b < MAX_CARS; ++b) clash |= obb_overlap_pose(pose[a], pose[b]);
+        sound[j] = (uint8_t)!clash;
+    }
+    for (int i = 0; i < n; ++i) {
+        out[i] = i;
+        for (int k = 0; k < SPAWN_SAFE_SEARCH && k < n; ++k)
+            if (sound[(i + k) % n]) { out[i] = (i + k) % n; break; }
+    }
+    free(sound);
+}
+
 /* Reset law (H6; racecar_oracle.py, _reset_envs): bin from word 0; car a at bin idx0 - a * BALL_GAP, moved sideways by
  * u * spawn_w and turned by v * HEADING_JITTER; if two proposed cars overlap, all cars of the env take the centre-line poses. */
 static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
@@ -208,7 +239,8 @@ static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
     }
     s->episode[e] += 1u;
     const int jitter = c->reset_mode != 0;
-    const int idx0 = !jitter ? BALL_GAP * (A - 1) + GRID_LEAD : (int)(((uint64_t)r[0][0] * (uint64_t)n) >> 32);
+    int idx0 = !jitter ? BALL_GAP * (A - 1) + GRID_LEAD : (int)(((uint64_t)r[0][0] * (uint64_t)n) >> 32);
+    if (jitter && A > 1) idx0 = t->spawn_safe[idx0];           /* never anchor several cars where the centre line folds */
     float centre[4][5], prop[4][5];
     for (int a = 0; a < A; ++a) {
         int idx = (idx0 - a * BALL_GAP) % n;

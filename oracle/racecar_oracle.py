@@ -97,6 +97,8 @@ SPAWN_MARGIN = f32(0.60)         # [m] kept between the rear-axle point and that
                                  # (0.474 m) + the two half cell diagonals (0.071 m) the cell-centre distance cannot see
 SPAWN_W_MAX = f32(1.5)           # [m] cap of the lateral offset
 HEADING_JITTER = f32(0.35)       # [rad] the heading is drawn within +- this of the track's direction
+MAX_CARS = 4                     # cars per env at most (include/racecar_hip.h RC_MAX_CARS)
+SPAWN_SAFE_SEARCH = 256          # several cars: bins searched forward for a start whose centre-line poses do not overlap
 PI = f32(3.14159274101257324)
 TWO_PI = f32(6.28318548202514648)
 INF = f32(np.inf)
@@ -343,6 +345,24 @@ def follow_the_gap_reference(lidar, prev_heading, dt, wheel_max=None, max_veloci
 
 
 # ----------------------------------------------------------------------------- the env
+def _obb_overlap_poses(xa, ya, cta, sta, xb, yb, ctb, stb):
+    """Oriented-rectangle overlap of two cars by separating axes (H5): rear-axle poses in, uint8 out."""
+    ax = xa + BOX_CX * cta
+    ay = ya + BOX_CX * sta
+    bx = xb + BOX_CX * ctb
+    by = yb + BOX_CX * stb
+    dx, dy = bx - ax, by - ay
+    c = np.abs(cta * ctb + sta * stb)
+    s = np.abs(sta * ctb - cta * stb)
+    ra = BOX_HL + (BOX_HL * c + BOX_HW * s)      # projections on A's long axis (and B's)
+    rb = BOX_HW + (BOX_HL * s + BOX_HW * c)      # on the short axes
+    sep = np.abs(dx * cta + dy * sta) > ra
+    sep |= np.abs(dy * cta - dx * sta) > rb
+    sep |= np.abs(dx * ctb + dy * stb) > ra
+    sep |= np.abs(dy * ctb - dx * stb) > rb
+    return (~sep).astype(np.uint8)
+
+
 class OracleConfig:
     def __init__(self, num_envs=1, cars_per_env=1, laps=10, time_limit=180.0,
                  terminate_on_collision=True, collision_reward=-1.0, task=TASK_MAX_PROGRESS,
@@ -431,6 +451,35 @@ class OracleRaceEnv:
         self._spawn_w = w.astype(f32)
         return self._spawn_w
 
+    def spawn_safe(self):
+        """int64 [n_centerline]: where a multi-car start drawn at bin i really goes.  Bin j is SOUND if the centre-line poses of
+        RC_MAX_CARS = 4 cars at bins j, j - 12, j - 24, j - 36 do not overlap pairwise (the rectangle test of H5 on the table's
+        own poses); safe[i] = the first sound bin among i, i + 1, ..., i + SPAWN_SAFE_SEARCH - 1 (around the lap), i itself if
+        there is none.  A centre line is the most central cell per BFS distance bin, and where the BFS wavefronts of the
+        progress grid fold - columbia's last bins run back along the bins before them, the start pixel lying in an open area
+         - bins 1.2 m apart along the table are centimetres apart on the ground; such bins are never the
+        anchor of a multi-car start.  One car: not used (every bin is a start)."""
+        if getattr(self, "_spawn_safe", None) is not None:
+            return self._spawn_safe
+        n = len(self.centerline)
+        x, y = self.centerline[:, 0], self.centerline[:, 1]
+        sn, cs = sincos32(self.centerline[:, 2])
+        i = np.arange(n)
+        sound = np.ones(n, bool)
+        for a in range(MAX_CARS):
+            for b in range(a + 1, MAX_CARS):
+                ia, ib = (i - a * BALL_GAP_BINS) % n, (i - b * BALL_GAP_BINS) % n
+                sound &= _obb_overlap_poses(x[ia], y[ia], cs[ia], sn[ia], x[ib], y[ib], cs[ib], sn[ib]) == 0
+        safe = i.copy()
+        found = sound.copy()
+        for k in range(1, min(SPAWN_SAFE_SEARCH, n)):
+            j = (i + k) % n
+            take = ~found & sound[j]
+            safe[take] = j[take]
+            found |= take
+        self._spawn_safe = safe.astype(np.int64)
+        return self._spawn_safe
+
     def _cell(self, wx, wy):
         gx = (wx - self.org_x) * self.inv_res
         gy = (wy - self.org_y) * self.inv_res
@@ -475,6 +524,8 @@ class OracleRaceEnv:
             idx0 = np.full(envs.size, BALL_GAP_BINS * (self.A - 1) + GRID_LEAD_BINS, np.int64)
         else:
             idx0 = ((r0.astype(u64) * u64(n_cl)) >> u64(32)).astype(np.int64)
+            if self.A > 1:
+                idx0 = self.spawn_safe()[idx0]          # never anchor several cars where the centre line folds: spawn_safe
         unit = lambda w: (w >> u32(8)).astype(f32) * f32(5.9604644775390625e-8) * f32(2.0) - f32(1.0)     # [-1, 1), exact
         width = self.spawn_width()
         centre, proposed = [], []
@@ -626,21 +677,7 @@ class OracleRaceEnv:
         return hit
 
     def _obb_overlap(self, ca, cb_):
-        cta, sta, ctb, stb = self.ct[ca], self.st[ca], self.ct[cb_], self.st[cb_]
-        ax = self.x[ca] + BOX_CX * cta
-        ay = self.y[ca] + BOX_CX * sta
-        bx = self.x[cb_] + BOX_CX * ctb
-        by = self.y[cb_] + BOX_CX * stb
-        dx, dy = bx - ax, by - ay
-        c = np.abs(cta * ctb + sta * stb)
-        s = np.abs(sta * ctb - cta * stb)
-        ra = BOX_HL + (BOX_HL * c + BOX_HW * s)      # projections on A's long axis (and B's)
-        rb = BOX_HW + (BOX_HL * s + BOX_HW * c)      # on the short axes
-        sep = np.abs(dx * cta + dy * sta) > ra
-        sep |= np.abs(dy * cta - dx * sta) > rb
-        sep |= np.abs(dx * ctb + dy * stb) > ra
-        sep |= np.abs(dy * ctb - dx * stb) > rb
-        return (~sep).astype(np.uint8)
+        return _obb_overlap_poses(self.x[ca], self.y[ca], self.ct[ca], self.st[ca], self.x[cb_], self.y[cb_], self.ct[cb_], self.st[cb_])
 
     # ------------------------------------------------------------------ step (H7-H10)
     def step(self, actions, repeat=1):

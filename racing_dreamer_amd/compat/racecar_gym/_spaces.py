@@ -1,12 +1,43 @@
-"""gym.spaces if gym is installed, else minimal Box/Dict stand-ins with the attributes the reference's
-wrappers read (.low, .high, .shape, .dtype, .spaces, [], .sample())."""
+"""gym.spaces and gym.Env if gym is installed, else minimal Box/Dict/Env stand-ins with the attributes the reference's
+wrappers read (.low, .high, .shape, .dtype, .spaces, [], .sample(); .unwrapped, .reward_range, .spec, .metadata).
+
+With gym present the shim's env classes ARE `gym.Env`s (`EnvBase`): the reference hands them to `gym.wrappers.TimeLimit` /
+`FilterObservation` and to SB3 (baselines/racing/experiments/sb3/sb_experiment.py:42-64,97-112), whose `check_env` / vec-env
+code tests `isinstance(env, gym.Env)`."""
 import numpy as np
 
 try:                                    # pragma: no cover - depends on the host environment
+    import gym                           # type: ignore
+    EnvBase = gym.Env                    # (first: a `gym` without Env - a names-only stub - takes the stand-ins below whole)
     from gym.spaces import Box, Dict     # type: ignore
     HAVE_GYM = True
 except Exception:                        # gym is not installed in the build container
     HAVE_GYM = False
+
+    class EnvBase:
+        """What old gym's `gym.Env` gives a subclass besides the abstract methods."""
+        metadata = {"render.modes": []}
+        reward_range = (-float("inf"), float("inf"))
+        spec = None
+        action_space = None
+        observation_space = None
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def seed(self, seed=None):
+            return
+
+        def close(self):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *args):
+            self.close()
+            return False
 
     class Box:
         def __init__(self, low, high, shape=None, dtype=np.float32):

@@ -18,7 +18,7 @@ from racing_dreamer_amd import spec
 from racing_dreamer_amd.batched_env import BatchedRaceEnv
 
 from .. import tasks as task_registry
-from .._spaces import Box, Dict as DictSpace
+from .._spaces import Box, EnvBase, Dict as DictSpace
 from .scenarios import MultiAgentScenario
 
 # The device backend.  Always the HIP env; tests substitute a recording/oracle double through this name.
@@ -141,8 +141,11 @@ class RaceCore:
         self.env.close()
 
 
-class MultiAgentRaceEnv:
+class MultiAgentRaceEnv(EnvBase):
+    """(a `gym.Env` when gym is installed: `_spaces.EnvBase`)"""
     metadata = {"render.modes": ["follow", "birds_eye"]}
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
 
     def __init__(self, scenario: MultiAgentScenario, device: int = 0, seed: int = 0, _core: RaceCore = None, _slot: int = 0):
         self._scenario = scenario

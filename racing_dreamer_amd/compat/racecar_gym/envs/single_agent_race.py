@@ -10,12 +10,17 @@ from __future__ import annotations
 import random
 from typing import List
 
+from .._spaces import EnvBase
 from .multi_agent_race import MultiAgentRaceEnv
 from .scenarios import MultiAgentScenario, SingleAgentScenario
 
 
-class SingleAgentRaceEnv:
+class SingleAgentRaceEnv(EnvBase):
+    """(a `gym.Env` when gym is installed - what `gym.wrappers.TimeLimit`, `FilterObservation` and SB3's `check_env` are
+    handed in baselines/racing/experiments/sb3/sb_experiment.py:42-64,97-112)"""
     metadata = {"render.modes": ["follow", "birds_eye"]}
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
 
     def __init__(self, scenario: SingleAgentScenario, device: int = 0, seed: int = 0):
         self._scenario = scenario
@@ -46,9 +51,11 @@ class SingleAgentRaceEnv:
         self._env.close()
 
 
-class _ChangingTrack:
+class _ChangingTrack(EnvBase):
     """Holds one env per scenario and moves to the next on reset (order 'sequential' / 'random') or on
     set_next_env() (order 'manual')."""
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
 
     def __init__(self, envs: List, order: str):
         if order not in ("sequential", "random", "manual"):
@@ -113,13 +120,15 @@ class ChangingTrackMultiAgentRaceEnv(_ChangingTrack):
         super().__init__([MultiAgentRaceEnv(s, device=device) for s in scenarios], order)
 
 
-class _Vectorized:
+class _Vectorized(EnvBase):
     """Synchronous vector env over a list of scenarios (baselines/racing/environment/environment.py:5,40).  Envs whose
     scenarios agree (track, agents, tasks: `scenario_key`) share ONE device handle - a BatchedRaceEnv with B = their
     number: one launch and one device-to-host copy per step for the whole group - and a list over several tracks becomes
     one handle per track.  Env i of the list is env i of the job: its random resets are drawn from its own stream (the
     Philox key holds the env's index in its group), so a vector env of n equal scenarios is n DIFFERENT envs, where n
     separately built B = 1 envs with one seed would all be the same one."""
+    reward_range = (-float("inf"), float("inf"))
+    spec = None
 
     def __init__(self, scenarios, device: int = 0, single: bool = False):
         from .multi_agent_race import RaceCore, scenario_key

@@ -20,7 +20,7 @@ struct RcTrackDev {
     const uint32_t *drv_words;   // drivable area, [h][pitch]
     const float *progress;       // [h][w], < 0 outside the drivable area
     const float *centerline;     // [n_centerline][4] = x, y, heading, progress
-    const float4 *spawn;         // [n_centerline][2] = (x, y, heading, cos), (sin, progress at that cell, checkpoint as int bits, 0):
+    const float4 *spawn;         // [n_centerline][2] = (x, y, heading, cos), (sin, progress at that cell, checkpoint | safe bin << 8 as int bits, lateral room):
                                  // everything a reset needs from a spawn index in one 32-byte gather (built on the device)
     const float *beams;          // [1080][2] = cos, sin of the beam angle in the sensor frame
     const float *footprint;      // [34][2] body-frame perimeter points

@@ -112,7 +112,7 @@ __device__ __forceinline__ int obb_overlap(const Car &a, const Car &b) {
 struct Spawn { float x, y, th, ct, st, pr; int cp; };
 
 // The spawn table (RcTrackDev::spawn): per centerline index the pose, sin / cos of its heading (the spec's sincos32),
-// the progress value of its cell, its checkpoint and the lateral room a random start has there - computed once per track ON
+// the progress value of its cell, its checkpoint (+ the anchor bin of a multi-car start, see below) and the lateral room a random start has there - computed once per track ON
 // THE DEVICE with the very functions a reset would call, so the centre-line part of a reset is one 32-byte gather with no
 // arithmetic behind it.  Lateral room (oracle: spawn_width): d2 = squared cell distance from the point's cell to the nearest
 // cell that is not drivable (outside the grid included) in the window of +- RCS_SPAWN_CLEAR_R cells, at most (R + 1)^2;
@@ -146,8 +146,31 @@ __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float
     int k = 0;
     while ((k + 1) * (k + 1) <= d2) ++k;
     const float w = clampf((float)k * t.res - RCS_SPAWN_MARGIN, 0.0f, RCS_SPAWN_W_MAX);
+    // Where a multi-car start drawn at this bin really goes (oracle: spawn_safe): the first bin j among i, i + 1, ... (around the
+    // lap, RCS_SPAWN_SAFE_SEARCH of them) at which the centre-line poses of RC_MAX_CARS cars RCS_BALL_GAP_BINS apart do not
+    // overlap pairwise; i itself if there is none.  Where the progress grid's wavefronts fold (columbia's last bins run back
+    // along the bins before them) bins 1.2 m apart along the table are centimetres apart on the ground.
+    const int n = t.n_centerline;
+    int safe = i;
+    for (int s = 0; s < RCS_SPAWN_SAFE_SEARCH && s < n; ++s) {
+        const int j = (i + s) % n;
+        Car c[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            int idx = (j - a * RCS_BALL_GAP_BINS) % n;
+            if (idx < 0) idx += n;
+            c[a].x = t.centerline[4 * idx]; c[a].y = t.centerline[4 * idx + 1];
+            sincos32(t.centerline[4 * idx + 2], c[a].st, c[a].ct);
+        }
+        int clash = 0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a + 1; b < 4; ++b) clash |= obb_overlap(c[a], c[b]);
+        if (!clash) { safe = j; break; }
+    }
     out[2 * i] = make_float4(x, y, th, cs);
-    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp), w);
+    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp | (safe << 8)), w);      // checkpoint < 256; the bin above it
 }
 
 __device__ __forceinline__ float unit_pm1(uint32_t w) { return ((float)(w >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f; }   // [-1, 1), exact
@@ -176,7 +199,8 @@ __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t
         for (int k = 1; k < 1 + A / 2; ++k) r[k] = rcd::philox4x32(g, ep, (uint32_t)k, 0u, p.seed_lo, p.seed_hi);
     }
     const int n = t.n_centerline;
-    const int idx0 = !jitter ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r[0].x, (uint32_t)n);
+    int idx0 = !jitter ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r[0].x, (uint32_t)n);
+    if (A > 1 && jitter) idx0 = __float_as_int(t.spawn[2 * idx0 + 1].z) >> 8;      // never anchor several cars where the centre line folds
     Spawn centre[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -185,7 +209,7 @@ __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t
         const float4 s0 = t.spawn[2 * idx], s1 = t.spawn[2 * idx + 1];
         Spawn &c = centre[a];
         c.x = s0.x; c.y = s0.y; c.th = s0.z; c.ct = s0.w;
-        c.st = s1.x; c.pr = s1.y; c.cp = __float_as_int(s1.z);
+        c.st = s1.x; c.pr = s1.y; c.cp = __float_as_int(s1.z) & 0xff;
         sp[a] = c;
         if (jitter) {
             const rcd::u32x4 &q = r[a == 0 ? 0 : 1 + (a - 1) / 2];

@@ -29,6 +29,7 @@
 #define RCS_SPAWN_MARGIN 0.60f    // [m] the footprint's farthest corner (0.474) + the two half cell diagonals (0.071)
 #define RCS_SPAWN_W_MAX 1.5f      // [m] cap of the lateral offset
 #define RCS_HEADING_JITTER 0.35f  // [rad] heading within +- this of the track's direction
+#define RCS_SPAWN_SAFE_SEARCH 256 // several cars: bins searched forward for a start whose four centre-line poses do not overlap
 #define RCS_N_FOOTPRINT 34
 #define RCS_FOOT_STEP 0.05f      // pitch of the footprint lattice [m] (12 x 7 nodes, rear axle at node (2, 3))
 #define RCS_PI 3.14159274101257324f

@@ -56,6 +56,7 @@ SPAWN_CLEAR_R = 40            # cells searched for the nearest non-drivable cell
 SPAWN_MARGIN = 0.60           # [m] footprint's farthest corner 0.474 + two half cell diagonals 0.071  (derived)
 SPAWN_W_MAX = 1.5             # [m] cap of the lateral offset                                   (free)
 HEADING_JITTER = 0.35         # [rad]                                                           (free)
+SPAWN_SAFE_SEARCH = 256       # bins searched forward for a start at which four cars 1.2 m apart do not overlap   (free)
 
 # --- action remap (dreamer/dream.py:138) ---------------------------------------------
 ACTION_LOW = (0.005, -1.0)

@@ -1061,7 +1061,9 @@ def test_random_starts_at_full_size_are_all_different_and_touch_nothing():
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
     from racing_dreamer_amd.track_assets import load_track
     from racing_dreamer_amd import spec
-    for track_name, n, cars, mode in (("austria", 65536, 1, "random"), ("treitlstrasse_v2", 32768, 2, "random_ball")):
+    # (columbia, round 5: its centre line folds at the finish line; a multi-car start drawn there is moved on - spawn_safe)
+    for track_name, n, cars, mode in (("austria", 65536, 1, "random"), ("treitlstrasse_v2", 32768, 2, "random_ball"),
+                                      ("columbia", 16384, 4, "random_ball"), ("columbia", 8192, 3, "random_ball")):
         t = load_track(track_name)
         env = BatchedRaceEnv(t, n, cars, auto_reset=True)
         ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution,
@@ -1069,7 +1071,8 @@ def test_random_starts_at_full_size_are_all_different_and_touch_nothing():
         pose = env.reset(mode=mode, seed=3)["pose"].cpu().numpy()
         want = np.asarray(ora.reset(mode=spec.RESET_MODES[mode], seed=3)["pose"]).reshape(n, cars, 6)
         assert np.array_equal(pose, want)
-        assert len(np.unique(pose.reshape(n, -1), axis=0)) == n
+        distinct = len(np.unique(pose.reshape(n, -1), axis=0))
+        assert distinct == n or (track_name == "columbia" and distinct > 0.98 * n)      # (envs whose proposals clash share the centre-line poses)
         if cars == 2:
             gap = np.linalg.norm(pose[:, 0, :2] - pose[:, 1, :2], axis=1)
             assert gap.min() > 0.3 and gap.max() < 1.2 + 2 * 1.5

@@ -1,5 +1,6 @@
 """The CPU oracle itself: published known answers, hand-derived known answers, properties, and the
 C restatement pinned bit-for-bit to the NumPy one."""
+import os
 import numpy as np
 import pytest
 
@@ -326,7 +327,7 @@ def test_scan_equals_brute_force_ray_box_intersection():
     assert worst < 2e-4
 
 
-@pytest.mark.parametrize("track_name,cars", [("columbia", 1), ("austria", 1), ("treitlstrasse_v2", 2), ("barcelona", 4)])
+@pytest.mark.parametrize("track_name,cars", [("columbia", 1), ("austria", 1), ("treitlstrasse_v2", 2), ("barcelona", 4), ("columbia", 3)])
 def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
     """H6 (dreamer/dream.py:105-108): `random` = a pose on the track with a minimum wall distance, heading along the
     track; `random_ball` = the cars of an env close together around one random point.  Checked on the C port (bit-identical
@@ -350,6 +351,12 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
     g = (np.arange(n) + cfg.first_env).astype(np.uint32)
     r0 = ro.philox4x32(g, np.zeros(n, np.uint32), np.uint32(0), np.uint32(0), 5, 0)[0]
     idx0 = ((r0.astype(np.uint64) * np.uint64(len(cl))) >> np.uint64(32)).astype(np.int64)
+    safe = ref.spawn_safe()
+    assert np.array_equal(safe, env._keep["spawn_safe"])
+    drawn = idx0
+    if cars > 1:                            # several cars are anchored at the first bin from the drawn one on whose poses do not overlap
+        idx0 = safe[idx0]
+        assert np.mean(idx0 != drawn) < 0.1
     for a in range(cars):
         idx = (idx0 - a * ro.BALL_GAP_BINS) % len(cl)
         off = xy[:, a] - cl[idx, :2]
@@ -359,19 +366,20 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
         dyaw = (yaw[:, a] - cl[idx, 2] + np.pi) % (2 * np.pi) - np.pi
         assert np.all(np.abs(dyaw) <= float(ro.HEADING_JITTER) + 1e-5), a
         moved = width[idx] > 0.2
-        if a == 0 or track_name != "columbia":
+        if a == 0 or track_name != "columbia":          # (columbia: the cars behind the first stand where the room is small)
             assert np.std(lateral[moved] / width[idx][moved]) > 0.5 and np.std(dyaw) > 0.15      # uniform: sigma = 0.577 / 0.2
-    hist = np.bincount(idx0 * 40 // len(cl), minlength=40)            # the lap in 40 stretches: 500 starts each
+    hist = np.bincount(drawn * 40 // len(cl), minlength=40)           # the lap in 40 stretches: 500 starts each
     assert hist.min() > 0.8 * n / 40 and hist.max() < 1.2 * n / 40
-    assert len(np.unique(pose.reshape(n, -1), axis=0)) == n
+    distinct = len(np.unique(pose.reshape(n, -1), axis=0))
+    # (columbia with several cars: next to the fold sound bins lie close on the ground, proposals clash there and the env takes
+    # the centre-line poses - the law's fallback -, which envs share)
+    assert distinct == n or (track_name == "columbia" and cars > 1 and distinct > 0.99 * n)
     # nothing touches anything at the start: one step with the brakes on leaves every car where it is and evaluates the contacts
     act = np.zeros((n * cars, 2), np.float32)
     act[:, 0] = -1.0
     out = env.step(act)
     wall, opp = np.asarray(out["wall_collision"]).reshape(n, cars), np.asarray(out["opponent_collision"]).reshape(n, cars)
-    assert int(wall.sum()) == 0
-    if track_name != "columbia":            # (columbia's centre line folds in its last four bins: DESIGN.md 2 item 6, known)
-        assert int(opp.sum()) == 0
+    assert int(wall.sum()) == 0 and int(opp.sum()) == 0      # (columbia's folded bins included since round 5: spawn_safe)
     # a finished env draws a NEW pose (episode counter in the Philox counter)
     env2 = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=64, cars_per_env=cars))
     a0 = np.asarray(env2.reset(mode=mode, seed=5)["pose"]).copy()
@@ -381,3 +389,48 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
     for a in range(cars):
         i = (ro.BALL_GAP_BINS * (cars - 1) + ro.GRID_LEAD_BINS - a * ro.BALL_GAP_BINS) % len(cl)
         assert np.array_equal(grid[:, a, :2], np.broadcast_to(t.centerline[i, :2], (64, 2))) and np.all(grid[:, a, 5] == t.centerline[i, 2])
+
+
+# Maps on which the centre line itself (the most central cell per 0.1 m of BFS arc) passes places narrower than a car turned by
+# the heading jitter - hand-drawn test maps with boxes on the track, none of them named by a scenario of the reference: 0.6 - 3 %
+# of the random starts touch a wall there (a start with zero lateral room keeps the centre-line POSITION but still turns by up to
+# 0.35 rad).  Found in round 5 by the test below; recorded in DESIGN.md 2 item 6, not repaired.
+NARROW_MAPS = {"plechaty2", "plechaty2nobox", "skirk", "torino", "torino_redraw_small_with_obstacles", "train_pile_of_blocks",
+               "train_pile_of_blocks_flipped"}
+
+
+def test_no_multi_car_start_overlaps_on_any_compiled_map():
+    """20 000 `random_ball` starts per track and A = 2, 3, 4 on EVERY compiled map - no two cars of an env
+    overlap, none touches a wall (the spec's own tests, `_obb_overlap` and `_wall_hit`, on the poses the reset law produced;
+    no scan is run: 60 000 x 1080 rays per case would make this a test of minutes).  Columbia's last four centre-line bins run back
+    along the four before them (the BFS wavefronts of its progress grid fold at the finish line):
+    `spawn_safe` moves a start drawn there to the next bin whose four poses are clear, and leaves every bin of an ordinary
+    track where it is."""
+    import json
+    from racing_dreamer_amd.track_assets import TRACK_DIR
+    with open(os.path.join(TRACK_DIR, "index.json")) as f:
+        names = sorted(k for k, v in json.load(f).items() if v["status"] == "ok")
+    assert len(names) >= 29
+    n, moved = 20000, {}
+    for name in names:
+        t = load_track(name)
+        for cars in (2, 3, 4):
+            env = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution,
+                                   ro.OracleConfig(num_envs=n, cars_per_env=cars, auto_reset=True))
+            env.seed, env.mode = 11, ro.RESET_RANDOM_BALL
+            env._reset_envs(np.arange(n))
+            e = np.arange(n)
+            for a in range(cars):
+                if name not in NARROW_MAPS:
+                    assert int(env._wall_hit(e * cars + a).sum()) == 0, (name, cars, a)
+                for b in range(a + 1, cars):
+                    assert int(env._obb_overlap(e * cars + a, e * cars + b).sum()) == 0, (name, cars, a, b)
+        safe = env.spawn_safe()
+        moved[name] = int((safe != np.arange(len(safe))).sum())
+    assert moved["columbia"] >= 4 and moved["austria"] == 0 and moved["barcelona"] == 0, moved
+    # the C port builds the same table (its resets are compared with these bit for bit elsewhere)
+    from oracle import c_oracle
+    t = load_track("columbia")
+    cenv = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=2, cars_per_env=2))
+    ref = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=2, cars_per_env=2))
+    assert np.array_equal(cenv._keep["spawn_safe"], ref.spawn_safe())

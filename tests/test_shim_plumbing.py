@@ -233,3 +233,166 @@ def test_host_progress_task_equals_the_device_task(ref_wrappers, monkeypatch):
                 break
     assert ended >= 2 and float(p["collision_reward"]) != 0.0
     env.close()
+
+
+# ---------------------------------------------------------------------------------------------- with a gym that checks
+def _install_strict_gym():
+    """A `gym` whose Env is a real class (gym 0.17's attributes) and whose Wrapper, TimeLimit, FilterObservation and a
+    `check_env`-style helper all insist on `isinstance(env, gym.Env)` - what SB3's check_env and vec-envs do with the env
+    baselines/racing/experiments/sb3/sb_experiment.py:42-64,97-112 builds.  Not reference code."""
+    import types
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden as mg
+
+    class Env:
+        metadata = {"render.modes": []}
+        reward_range = (-float("inf"), float("inf"))
+        spec = None
+        action_space = None
+        observation_space = None
+
+        @property
+        def unwrapped(self):
+            return self
+
+        def seed(self, seed=None):
+            return
+
+        def close(self):
+            pass
+
+    class Wrapper(Env):
+        def __init__(self, env):
+            assert isinstance(env, Env), f"{type(env).__name__} is not a gym.Env"
+            self.env = env
+            self.action_space, self.observation_space = env.action_space, env.observation_space
+            self.reward_range, self.metadata = env.reward_range, env.metadata
+
+        def __getattr__(self, name):
+            if name.startswith("_"):
+                raise AttributeError(name)
+            return getattr(self.env, name)
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
+
+        def step(self, action):
+            return self.env.step(action)
+
+        def reset(self, **kw):
+            return self.env.reset(**kw)
+
+    class ObservationWrapper(Wrapper):
+        def reset(self, **kw):
+            return self.observation(self.env.reset(**kw))
+
+        def step(self, action):
+            obs, r, d, info = self.env.step(action)
+            return self.observation(obs), r, d, info
+
+    class FilterObservation(ObservationWrapper):            # gym.wrappers.FilterObservation
+        def __init__(self, env, filter_keys=None):
+            super().__init__(env)
+            self._keys = list(filter_keys)
+            self.observation_space = spaces.Dict({k: v for k, v in env.observation_space.spaces.items() if k in self._keys})
+
+        def observation(self, obs):
+            return {k: v for k, v in obs.items() if k in self._keys}
+
+    class TimeLimit(Wrapper):                               # gym.wrappers.TimeLimit
+        def __init__(self, env, max_episode_steps=None):
+            super().__init__(env)
+            self._max, self._t = max_episode_steps, None
+
+        def reset(self, **kw):
+            self._t = 0
+            return self.env.reset(**kw)
+
+        def step(self, action):
+            assert self._t is not None, "Cannot call env.step() before calling reset()"
+            obs, r, d, info = self.env.step(action)
+            self._t += 1
+            if self._t >= self._max:
+                info["TimeLimit.truncated"] = not d
+                d = True
+            return obs, r, d, info
+
+    gym = types.ModuleType("gym")
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box, spaces.Dict = mg.Box, mg.Dict
+    spaces.flatten_space, spaces.flatten, spaces.unflatten = mg._flatten_space, mg._flatten, mg._unflatten
+    wrappers = types.ModuleType("gym.wrappers")
+    wrappers.TimeLimit, wrappers.FilterObservation = TimeLimit, FilterObservation
+    gym.spaces, gym.wrappers, gym.Env, gym.Wrapper, gym.ObservationWrapper = spaces, wrappers, Env, Wrapper, ObservationWrapper
+    sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.wrappers": wrappers})
+    return gym
+
+
+def _check_env(env, gym):
+    """The structural part of stable_baselines3.common.env_checker.check_env."""
+    assert isinstance(env, gym.Env), "Your environment must inherit from the gym.Env class"
+    assert env.observation_space is not None and env.action_space is not None
+    assert isinstance(env.reward_range, tuple) and len(env.reward_range) == 2
+    assert isinstance(env.metadata, dict) and env.unwrapped is not None
+
+
+def test_shim_envs_are_gym_envs_when_gym_is_present(monkeypatch):
+    """with gym installed every env class of the shim IS a `gym.Env` - so the env construction of
+    baselines/racing/experiments/sb3/sb_experiment.py:42-64 works with wrappers that insist on it - and without gym they are the
+    stand-in base (every other test of this file)."""
+    import importlib.util
+    saved = {k: v for k, v in sys.modules.items() if k == "gym" or k.startswith("gym.") or k == "racecar_gym" or k.startswith("racecar_gym.")}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        gym = _install_strict_gym()
+        from racing_dreamer_amd import compat
+        compat.install()
+        import racecar_gym
+        import racecar_gym._spaces as sp
+        import racecar_gym.envs.multi_agent_race as mar
+        from oracle_backend import OracleBackend
+        monkeypatch.setattr(mar, "_BACKEND", OracleBackend)
+        assert sp.HAVE_GYM and sp.EnvBase is gym.Env
+        from racecar_gym import SingleAgentScenario
+        from racecar_gym.envs import (ChangingTrackMultiAgentRaceEnv, ChangingTrackSingleAgentRaceEnv, MultiAgentRaceEnv, MultiAgentScenario,
+                                      SingleAgentRaceEnv, VectorizedMultiAgentRaceEnv, VectorizedSingleAgentRaceEnv)
+        for cls in (SingleAgentRaceEnv, MultiAgentRaceEnv, ChangingTrackSingleAgentRaceEnv, ChangingTrackMultiAgentRaceEnv,
+                    VectorizedSingleAgentRaceEnv, VectorizedMultiAgentRaceEnv):
+            assert issubclass(cls, gym.Env), cls
+
+        def load(name, path):
+            spec = importlib.util.spec_from_file_location(name, path)
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            return mod
+        SA = load("ref_single_agent_strict", os.path.join(REF, "baselines/racing/environment/single_agent.py"))
+        CM = load("ref_common_strict", os.path.join(REF, "baselines/racing/environment/common.py"))
+        monkeypatch.chdir(os.path.join(REF, "baselines"))
+        scenarios = [SingleAgentScenario.from_spec(f"scenarios/max_progress/{t}.yml", rendering=False) for t in ("columbia", "austria")]
+        env = ChangingTrackSingleAgentRaceEnv(scenarios=scenarios, order="sequential")            # sb_experiment.py:61-63
+        _check_env(env, gym)
+        env = gym.wrappers.FilterObservation(env, filter_keys=["lidar"])                          # :43
+        env = SA.Flatten(env, flatten_obs=True, flatten_actions=True)                             # :44
+        env = SA.NormalizeObservations(env)                                                       # :45
+        env = CM.FixedResetMode(env, mode="random")                                               # :46
+        env = gym.wrappers.TimeLimit(env, max_episode_steps=40)                                   # :47
+        env = SA.ActionRepeat(env, n=4)                                                           # :48
+        _check_env(env, gym)
+        assert isinstance(env.unwrapped, ChangingTrackSingleAgentRaceEnv)
+        obs = env.reset()
+        assert obs.shape == (1080,) and 0.0 <= obs.min() and obs.max() <= 1.0
+        done, steps = False, 0
+        while not done:
+            obs, r, done, info = env.step(np.array([0.4, 0.05]))
+            steps += 1
+        assert 1 <= steps <= 10 and {"wrong_way", "progress", "lap"} <= set(info)
+        env.close()
+        multi = MultiAgentRaceEnv(MultiAgentScenario.from_spec("scenarios/max_progress/columbia.yml", rendering=False))
+        _check_env(multi, gym)
+        multi.close()
+    finally:
+        for k in [m for m in sys.modules if m == "gym" or m.startswith("gym.") or m == "racecar_gym" or m.startswith("racecar_gym.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
