@@ -621,19 +621,33 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
     env.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    env.reset_kernel_times()
-    env.set_profiling(True)
-    for k in range(min(steps, 40)):
-        env.step_random(seed=1, step=warmup + steps + k)
-    env.sync()
-    env.set_profiling(False)
-    kt = {k: round(v["avg_ms"], 4) for k, v in env.kernel_times().items() if v["launches"]}
+    # Per-kernel times: ONE kernel per pass, as the headline does for its scan.  With the launch-attached timers on every kernel
+    # of the step at once, each kernel's start stamp is taken when its packet is picked up - while the kernel before it still
+    # drains - so at small batches the per-kernel figures summed to MORE than the step (BENCH_r04: configs[1] 0.0093 + 0.0255 =
+    # 0.0348 ms against a 0.0311 ms step).  One timer per pass leaves the other kernels untimed and the
+    # step's rhythm as in the timed window.
+    from racing_dreamer_amd import _lib as L
+    kt, k0 = {}, warmup + steps
+    for kid in (L.K_RAYCAST, L.K_DYNAMICS) + ((L.K_PATCH,) if obs_type == "lidar_occupancy" else ()):
+        env.reset_kernel_times()
+        env.set_profiling(True, kernels=[kid])
+        for k in range(min(steps, 40)):
+            env.step_random(seed=1, step=k0 + k)
+        k0 += min(steps, 40)
+        env.sync()
+        env.set_profiling(False)
+        v = env.kernel_times()[L.KERNEL_NAMES[kid]]
+        if v["launches"]:
+            kt[L.KERNEL_NAMES[kid]] = round(v["avg_ms"], 4)
     env.close()
     n_cars = envs * cars
     step_bytes = (STEP_BYTES_PER_CAR + (PATCH_BYTES_PER_CAR if obs_type == "lidar_occupancy" else 0)) * n_cars
     ms = dt / steps * 1e3
     out = {"workload": name, "envs": envs, "cars_per_env": cars, "track": track_name, "obs_type": obs_type,
            "steps": steps, "ms_per_step": ms, "env_steps_per_s": envs * steps / dt, "kernels_ms": kt,
+           "kernels_sum_ms": round(sum(kt.values()), 4), "kernels_over_step": round(sum(kt.values()) / ms, 3),
+           "kernels_note": "each kernel timed in a pass of its own (launch-attached events on that kernel only); "
+                           "ms_per_step - kernels_sum_ms = launch gaps between the step's kernels",
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                         "step_bytes": step_bytes, "step_achieved": step_bytes / (ms * 1e-3) / 1e9,
                         "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -668,13 +682,19 @@ def time_mixed_tracks(names, envs, steps, warmup, settle=150):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     lead = env.parts[0]                     # (a step is one launch per kernel over all blocks, timed on the first handle)
-    lead.reset_kernel_times()
-    lead.set_profiling(True)
-    for k in range(min(steps, 40)):
-        env.step_random(seed=1, step=warmup + steps + k)
-    env.sync()
-    lead.set_profiling(False)
-    kt = {k: round(v["avg_ms"], 4) for k, v in lead.kernel_times().items() if v["launches"]}
+    from racing_dreamer_amd import _lib as L
+    kt, k0 = {}, warmup + steps
+    for kid in (L.K_RAYCAST, L.K_DYNAMICS):               # one kernel per pass: see time_config
+        lead.reset_kernel_times()
+        lead.set_profiling(True, kernels=[kid])
+        for k in range(min(steps, 40)):
+            env.step_random(seed=1, step=k0 + k)
+        k0 += min(steps, 40)
+        env.sync()
+        lead.set_profiling(False)
+        v = lead.kernel_times()[L.KERNEL_NAMES[kid]]
+        if v["launches"]:
+            kt[L.KERNEL_NAMES[kid]] = round(v["avg_ms"], 4)
     env.close()
     ms = dt / steps * 1e3
     step_bytes = STEP_BYTES_PER_CAR * envs
@@ -756,17 +776,37 @@ def main():
         env.set_profiling(True, kernels=[L.K_RAYCAST])
         env.sync()
         torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record(env.stream)
         for k in range(n_fresh):
             env.step_random(seed=3, step=k)
+        ev1.record(env.stream)
         env.sync()
         torch.cuda.synchronize()
         dtf = time.perf_counter() - t0
         env.set_profiling(False)
+        fresh_scan = env.kernel_times()["rc_raycast_kernel"]["avg_ms"]
+        # the same 20 steps once more for the dynamics kernel alone (one timer per pass, see time_config)
+        env.reset(mode="random", seed=0)
+        env.reset_kernel_times()
+        env.set_profiling(True, kernels=[L.K_DYNAMICS])
+        for k in range(n_fresh):
+            env.step_random(seed=3, step=k)
+        env.sync()
+        env.set_profiling(False)
+        fresh_dyn = env.kernel_times()["rc_dynamics_kernel"]["avg_ms"]
+        gpu_ms = ev0.elapsed_time(ev1) / n_fresh
         fresh = {"steps": n_fresh, "ms_per_step": dtf / n_fresh * 1e3, "env_steps_per_s": shard.num_envs * n_fresh / dtf,
-                 "raycast_ms": round(env.kernel_times()["rc_raycast_kernel"]["avg_ms"], 4),
+                 "raycast_ms": round(fresh_scan, 4), "dynamics_ms": round(fresh_dyn, 4),
+                 "gpu_ms_per_step": round(gpu_ms, 4),
+                 "host_overhead_ms_per_step": round(dtf / n_fresh * 1e3 - gpu_ms, 4),
+                 "other_gpu_ms_per_step": round(gpu_ms - fresh_scan - fresh_dyn, 4),
                  "note": "the first 20 steps after reset(mode='random') - no settling of the poses; the GPU itself kept busy by 150 steps "
-                         "before that reset - host-timed with the scan's launch timers on"}
+                         "before that reset - host-timed with the scan's launch timers on.  gpu_ms_per_step = the same window between two "
+                         "events on the env's stream: what is left of ms_per_step beyond it is the host's share of a 4 ms window (first "
+                         "launch, the closing synchronisation); other_gpu_ms_per_step = the window's GPU time beyond scan + dynamics: the "
+                         "sort of the car order at the first observation after a reset (three small launches) and the launch gaps"}
         env.reset(mode="random", seed=0)
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     via = args.gather_via
@@ -887,6 +927,26 @@ def main():
     env.set_profiling(False)
     ktimes = env.kernel_times()
     scan_symbol = env.scan_kernel_name()
+    # a long steady-state figure of the SAME env and loop right behind the driver's window (a 20-step window is
+    # 3.7 ms, too short for an outside observer; this one is >= 2 000 steps, ~0.4 s, and contains its share of order re-sorts)
+    steady = None
+    if not distributed and not args.no_configs:
+        n_steady = max(2000, 10 * args.steps)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record(env.stream)
+        for k in range(n_steady):
+            gather.step(step_no + k)
+        ev1.record(env.stream)
+        finish(gather)
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t0
+        step_no += n_steady
+        steady = {"steps": n_steady, "ms_per_step": dts / n_steady * 1e3, "env_steps_per_s": shard.num_envs * n_steady * args.repeat / dts,
+                  "gpu_ms_per_step": ev0.elapsed_time(ev1) / n_steady,
+                  "note": "the headline's env and loop, continued for a window an observer can see (no timers on); host-timed like the "
+                          "headline, gpu_ms_per_step between two events on the env's stream"}
     # the other kernels of the step: a short untimed pass with all timers on
     env.reset_kernel_times()
     env.set_profiling(True, kernels=[L.K_PATCH, L.K_DYNAMICS])
@@ -972,7 +1032,10 @@ def main():
                     "of the grid traversal, not by HBM (SURVEY.md 8d); the >= 40 % HBM target is NOT met; DESIGN.md 4.2",
         },
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
+        "kernels_sum_ms": round(sum(v["avg_ms"] for v in ktimes.values() if v["launches"]), 4),
     }
+    if steady is not None:
+        out["steady"] = steady
     if fresh is not None:
         out["fresh_reset"] = fresh
     if distributed:

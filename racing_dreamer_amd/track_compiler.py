@@ -310,19 +310,41 @@ def save_track(t: CompiledTrack, out_path: str) -> None:
     )
 
 
+START_POSITIONS = os.path.join(os.path.dirname(__file__), "tracks", "start_positions.json")
+
+
+def start_positions() -> dict:
+    """Per-map start positions (world x, y) for the maps whose default start - world (0, 0), generate-costmap.py:463-464 - is not
+    on the track: what the reference's generator takes as --start_x / --start_y (generate-costmap.py:460-475).  Chosen by
+    tools/find_start.py (the first lattice cell in scan order from which the compiled track closes), committed as data."""
+    import json
+    if not os.path.exists(START_POSITIONS):
+        return {}
+    with open(START_POSITIONS) as f:
+        return {k: tuple(v["start"]) for k, v in json.load(f).items() if "start" in v}
+
+
 def compile_all(maps_dir: str, out_dir: str) -> dict:
     """Every map yaml of `maps_dir` with the generator's default start position (world (0, 0),
-    generate-costmap.py:463-464): assets for those that compile, the reason for those that do not, `index.json` with
-    both.  Maps that already have a track name (TRACK_TO_MAP) are stored under that name."""
+    generate-costmap.py:463-464) - or the one `start_positions()` holds for it: assets for those that compile, the reason for
+    those that do not, `index.json` with both.  Maps that already have a track name (TRACK_TO_MAP) are stored under that name."""
     import glob
     import json
     by_map = {v: k for k, v in TRACK_TO_MAP.items()}
+    starts = start_positions()
+    refused = {}
+    if os.path.exists(START_POSITIONS):
+        with open(START_POSITIONS) as f:
+            refused = {k: v["refused"] for k, v in json.load(f).items() if "refused" in v}
     index = {}
     for path in sorted(glob.glob(os.path.join(maps_dir, "*.yaml"))):
         map_name = os.path.basename(path)[:-5]
         name = by_map.get(map_name, map_name)
+        if name in refused:
+            index[name] = {"map": map_name, "status": "not compiled", "reason": refused[name]}
+            continue
         try:
-            t = compile_track(name, maps_dir)
+            t = compile_track(name, maps_dir, starts.get(name, (0.0, 0.0)))
         except (TrackCompileError, AssertionError) as e:
             index[name] = {"map": map_name, "status": "not compiled", "reason": str(e) or "empty centre-line bin (open track)"}
             continue
@@ -334,6 +356,8 @@ def compile_all(maps_dir: str, out_dir: str) -> dict:
         h, w = t.occ.shape
         index[name] = {"map": map_name, "status": "ok", "cells": [int(h), int(w)], "max_steps": int(t.max_steps),
                        "track_length_m": round(t.max_steps * t.resolution, 2)}
+        if name in starts:
+            index[name]["start_position"] = [float(v) for v in starts[name]]
     with open(os.path.join(out_dir, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     return index

@@ -165,3 +165,84 @@ def test_reference_occupancy_decoder_reconstructs_this_envs_patches_the_right_wa
     assert s["identity"].mean() > 0.5 and s["identity"].mean() > s["mirrored"].mean() + 0.08, {k: v.mean() for k, v in s.items()}
     assert (s["identity"] > s["mirrored"]).mean() > 0.7                # frame by frame
     assert s["upside_down"].mean() < 0.4 and abs(s["rotated"].mean()) < 0.15
+
+
+# ------------------------------------------------------------------------------------------------------------------ G12
+def _protocol():
+    import importlib.util
+    path = os.path.join(os.path.dirname(GOLDEN), "..", "tools", "analysis", "eval_protocol.py")
+    spec = importlib.util.spec_from_file_location("eval_protocol", os.path.abspath(path))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# dreamer/plotting/structs.py:23-28 - the only task-performance numbers the reference holds (max progress in laps)
+PUBLISHED_DREAMER = {"austria": 1.31, "columbia": 2.23, "treitlstrasse_v2": 2.00}
+PUBLISHED_MODEL_FREE_AUSTRIA = {"d4pg": 0.38, "mpo": 0.36, "ppo": 0.36, "sac": 0.36, "lstm-ppo": 0.36}
+# The band G12 asserts for the austria agent under the reference's test protocol: measured / published must lie in [0.85, 1.35].
+# Measured in round 5: 1.53 laps (1.51 .. 1.55 over 8 episodes) against 1.31 published = 1.17.  The band is wide on purpose: the
+# published figure is the BEST evaluation of the paper's training runs, the shipped checkpoint is whatever the authors deployed on
+# their car - another agent of the same kind -, and the reward head of that very checkpoint pulls the other way (it expects
+# 1.35 - 1.7 x the progress per step that this env pays).  A car 35 % faster or 15 % slower along the track than
+# the paper's would leave it.
+G12_BAND = (0.85, 1.35)
+
+
+def test_g12_progress_under_the_references_test_protocol_against_its_published_numbers():
+    """G12: the reference's shipped agents under the reference's own TEST protocol (dreamer/dream.py:55,58,
+    120-121: scenario max_progress, grid start, action_repeat 4, TimeLimit 4000 / 4 agent steps = 40 s, the episode ends at the
+    first wall contact; figure = lap + progress - 1), on the C oracle, beside dreamer/plotting/structs.py:26-28.
+      austria agent on austria ........ 1.53 laps here, 1.31 published: the one pin on how FAST the car covers track (ratio 1.17)
+      treitlstrasse agent on its track  0.78 here, 2.00 published: the shipped checkpoint drives at 1.1 m/s (it was trained for the
+                                        real car, ros_agent/checkpoints/treitlstrasse_dreamer) - 2.00 laps of 51.65 m in 40 s need
+                                        2.6 m/s: it is NOT the paper's agent, whatever this env's longitudinal law
+      columbia ........................ no shipped agent drives it (the austria agent touches a wall in every episode): 2.23 cannot be tested."""
+    ep = _protocol()
+    n = 8
+    a = ep.run_episodes("austria", "austria", n, repeat=4, max_agent_steps=1000, laps=10)
+    assert (a["ended"] == "limit").all(), a["ended"]                       # 40 s without a wall contact, every episode
+    ratio = a["progress"].mean() / PUBLISHED_DREAMER["austria"]
+    assert G12_BAND[0] <= ratio <= G12_BAND[1], (a["progress"], ratio)
+    assert a["progress"].max() - a["progress"].min() < 0.1                  # (the sampled policy's episodes differ by centimetres per second)
+    assert np.all(a["time"] == pytest.approx(40.0, abs=0.05))
+    t = ep.run_episodes("treitlstrasse_v2", "treitlstrasse", n, repeat=4, max_agent_steps=1000, laps=10)
+    assert t["mean_speed"].mean() < 1.5 and np.median(t["progress"]) < 0.5 * PUBLISHED_DREAMER["treitlstrasse_v2"], t
+    need = PUBLISHED_DREAMER["treitlstrasse_v2"] * 51.65 / 40.0            # m/s the published figure implies on this track
+    assert need > 2.0 * t["mean_speed"].mean()
+    c = ep.run_episodes("columbia", "austria", n, repeat=4, max_agent_steps=1000, laps=10)
+    assert (c["ended"] == "wall").sum() >= n - 1 and np.median(c["progress"]) < 1.0
+
+
+def test_g12_the_dreamer_evaluation_protocol_repeat_8_one_lap():
+    """dreamer/evaluations/run_evaluation.py:76 + make_env.py:9-15: scenario eval (laps 1), grid start, action_repeat 8, no
+    TimeLimit wrapper.  The austria agent completes its lap in 7 of 8 episodes here (32.8 s: 2.4 m/s - at eight sub-steps per
+    decision it drives more carefully than at the four it was trained with)."""
+    ep = _protocol()
+    b = ep.run_episodes("austria", "austria", 8, repeat=8, max_agent_steps=2250, laps=1)
+    done = b["ended"] == "laps"
+    assert done.sum() >= 6 and 25.0 < b["time"][done].mean() < 45.0, b
+    assert np.all(b["progress"][done] >= 1.0) and np.all(b["progress"][done] < 1.02)
+
+
+def test_g12_austrias_first_hairpin_is_where_the_model_free_agents_stop():
+    """dreamer/plotting/structs.py:23: on austria EVERY model-free baseline's best progress is 0.36 - 0.38 laps.  A property of
+    this build's progress grid, independent of any agent: the first turn of austria's centre line that changes the heading by
+    more than 2 rad within 5 m (the first hairpin; the next one is at 0.54) has its apex at 0.35 of the lap, and every published
+    model-free figure lies between that apex and 3 m (0.04 lap) behind it - in the hairpin, not before it and not past its exit:
+    the published stall point is this build's hairpin, so start line, direction of travel and progress normalisation of the
+    costmap agree with the reference's to within a few per cent of a lap."""
+    cl = np.asarray(load_track("austria").centerline, np.float64)
+    th = np.unwrap(cl[:, 2])
+    k = 25                                                        # bins of 0.1 m either side
+    turn = np.abs(np.roll(th, -k) - np.roll(th, k))
+    turn[:k] = turn[-k:] = 0.0
+    first = int(np.argmax(turn > 2.0))                            # where the 5 m window first holds such a turn
+    stretch = [i for i in range(first, first + 3 * k) if turn[i] > 2.0]
+    apex = cl[int(round(np.mean(stretch))), 3]
+    assert 0.34 <= apex <= 0.37, apex
+    lap_m = len(cl) * 0.1
+    for name, best in PUBLISHED_MODEL_FREE_AUSTRIA.items():
+        assert apex <= best <= apex + 3.0 / lap_m + 0.005, (name, best, apex)
+    # nothing like it before: an agent that cannot take a hairpin gets exactly this far
+    assert turn[:first - 2 * k].max() < 1.6

@@ -61,3 +61,19 @@ def test_reference_agent_drives_a_thousand_cars_on_the_device():
     crashes_m, _, _ = drive(dev, DreamerPolicy(weights("austria"), sample=False), n, 60, mode=ro.RESET_RANDOM, mirror=True)
     assert crashes_m >= n // 2, crashes_m
     dev.env.close()
+
+
+def test_g12_the_references_test_protocol_on_the_device():
+    """G12 on the HIP env (tests/test_golden_policy.py has the C-oracle run and the published numbers): the austria agent under
+    dreamer/dream.py's test protocol - grid start, action_repeat 4, 1000 agent steps = 40 s, max_progress scenario - covers
+    1.31 x [0.85, 1.35] laps without touching a wall; the deterministic agent's episode is the C oracle's, bit for bit."""
+    from test_golden_policy import G12_BAND, PUBLISHED_DREAMER, _protocol
+    ep = _protocol()
+    n = 8
+    a = ep.run_episodes("austria", "austria", n, repeat=4, max_agent_steps=1000, laps=10, backend="hip")
+    assert (a["ended"] == "limit").all(), a["ended"]
+    ratio = a["progress"].mean() / PUBLISHED_DREAMER["austria"]
+    assert G12_BAND[0] <= ratio <= G12_BAND[1], (a["progress"], ratio)
+    d = ep.run_episodes("austria", "austria", 4, repeat=4, max_agent_steps=1000, laps=10, backend="hip", sample=False)
+    c = ep.run_episodes("austria", "austria", 4, repeat=4, max_agent_steps=1000, laps=10, backend="c", sample=False)
+    assert np.array_equal(d["progress"], c["progress"]) and np.array_equal(d["time"], c["time"])
