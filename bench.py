@@ -984,8 +984,10 @@ def main():
     elif gather_mode == "none":
         gather_txt = "NO trajectory exchange (--gather none)"
     elif gather_mode == "sharded":
-        gather_txt = ("trajectory store sharded: " + gather.includes + "; the per-step gathers of whole records are the "
-                      "`full-u16` / `full` legs of gather_modes")
+        gather_txt = ("`value` is timed with THIS payload on the links - trajectory store sharded: " + gather.includes
+                      + "; the per-step gathers of whole records are the `full-u16` / `full` legs of gather_modes (a record per "
+                        "sub-step) and of gather_modes_repeat_4 (a record per agent step of 4 sub-steps: the reference's cadence); "
+                        "BASELINE configs[4]'s track mix is the leg configs4_track_mix")
     else:
         how = {"torch": "RCCL all-gather through torch.distributed", "abi": "RCCL all-gather through rc_gather_trajectory",
                "p2p": "direct peer copies through rc_gather_trajectory_p2p (hipIpc, one copy stream per peer)"}[via]
@@ -1148,9 +1150,75 @@ def main():
                 if rank == 0:
                     out["gather_modes"][m] = e
                     out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
+    # The whole-record gathers at the REFERENCE's cadence: Collect records one transition per AGENT step
+    # (dreamer/wrappers.py:107-116 ActionRepeat inside, :213-219 Collect outside), the reference runs action_repeat 4
+    # (dreamer/dream.py:55) - so one record crosses the links per 4 sub-steps, the scan runs once per record, and the link
+    # bound is set against a step of four dynamics kernels + one scan.  (The legs above gather a record per sub-step.)
+    if distributed and not args.no_gather_modes:
+        out["gather_modes_repeat_4"] = {} if rank == 0 else None
+        for m in ("full-u16", "full"):
+            with guard.leg(m + "@repeat4"):
+                g = make_collector(m)
+                n_leg = max(args.steps // 4, 5)
+                step_no += preheat(g, step_no, 40)
+                finish(g)
+                t = timed(g, step_no, n_leg, repeat=4)
+                step_no += n_leg
+                e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
+                e["link_bound_ms_per_agent_step"] = e.pop("link_bound_ms_per_step")
+                e["bytes_per_gpu_per_agent_step"] = e.pop("bytes_per_gpu_per_step")
+                e["inbound_bytes_per_gpu_per_agent_step"] = e.pop("inbound_bytes_per_gpu_per_step")
+                e.update(action_repeat=4, ms_per_agent_step=t / n_leg * 1e3, agent_steps_per_s=total_envs * n_leg / t,
+                         env_steps_per_s=total_envs * n_leg * 4 / t, agent_steps=n_leg, includes=g.includes,
+                         cadence="one record per agent step of 4 sub-steps, the scan once per record (dreamer/wrappers.py:107-116,213-219; dream.py:55)")
+                if not args.no_gather_check:
+                    c = g.check(step_no, dist)
+                    step_no += 8
+                    e["check"] = c
+                    checks[m + "@repeat4"] = c
+                g.close()
+                if rank == 0:
+                    out["gather_modes_repeat_4"][m] = e
+                    out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
     if getattr(env, "_p2p_mode", None) is not None:
         with guard.leg("p2p_close"):
             p2p_close()
+
+    # BASELINE.json configs[4] inside the plain `--gpus N` run: rank r on [columbia, austria, barcelona][r mod 3],
+    # the headline's payload (the sharded store) over the mix.  Each rank builds a SECOND env on its track of the mix (the
+    # headline's env stays as it is); ranks on different tracks run steps of different length, so the closing barrier waits for
+    # the slowest track - which is the point of the configuration.
+    if distributed and not args.mixed_tracks and not args.no_gather_modes:
+        with guard.leg("configs4_track_mix"):
+            mix = ["columbia", "austria", "barcelona"]
+            mine = mix[rank % 3]
+            env_mix = BatchedRaceEnv(load_track(mine), shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
+                                     device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
+            env_mix.reset(mode="random", seed=0)
+            head_env, env = env, env_mix              # (the collectors close over `env`)
+            try:
+                torch.cuda.set_stream(env.stream)
+                g = make_collector(gather_mode)
+                k = 0
+                if gather_mode == "sharded":
+                    k += g.prefill(k)
+                k += preheat(g, k)
+                finish(g)
+                n_leg = max(args.steps, 2 * BATCH_EVERY)
+                t = timed(g, k, n_leg)
+                g.close()
+            finally:
+                env = head_env
+                torch.cuda.set_stream(env.stream)
+                env_mix.close()
+            tracks_by_rank = [None] * world
+            dist.all_gather_object(tracks_by_rank, mine)
+            if rank == 0:
+                out["configs4_track_mix"] = {
+                    "workload": f"BASELINE.json configs[4]: {total_envs} envs over {world} ranks, rank r on [columbia, austria, barcelona][r mod 3], "
+                                f"payload = the headline's ({gather_mode})",
+                    "tracks_by_rank": tracks_by_rank, "steps": n_leg, "ms_per_step": t / n_leg * 1e3,
+                    "env_steps_per_s": total_envs * n_leg * args.repeat / t, "gather": gather_mode}
 
     # secondary figure: cars driven along the track at speed by the reference's follow-the-gap law (its other prefill
     # policy, dreamer/dream.py:211-216) instead of crawling under random actions: single-GPU runs only

@@ -165,3 +165,17 @@ def test_bench_two_ranks_functional():
     assert gm["summary"]["bytes_per_gpu_per_step"] == pytest.approx(2048 * 76, rel=0.05)
     assert all(gm[m]["ms_per_step"] > 0 for m in gm) and gm["none"]["link_bound_ms_per_step"] == 0.0
     assert gm["full"]["link_bound_ms_per_step"] == pytest.approx(2 * gm["full-u16"]["link_bound_ms_per_step"], rel=0.02)
+    # the plain `--gpus N` line carries the north star's workload - the whole-record gathers at the reference's
+    # cadence (one record per agent step of 4 sub-steps) with their byte counts and link bounds, and configs[4]'s track mix
+    r4 = d["gather_modes_repeat_4"]
+    assert set(r4) == {"full-u16", "full"}
+    for m, per_car in (("full-u16", 2236), ("full", 4396)):
+        e = r4[m]
+        assert e["action_repeat"] == 4 and e["bytes_per_gpu_per_agent_step"] == pytest.approx(2048 * per_car, rel=0.01)
+        assert e["ms_per_agent_step"] > 0 and e["env_steps_per_s"] == pytest.approx(4 * e["agent_steps_per_s"], rel=1e-6)
+        assert e["link_bound_ms_per_agent_step"] == pytest.approx(gm[m]["link_bound_ms_per_step"], rel=1e-6)
+        assert e["check"]["ok"] is True and "agent step" in e["cadence"]
+    mix = d["configs4_track_mix"]
+    assert mix["tracks_by_rank"] == ["columbia", "austria"] and mix["gather"] == "sharded" and mix["env_steps_per_s"] > 0
+    assert "configs[4]" in mix["workload"] and "`value` is timed with THIS payload" in d["config"]["workload"]
+    assert d["gather_check"]["ok"] is True and {"full@repeat4", "full-u16@repeat4"} <= set(d["gather_check"]["payloads"])

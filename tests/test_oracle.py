@@ -396,7 +396,8 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
 # of the random starts touch a wall there (a start with zero lateral room keeps the centre-line POSITION but still turns by up to
 # 0.35 rad).  Found in round 5 by the test below; recorded in DESIGN.md 2 item 6, not repaired.
 NARROW_MAPS = {"plechaty2", "plechaty2nobox", "skirk", "torino", "torino_redraw_small_with_obstacles", "train_pile_of_blocks",
-               "train_pile_of_blocks_flipped"}
+               "train_pile_of_blocks_flipped",
+               "levinelobby"}      # (a building lobby compiled from a start of its own: an open area, not a loop - its "centre line" jumps between rooms: 7 %)
 
 
 def test_no_multi_car_start_overlaps_on_any_compiled_map():
