@@ -1,0 +1,11 @@
+#!/bin/bash
+# One A/B session on the GPU box: parity of every variant in racing_dreamer_amd/lib/ab/, then tools/ab_bench.sh.
+#   bash tools/ab_session.sh [reps] [bench args...] > gpurun_out/ab.log
+lib=racing_dreamer_amd/lib/libracecar_hip.so
+cp $lib /tmp/ab_session_original.so
+for v in racing_dreamer_amd/lib/ab/*.so; do
+  cp $v $lib
+  timeout -k 10 300 python tools/ab_check.py $(basename $v .so) 2>&1 | grep ab_check || echo "ab_check $(basename $v .so): FAILED"
+done
+cp /tmp/ab_session_original.so $lib
+bash tools/ab_bench.sh "$@"
