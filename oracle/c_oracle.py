@@ -77,6 +77,8 @@ def load():
         for f in (lib.oc_reset, lib.oc_step_range, lib.oc_raycast_range, lib.oc_patch_range, lib.oc_random_actions, lib.oc_spawn_width,
                   lib.oc_spawn_safe):
             f.restype = None
+        lib.oc_set_dynamics.argtypes = [C.c_float] * 5
+        lib.oc_set_dynamics.restype = None
         lib.oc_spin.argtypes = [C.c_uint64]
         lib.oc_spin.restype = C.c_uint64
         _lib = lib
@@ -214,3 +216,10 @@ class COracleEnv:
         if self.cfg.render_occupancy:
             d["lidar_occupancy"] = self.patch.copy()
         return d
+
+
+def set_dynamics(accel_max=None, drag=None, max_vel=None, steer_gain=None, steer_step=None):
+    """Calibration sweeps only (tools/analysis/agent_calibration.py): the integrator's free parameters of EVERY C-oracle env of
+    this process; None = the spec's value (racecar_oracle.py).  `set_dynamics()` restores the spec."""
+    v = lambda x, d: float(d if x is None else x)
+    load().oc_set_dynamics(v(accel_max, ro.ACCEL_MAX), v(drag, ro.DRAG), v(max_vel, ro.MAX_VEL), v(steer_gain, ro.STEER_GAIN), v(steer_step, ro.STEER_STEP))

@@ -40,6 +40,12 @@
 #define ACCEL_MAX 4.0f
 #define DRAG 0.8f
 #define STEER_STEP 0.032f
+/* The free parameters of the integrator as variables, the spec's values by default: the calibration sweeps against the
+ * reference's trained agents (tools/analysis/agent_calibration.py) set them through oc_set_dynamics; nothing else does. */
+static struct { float accel_max, drag, max_vel, steer_gain, steer_step; } g_dyn = {ACCEL_MAX, DRAG, MAX_VEL, STEER_GAIN, STEER_STEP};
+void oc_set_dynamics(float accel_max, float drag, float max_vel, float steer_gain, float steer_step) {
+    g_dyn.accel_max = accel_max; g_dyn.drag = drag; g_dyn.max_vel = max_vel; g_dyn.steer_gain = steer_gain; g_dyn.steer_step = steer_step;
+}
 #define BOX_CX 0.175f
 #define BOX_HL 0.275f
 #define BOX_HW 0.15f
@@ -376,10 +382,10 @@ void oc_step_range(const oc_track *t, const oc_cfg *c, oc_state *s, const float 
                 for (int a = 0; a < A; ++a) {
                     const int i = e * A + a;
                     const float m = motor[a];
-                    const float force = fabsf(m) * ACCEL_MAX;
-                    const float acc = (m >= 0.0f ? force : -force) - DRAG * s->v[i];
-                    const float v = clampf(s->v[i] + acc * DT, 0.0f, MAX_VEL);
-                    const float dd = clampf(steer[a] * STEER_GAIN - s->delta[i], -STEER_STEP, STEER_STEP);
+                    const float force = fabsf(m) * g_dyn.accel_max;
+                    const float acc = (m >= 0.0f ? force : -force) - g_dyn.drag * s->v[i];
+                    const float v = clampf(s->v[i] + acc * DT, 0.0f, g_dyn.max_vel);
+                    const float dd = clampf(steer[a] * g_dyn.steer_gain - s->delta[i], -g_dyn.steer_step, g_dyn.steer_step);
                     const float dl = s->delta[i] + dd;
                     float sd, cd;
                     sincos32(dl, &sd, &cd);

@@ -59,9 +59,8 @@ def main():
         print(path, os.path.getsize(path), "bytes")
 
 
-def occupancy_agent():
-    """treitlstrasse_dreamer_20210224: the agent trained with the lidar_occupancy reconstruction (LidarOccupancyDecoder)."""
-    directory = "treitlstrasse_dreamer_20210224"
+def occupancy_agent(directory="treitlstrasse_dreamer_20210224", name="treitlstrasse_occupancy"):
+    """treitlstrasse_dreamer_20210224 / _20210220: the agents trained with the lidar_occupancy reconstruction (LidarOccupancyDecoder)."""
     rssm, h1 = read(os.path.join(CHECKPOINTS, directory, "rssm.pkl"), RSSM_SHAPES)
     actor, h2 = read(os.path.join(CHECKPOINTS, directory, "actor.pkl"), ACTOR_NORM_SHAPES)
     decoder, h3 = read(os.path.join(CHECKPOINTS, directory, "decoder.pkl"), DECODER_SHAPES)
@@ -70,7 +69,7 @@ def occupancy_agent():
     out.update(zip(DECODER_KEYS, decoder))
     assert (out["hnorm_var"] > 0).all()
     out["source"] = np.array(f"ros_agent/checkpoints/{directory}/rssm.pkl sha256 {h1}; actor.pkl sha256 {h2}; decoder.pkl sha256 {h3}")
-    path = os.path.join(ROOT, "tests", "golden", "dreamer_policy_treitlstrasse_occupancy.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"dreamer_policy_{name}.npz")
     np.savez_compressed(path, **out)
     print(path, os.path.getsize(path), "bytes")
 
@@ -78,3 +77,4 @@ def occupancy_agent():
 if __name__ == "__main__":
     main()
     occupancy_agent()
+    occupancy_agent("treitlstrasse_dreamer_20210220", "treitlstrasse_20210220")      # (round 5: the fourth shipped checkpoint, for G12)

@@ -1072,7 +1072,7 @@ def test_random_starts_at_full_size_are_all_different_and_touch_nothing():
         want = np.asarray(ora.reset(mode=spec.RESET_MODES[mode], seed=3)["pose"]).reshape(n, cars, 6)
         assert np.array_equal(pose, want)
         distinct = len(np.unique(pose.reshape(n, -1), axis=0))
-        assert distinct == n or (track_name == "columbia" and distinct > 0.98 * n)      # (envs whose proposals clash share the centre-line poses)
+        assert distinct == n or (track_name == "columbia" and distinct > 0.95 * n)      # (envs whose proposals clash share the centre-line poses)
         if cars == 2:
             gap = np.linalg.norm(pose[:, 0, :2] - pose[:, 1, :2], axis=1)
             assert gap.min() > 0.3 and gap.max() < 1.2 + 2 * 1.5
