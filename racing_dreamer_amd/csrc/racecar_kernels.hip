@@ -1761,7 +1761,8 @@ size_t g_lds_limit = 0;              // what rck_set_lds_limits was last called 
 
 const Lab &lab() {
     std::lock_guard<std::mutex> lock(g_lab_mutex);
-    if (g_lab.handle != nullptr || !g_lab.why.empty()) return g_lab;
+    if (g_lab.handle != nullptr) return g_lab;
+    g_lab.why.clear();               // (not loaded yet: look again - it may have been built since the last request)
     Dl_info info;
     std::string dir = ".";
     if (dladdr(reinterpret_cast<const void *>(&rck_set_launch_events), &info) != 0 && info.dli_fname != nullptr) {
@@ -1794,10 +1795,16 @@ const Lab &lab() {
 }
 }  // namespace
 
-// nullptr if the lab's kernels can be launched, else the reason (a string that lives as long as the process)
+// nullptr if the lab's kernels can be launched, else the reason (the calling thread's copy: valid until its next call)
 const char *rck_lab_unavailable() {
+    thread_local std::string reason;
     const Lab &l = lab();
-    return l.handle != nullptr ? nullptr : l.why.c_str();
+    if (l.handle != nullptr) return nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_lab_mutex);
+        reason = l.why;
+    }
+    return reason.c_str();
 }
 
 hipError_t rck_set_lds_limits(size_t lds_bytes) {
