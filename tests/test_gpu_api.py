@@ -310,3 +310,36 @@ def test_instrumented_scan_gives_the_same_ranges_and_sane_stamps():
     assert torch.equal(va["lidar"], vb["lidar"]) and int(stamps.abs().sum()) == 0
     a.close()
     b.close()
+
+
+def test_lab_kernels_fail_loudly_when_the_lab_library_is_absent():
+    """The shipped library carries no lab kernels: with libracecar_lab.so out of reach, asking for a superseded scan
+    variant or for the instrumented scan is an ERROR that names the build command - not a fallback - and the shipped scan goes on
+    working.  (A process of its own: the lab library, once loaded, stays loaded.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys
+os.environ["RC_LAB_LIBRARY"] = "/nonexistent/libracecar_lab.so"
+sys.path.insert(0, %r)
+import torch
+from racing_dreamer_amd.batched_env import BatchedRaceEnv
+env = BatchedRaceEnv("columbia", 64, 1, auto_reset=True)
+env.reset(mode="random", seed=1)
+rc = env._lib.rc_set_raycast_variant(env._h, 3)
+print("variant", rc, env._lib.rc_last_error().decode())
+buf = torch.zeros((4, 32), dtype=torch.int64, device="cuda")
+rc2 = env._lib.rc_debug_scan_stamps(env._h, buf.data_ptr(), 4)
+print("stamps", rc2, env._lib.rc_last_error().decode())
+out = env.step_random(1, 0)
+torch.cuda.synchronize()
+print("scan", env.scan_kernel_name(), float(out["lidar"].max()))
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = {l.split(" ", 1)[0]: l for l in r.stdout.splitlines() if l.split(" ", 1)[0] in ("variant", "stamps", "scan")}
+    for key in ("variant", "stamps"):
+        assert int(lines[key].split()[1]) != 0 and "lab library is not built" in lines[key] and "racing_dreamer_amd.build --lab" in lines[key], lines[key]
+    assert "rc_raycast_car_kernel<1" in lines["scan"] and float(lines["scan"].split()[-1]) > 1.0
