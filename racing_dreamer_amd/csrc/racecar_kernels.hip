@@ -1774,7 +1774,8 @@ const Lab &lab() {
     const std::string path = over != nullptr ? std::string(over) : dir + "/libracecar_lab.so";
     void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (h == nullptr) {
-        g_lab.why = "the lab library is not built (" + path + ": " + std::string(dlerror() ? dlerror() : "not found") +
+        const char *err = dlerror();              // (once: the call clears the message)
+        g_lab.why = "the lab library is not built (" + path + ": " + std::string(err != nullptr ? err : "not found") +
                     "); build it with `python -m racing_dreamer_amd.build --lab`";
         return g_lab;
     }
