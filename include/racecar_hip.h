@@ -401,6 +401,12 @@ void rc_spec_tables(float *beams_1080x2, float *footprint_34x2);
  * [27, 227] (2^-100 .. 2^100, 3.37e9 values) on `device`; *n_mismatch must come back 0. */
 int rc_selftest_reciprocal(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
 
+/* The same for the square root of the reference follow-the-gap agent's arccos (ros_agent/agents/follow_the_gap/src/agent.py:171:
+ * np.arccos; spec: oracle.acos32): v_sqrt_f32 alone is good to 1 ulp, the kernel's fix-up (two fused residuals) makes it the
+ * correctly rounded root the spec's np.sqrt is.  Checks every positive binary32 from 2^-60 to 2^10 (587 M values) and zero
+ * against the double-precision root rounded once; *n_mismatch must come back 0. */
+int rc_selftest_sqrt(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
+
 const char *rc_last_error(void);
 int rc_abi_version(void);
 /* Hash (32 hex digits) of the compiler flags and of the contents of every source and header this library was built

@@ -114,6 +114,7 @@ SYMBOLS = {
     "rc_spec_tables": (None, [C.c_void_p, C.c_void_p]),
     "rc_set_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rc_selftest_sqrt": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rc_last_error": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),
     "rc_build_id": (C.c_char_p, []),

@@ -560,6 +560,25 @@ int rc_selftest_reciprocal(int32_t device, uint64_t *n_checked, uint64_t *n_mism
     return RC_OK;
 }
 
+int rc_selftest_sqrt(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch) {
+    if (!n_checked || !n_mismatch) return fail(RC_ERR_INVALID, "NULL output pointer");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *dev = nullptr, host = 0;
+    HIP_TRY(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemset(dev, 0, sizeof(host));
+    // every positive binary32 from 2^-60 to 2^10: far beyond the arguments the reference follow-the-gap agent's arccos takes it for
+    // ((1 - |x|) / 2 in [0, 0.25]); zero is checked with them
+    const uint32_t lo_bits = (127u - 60u) << 23, hi_bits = ((127u + 10u) << 23) - 1u;
+    if (e == hipSuccess) e = rck_launch_selftest_sqrt(lo_bits, hi_bits, dev, nullptr);
+    if (e == hipSuccess) e = rck_launch_selftest_sqrt(0u, 0u, dev, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(RC_ERR_HIP, "rc_selftest_sqrt: %s", hipGetErrorString(e));
+    *n_checked = (uint64_t)(hi_bits - lo_bits + 1u) + 1u;
+    *n_mismatch = host;
+    return RC_OK;
+}
+
 void rc_spec_tables(float *beams_1080x2, float *footprint_34x2) {
     if (beams_1080x2 && footprint_34x2) make_tables(beams_1080x2, footprint_34x2);
 }

@@ -1158,11 +1158,34 @@ __device__ __forceinline__ float fr_asin_small(float t) {            // |t| <= 0
     const float pz = ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z;
     return pz * t + t;
 }
+// Correctly rounded binary32 square root for 2^-96 <= x < 2^96 (what the spec's np.sqrt is).  `__fsqrt_rn` compiles to the bare
+// v_sqrt_f32 here, which is good to 1 ulp only: one scan in ~150 000 put an extension's end within that ulp of a beam index and
+// the device agent's heading half a beam off the spec's (found in round 5 on the re-mapped columbia; tests/test_gpu_parity.py).
+// The fix-up is the standard one: with s the instruction's result and s-, s+ its neighbours, the residuals x - s- s and x - s+ s
+// (each ONE fma, exact enough to carry the sign) say on which side of s the root lies.
+__device__ __forceinline__ float fr_sqrt_rn(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return (x == 0.0f || !(x == x)) ? s : r;                             // (zero and NaN: the instruction's own answer)
+}
+// Device self-test of that (rc_selftest_sqrt): every binary32 in [lo_bits, hi_bits] against the double-precision root rounded once
+__global__ __launch_bounds__(256) void rc_selftest_sqrt_kernel(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    for (uint64_t b = (uint64_t)lo_bits + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b <= hi_bits; b += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)b);
+        bad += __float_as_uint(fr_sqrt_rn(x)) != __float_as_uint((float)sqrt((double)x));
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 __device__ __forceinline__ float fr_acos(float x) {                  // racecar_oracle.acos32
     const float ax = fabsf(x);
     if (!(ax <= 1.0f)) return __builtin_nanf("");
     if (ax > 0.5f) {
-        const float a = 2.0f * fr_asin_small(__fsqrt_rn((1.0f - ax) * 0.5f));
+        const float a = 2.0f * fr_asin_small(fr_sqrt_rn((1.0f - ax) * 0.5f));
         return x < 0.0f ? 3.14159274101257324f - a : a;
     }
     return 1.57079637050628662f - fr_asin_small(x);
@@ -1922,6 +1945,11 @@ hipError_t rck_launch_ftg_reference(const RcParams &p, float *actions, float *pr
 hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s) {
     const int threads = 256, blocks = (p.n_cars + threads - 1) / threads;
     launch(rc_set_pose_kernel, dim3(blocks), dim3(threads), 0, s, p, xyyaw_dev);
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_selftest_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches_dev, hipStream_t s) {
+    hipLaunchKernelGGL(rc_selftest_sqrt_kernel, dim3(4096), dim3(256), 0, s, lo_bits, hi_bits, mismatches_dev);
     return hipGetLastError();
 }
 

@@ -42,13 +42,23 @@ from scipy import ndimage
 
 # track name (as used by the reference's scenario files) -> map yaml basename
 # (docs/maps/README.md:23,27-30; dreamer/scenarios/max_progress/*.yml world.name)
+# columbia (round 5): the authors' own drawing of the F1TENTH Columbia track, `columbia_small` - NOT `columbia.pgm`, the raw
+# f1tenth_simulator map of the same name (an open blob of free space around a thin divider, 24.3 m round its inner edge, on which no
+# shipped agent drives).  Evidence: the published progress figures for columbia (2.0 - 2.2 laps in 40 s for every
+# method, dreamer/plotting/structs.py:23-28) are 3.0 - 3.4 m/s on columbia_small's 61.2 m and an absurd 1.3 m/s on the blob; both
+# shipped Dreamer agents lap columbia_small zero-shot (2.4 - 2.5 laps) and hit a wall in every episode on the blob; and
+# columbia_small carries the start-line markings (chequered flags, arrow at world (0, 0)) of the authors' other scene maps
+# (f1_aut, f1_esp, Treitlstrasse_3-U_*).  The raw map stays available as `columbia_slam`.
 TRACK_TO_MAP = {
-    "columbia": "columbia",
+    "columbia": "columbia_small",
     "austria": "f1_aut",
     "barcelona": "f1_esp",
     "gbr": "f1_gbr",
     "treitlstrasse_v2": "Treitlstrasse_3-U_v2",
 }
+
+# maps whose yaml basename is now another track's name: stored under these asset names
+MAP_ASSET_NAME = {"columbia": "columbia_slam"}
 
 CROP_MARGIN = 16          # cells of context kept around the drivable bbox (0.8 m)
 CENTERLINE_BIN = 2        # BFS steps per centerline bin (0.1 m of arc)
@@ -190,7 +200,8 @@ class TrackCompileError(ValueError):
 
 
 def _load_map(name: str, maps_dir: str, world_start):
-    map_name = TRACK_TO_MAP.get(name, name)
+    by_asset = {v: k for k, v in MAP_ASSET_NAME.items()}
+    map_name = TRACK_TO_MAP.get(name, by_asset.get(name, name))
     with open(os.path.join(maps_dir, map_name + ".yaml")) as f:
         props = yaml.safe_load(f)
     res = float(props["resolution"])
@@ -339,7 +350,7 @@ def compile_all(maps_dir: str, out_dir: str) -> dict:
     index = {}
     for path in sorted(glob.glob(os.path.join(maps_dir, "*.yaml"))):
         map_name = os.path.basename(path)[:-5]
-        name = by_map.get(map_name, map_name)
+        name = by_map.get(map_name, MAP_ASSET_NAME.get(map_name, map_name))
         if name in refused:
             index[name] = {"map": map_name, "status": "not compiled", "reason": refused[name]}
             continue

@@ -319,7 +319,9 @@ def gen_patches(W, out):
     from racing_dreamer_amd.track_assets import load_track
     rng = np.random.default_rng(7)
     data = {"versions": versions()}
-    for name in ("austria", "treitlstrasse_v2", "columbia"):
+    # (columbia_slam = docs/maps/maps/columbia.pgm, "columbia" until round 5; columbia = columbia_small, appended: the random stream
+    # of the first three tracks is what it was)
+    for name in ("austria", "treitlstrasse_v2", "columbia_slam", "columbia"):
         t = load_track(name)
         gm = FullFrameMap(t)
         # >= 64 poses per track: 64 along the track with lateral / heading jitter, 24 pushed up to and

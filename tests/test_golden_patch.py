@@ -30,7 +30,7 @@ def _nonconstant(img, rad=1):
     return ndimage.maximum_filter(img, size=(1, k, k), mode="nearest") != ndimage.minimum_filter(img, size=(1, k, k), mode="nearest")
 
 
-@pytest.mark.parametrize("name", ["austria", "treitlstrasse_v2", "columbia"])
+@pytest.mark.parametrize("name", ["austria", "treitlstrasse_v2", "columbia_slam", "columbia"])
 def test_patch_agrees_with_reference(name):
     """>= 64 poses per track along the track, 24 pushed to and past the track border, yaws at both ends of (-pi, pi]
     (tests/golden/make_golden.py).  Beyond the pixel agreement, WHERE the sampler and the reference differ is pinned:

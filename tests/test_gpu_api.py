@@ -108,7 +108,9 @@ def test_reciprocal_selftest_is_exact_on_this_device():
     reciprocal (what the oracle's `1.0f / d` is) for every input in the fast path's range - checked exhaustively
     on the device the tests run on."""
     import ctypes as C
+    import torch
     from racing_dreamer_amd import _lib as L
+    torch.cuda.init()        # (torch first: once another library has initialised HIP in the process, torch.cuda.is_available() reads False)
     lib = L.load_library()
     n, bad = C.c_uint64(0), C.c_uint64(0)
     L.check(lib.rc_selftest_reciprocal(0, C.byref(n), C.byref(bad)))
@@ -343,3 +345,16 @@ print("scan", env.scan_kernel_name(), float(out["lidar"].max()))
     for key in ("variant", "stamps"):
         assert int(lines[key].split()[1]) != 0 and "lab library is not built" in lines[key] and "racing_dreamer_amd.build --lab" in lines[key], lines[key]
     assert "rc_raycast_car_kernel<1" in lines["scan"] and float(lines["scan"].split()[-1]) > 1.0
+
+
+def test_sqrt_selftest_is_exact_on_this_device():
+    """The reference follow-the-gap agent's arccos takes a square root; the kernel's root (v_sqrt_f32 + a two-residual fix-up)
+    must be the correctly rounded one the spec's np.sqrt is - checked over every binary32 from 2^-60 to 2^10 on the device."""
+    import ctypes as C
+    import torch
+    from racing_dreamer_amd import _lib as L
+    torch.cuda.init()        # (torch first, see the reciprocal self-test)
+    lib = L.load_library()
+    n, bad = C.c_uint64(0), C.c_uint64(0)
+    L.check(lib.rc_selftest_sqrt(0, C.byref(n), C.byref(bad)))
+    assert n.value == 70 * (1 << 23) + 1 and bad.value == 0

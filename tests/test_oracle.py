@@ -327,7 +327,8 @@ def test_scan_equals_brute_force_ray_box_intersection():
     assert worst < 2e-4
 
 
-@pytest.mark.parametrize("track_name,cars", [("columbia", 1), ("austria", 1), ("treitlstrasse_v2", 2), ("barcelona", 4), ("columbia", 3)])
+@pytest.mark.parametrize("track_name,cars", [("columbia", 1), ("austria", 1), ("treitlstrasse_v2", 2), ("barcelona", 4), ("columbia_slam", 1),
+                                             ("columbia_slam", 3), ("columbia", 3)])
 def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
     """H6 (dreamer/dream.py:105-108): `random` = a pose on the track with a minimum wall distance, heading along the
     track; `random_ball` = the cars of an env close together around one random point.  Checked on the C port (bit-identical
@@ -366,20 +367,20 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
         dyaw = (yaw[:, a] - cl[idx, 2] + np.pi) % (2 * np.pi) - np.pi
         assert np.all(np.abs(dyaw) <= float(ro.HEADING_JITTER) + 1e-5), a
         moved = width[idx] > 0.2
-        if a == 0 or track_name != "columbia":          # (columbia: the cars behind the first stand where the room is small)
+        if a == 0 or track_name != "columbia_slam":     # (the raw columbia map: the cars behind the first stand where the room is small)
             assert np.std(lateral[moved] / width[idx][moved]) > 0.5 and np.std(dyaw) > 0.15      # uniform: sigma = 0.577 / 0.2
     hist = np.bincount(drawn * 40 // len(cl), minlength=40)           # the lap in 40 stretches: 500 starts each
     assert hist.min() > 0.8 * n / 40 and hist.max() < 1.2 * n / 40
     distinct = len(np.unique(pose.reshape(n, -1), axis=0))
-    # (columbia with several cars: next to the fold sound bins lie close on the ground, proposals clash there and the env takes
-    # the centre-line poses - the law's fallback -, which envs share)
-    assert distinct == n or (track_name == "columbia" and cars > 1 and distinct > 0.99 * n)
+    # (the raw columbia map with several cars: next to the fold sound bins lie close on the ground, proposals clash there and the
+    # env takes the centre-line poses - the law's fallback -, which envs share)
+    assert distinct == n or (cars > 1 and distinct > 0.99 * n)
     # nothing touches anything at the start: one step with the brakes on leaves every car where it is and evaluates the contacts
     act = np.zeros((n * cars, 2), np.float32)
     act[:, 0] = -1.0
     out = env.step(act)
     wall, opp = np.asarray(out["wall_collision"]).reshape(n, cars), np.asarray(out["opponent_collision"]).reshape(n, cars)
-    assert int(wall.sum()) == 0 and int(opp.sum()) == 0      # (columbia's folded bins included since round 5: spawn_safe)
+    assert int(wall.sum()) == 0 and int(opp.sum()) == 0      # (columbia_slam's folded bins included since round 5: spawn_safe)
     # a finished env draws a NEW pose (episode counter in the Philox counter)
     env2 = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=64, cars_per_env=cars))
     a0 = np.asarray(env2.reset(mode=mode, seed=5)["pose"]).copy()
@@ -404,7 +405,7 @@ NARROW_MAPS = {"plechaty2", "plechaty2nobox", "skirk", "torino", "torino_redraw_
 def test_no_multi_car_start_overlaps_on_any_compiled_map():
     """20 000 `random_ball` starts per track and A = 2, 3, 4 on EVERY compiled map - no two cars of an env
     overlap, none touches a wall (the spec's own tests, `_obb_overlap` and `_wall_hit`, on the poses the reset law produced;
-    no scan is run: 60 000 x 1080 rays per case would make this a test of minutes).  Columbia's last four centre-line bins run back
+    no scan is run: 60 000 x 1080 rays per case would make this a test of minutes).  columbia_slam's (the raw columbia.pgm's) last four centre-line bins run back
     along the four before them (the BFS wavefronts of its progress grid fold at the finish line):
     `spawn_safe` moves a start drawn there to the next bin whose four poses are clear, and leaves every bin of an ordinary
     track where it is."""
@@ -429,10 +430,10 @@ def test_no_multi_car_start_overlaps_on_any_compiled_map():
                     assert int(env._obb_overlap(e * cars + a, e * cars + b).sum()) == 0, (name, cars, a, b)
         safe = env.spawn_safe()
         moved[name] = int((safe != np.arange(len(safe))).sum())
-    assert moved["columbia"] >= 4 and moved["austria"] == 0 and moved["barcelona"] == 0, moved
+    assert moved["columbia_slam"] >= 4 and moved["columbia"] == 0 and moved["austria"] == 0 and moved["barcelona"] == 0, moved
     # the C port builds the same table (its resets are compared with these bit for bit elsewhere)
     from oracle import c_oracle
-    t = load_track("columbia")
+    t = load_track("columbia_slam")
     cenv = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=2, cars_per_env=2))
     ref = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=2, cars_per_env=2))
     assert np.array_equal(cenv._keep["spawn_safe"], ref.spawn_safe())

@@ -51,7 +51,7 @@ def test_assets_present_and_sane():
 def test_maps_npz_export_has_the_generators_keys_and_values(tmp_path):
     """generate-costmap.py:410-425: key names, value conventions and frame of the racecar_gym-style maps.npz."""
     out = tmp_path / "maps.npz"
-    tc.export_maps_npz("columbia", REF_MAPS, str(out))
+    tc.export_maps_npz("columbia_slam", REF_MAPS, str(out))      # docs/maps/maps/columbia.pgm: not square, the raw f1tenth_simulator map
     d = np.load(out)
     assert sorted(d.files) == ["drivable_area", "norm_distance_from_start", "norm_distance_to",
                                "norm_distance_to_obstacle", "properties"]
@@ -61,7 +61,7 @@ def test_maps_npz_export_has_the_generators_keys_and_values(tmp_path):
     pr = d["properties"]
     assert len(pr) == 12 and tuple(pr[:2]) == (0.0, 0.0) and tuple(pr[2:4]) == (214.0, 153.0)     # start pixel (col, row)
     assert pr[6] == 0.65 and tuple(pr[9:11]) == full and pr[11] == 0.05
-    a = ta.load_track("columbia")
+    a = ta.load_track("columbia_slam")
     r0, c0, fh, fw = a.crop
     drv_full = np.zeros(full, bool)
     drv_full[r0:r0 + a.height, c0:c0 + a.width] = a.drivable[::-1]                                  # asset rows are south-up
@@ -164,7 +164,7 @@ def test_scene_export_is_what_the_plotting_code_loads(tmp_path):
     if not os.path.isdir(maps_dir):
         import pytest
         pytest.skip("needs the reference's map images (build container only)")
-    track = "columbia"
+    track = "columbia_slam"
     config_file = export_scene(track, maps_dir, str(tmp_path))
     assert config_file.endswith(f"{track}/{track}.yml")
     config = SceneConfig()                                                  # plot_trajectories.py:20-25
