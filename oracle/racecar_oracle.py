@@ -456,7 +456,7 @@ class OracleRaceEnv:
         RC_MAX_CARS = 4 cars at bins j, j - 12, j - 24, j - 36 do not overlap pairwise (the rectangle test of H5 on the table's
         own poses); safe[i] = the first sound bin among i, i + 1, ..., i + SPAWN_SAFE_SEARCH - 1 (around the lap), i itself if
         there is none.  A centre line is the most central cell per BFS distance bin, and where the BFS wavefronts of the
-        progress grid fold - columbia's last bins run back along the bins before them, the start pixel lying in an open area
+        progress grid fold - the raw columbia.pgm's (track `columbia_slam`) last bins run back along the bins before them, the start pixel lying in an open area
          - bins 1.2 m apart along the table are centimetres apart on the ground; such bins are never the
         anchor of a multi-car start.  One car: not used (every bin is a start)."""
         if getattr(self, "_spawn_safe", None) is not None:

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float
     const float w = clampf((float)k * t.res - RCS_SPAWN_MARGIN, 0.0f, RCS_SPAWN_W_MAX);
     // Where a multi-car start drawn at this bin really goes (oracle: spawn_safe): the first bin j among i, i + 1, ... (around the
     // lap, RCS_SPAWN_SAFE_SEARCH of them) at which the centre-line poses of RC_MAX_CARS cars RCS_BALL_GAP_BINS apart do not
-    // overlap pairwise; i itself if there is none.  Where the progress grid's wavefronts fold (columbia's last bins run back
+    // overlap pairwise; i itself if there is none.  Where the progress grid's wavefronts fold (columbia_slam's last bins run back
     // along the bins before them) bins 1.2 m apart along the table are centimetres apart on the ground.
     const int n = t.n_centerline;
     int safe = i;
