@@ -71,14 +71,14 @@ def test_reference_render_wrapper_collects_per_agent_videos_on_the_shim(ref_wrap
     os.chdir(os.path.join(REF, "baselines"))                      # the 4-agent scenario A..D
     videos = []
     env = W.RaceCarWrapper(W.RaceCarBaseEnv(track="columbia", task="max_progress"), agent_id="A")
-    env = W.TimeLimit(W.FixedResetMode(env, mode="grid"), 6)
+    env = W.TimeLimit(W.FixedResetMode(env, mode="grid"), 40)      # (0.4 s: on columbia's 34 m wide map a bird's-eye pixel is 11 cm)
     env = W.Render(env, callbacks=[lambda v: videos.append({k: list(f) for k, f in v.items()})], follow_view=True)
     env.reset()
     done, steps = False, 0
     while not done:
         obs, rew, dones, info = env.step({a: np.array([0.6, 0.0]) for a in env.agent_ids})
         done, steps = any(dones.values()), steps + 1
-    assert steps == 6 and len(videos) == 1
+    assert steps == 40 and len(videos) == 1
     v = videos[0]
     assert sorted(v) == ["birds_eye-A", "follow-A", "follow-B", "follow-C", "follow-D"]          # wrappers.py:169-173
     for k, frames in v.items():
