@@ -308,14 +308,24 @@ void set_launch_geometry(rc_env *env) {
         li.car_threads = (threads == 64 || threads == 128 || threads == 256) ? threads : 64;
         // one wave per car keeps the chip busy only with several waves per wave slot (8 per SIMD x 4 SIMDs x CUs) for the
         // dispatcher to balance; smaller batches split each car's 17 rounds over `split` waves (round k of a car goes to
-        // wave k mod split).  Measured on columbia: 4 096 cars 0.0343 / 0.0313 / 0.0284 / 0.0308 / 0.0293 / 0.0344 ms
-        // for split 1 / 2 / 3 / 4 / 9 / 17; 16 384 cars 0.0737 / 0.0799 / 0.0750 / 0.0869 ms for 1 / 2 / 3 / 4 - about
-        // 48 waves per CU in total is the sweet spot (a wave's fixed cost, the car's state and first-trip line, is
-        // paid once per wave).
+        // wave k mod split).  Below 8 192 cars every wave is resident at once and the launch lasts as long as its slowest
+        // wave: T = 15 us + 2.9 ns x cars from 4 096 cars up.  Measured on columbia (tools/split_sweep.py, round 5, us):
+        //     cars   split 1      2      3      4      6      9     17
+        //      256     21.6   14.3   12.3   10.9   11.7    9.3    8.9
+        //     1024     23.8   16.5   14.8   13.9   13.0   11.8   12.5
+        //     2048     24.9   18.6   17.1   16.8   17.2   16.7   18.9
+        //     4096     27.0   25.5   24.5   27.4   25.8   26.9   31.8
+        //     6144     31.3   34.7   32.7
+        //     8192     36.6   41.3   39.8   44.7   43.6   46.7   56.6
+        //    16384     62.8   72.2   68.7   81.6   80.2   84.2  105.8
+        // as many waves as the chip holds at once (32 per CU) and never more (a wave's fixed cost - the car's state and
+        // first-trip line, 1.3 us - is paid once per wave, and a second generation of waves waits for the first):
+        // floor(32 n_cu / cars), which is 1 from 4 097 cars up (rounds 2-4 took ceil(48 n_cu / cars): 8 192 cars in two
+        // waves each, 41 us instead of 37; 6 144 cars 35 instead of 31).
         int split = env->dbg[RC_DBG_RAY_SPLIT];
         if (split < 1 || split > 17) {
-            const long long want = 48LL * li.n_cu, n = env->n_cars;
-            split = (int)std::min<long long>(17, std::max<long long>(1, (want + n - 1) / n));
+            const long long want = 32LL * li.n_cu, n = env->n_cars;
+            split = (int)std::min<long long>(17, std::max<long long>(1, want / n));
         }
         li.car_split = split;
     } else if (li.raycast_variant >= 4) {
@@ -1103,9 +1113,9 @@ static int group_step(rc_env **envs, int32_t n, const float *actions_dev, int32_
     g.wave_start[n] = waves;
     TIMED(lead, RC_K_DYNAMICS, rck_launch_dynamics_group(g, lead->cfg.cars_per_env, repeat, ra, lead->stream));
     // scan: a wave = one car (or 1 / split of one); the split follows the group's total, as one handle of that size would
-    const long long want = 48LL * lead->launch.n_cu;
+    const long long want = 32LL * lead->launch.n_cu;
     int split = lead->dbg[RC_DBG_RAY_SPLIT];
-    if (split < 1 || split > 17) split = (int)std::min<long long>(17, std::max<long long>(1, (want + cars - 1) / cars));
+    if (split < 1 || split > 17) split = (int)std::min<long long>(17, std::max<long long>(1, want / cars));
     waves = 0;
     for (int b = 0; b < n; ++b) {
         g.wave_start[b] = waves;

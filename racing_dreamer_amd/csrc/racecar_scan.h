@@ -445,7 +445,7 @@ constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... an
 // STAMPS: the instrumented build (rc_debug_scan_stamps): shader-clock values at fixed points of the wave's life and two
 // counters, RC_STAMP_SLOTS uint64 per wave - slot 0 entry, 1 car state arrived, 2 first-trip line staged and first round
 // prepared, 3 + i end of the wave's i-th round, 20 rounds done, 21 flush issued, 22 wave-level trips, 23 of which took
-// the exact path, 24 HW_ID, 25 / 26 trips per round (a nibble each).
+// the exact path, 24 HW_ID, 5 XCC_ID, 6 / 7 the chip-wide 100 MHz clock at entry / flush, 25 / 26 trips per round (a nibble each).
 // OVERLAP: the next round is prepared under the first request of the current one (ray_traverse's `between`) instead of
 // ahead of the traversal.
 template <int A, bool STAMPS = false, bool OVERLAP = false, bool GUARD = true>
@@ -476,6 +476,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     };
     unsigned long long nib_lo = 0, nib_hi = 0;
     stamp(0);
+    if (STAMPS) stamp_value(6, __builtin_amdgcn_s_memrealtime());       // the 100 MHz reference clock, one for the whole chip (s_memtime is per CU)
     // the wave's first beam pair does not depend on the car: requested before the car's state, so the two round trips
     // overlap (a wave's start-up - state, start cell, first-trip line - is serial latency that nothing else hides)
     const char *beams = reinterpret_cast<const char *>(t.beams);        // padded to 17 * 64 entries (rc_load_track)
@@ -654,6 +655,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
     }
     if (STAMPS) {
         stamp(21);
+        stamp_value(7, __builtin_amdgcn_s_memrealtime());
         stamp_value(22, (unsigned long long)total_trips);
         stamp_value(23, (unsigned long long)__builtin_popcountll(__builtin_amdgcn_ballot_w64(wave_exact != 0)));   // lanes that ever took it
         stamp_value(27, t_wait);
@@ -665,6 +667,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         stamp_value(25, nib_lo);
         stamp_value(26, nib_hi);
         stamp_value(24, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)));   // HW_ID
+        stamp_value(5, (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((32 - 1) << 11)));   // XCC_ID (the clocks of two XCDs are not comparable)
     }
 }
 
