@@ -291,6 +291,12 @@ struct KernelTimer {
         if (_rc) return _rc;                            \
     } while (0)
 
+// Waves per car of the one-wave-per-car scan (the measurements: set_launch_geometry, tools/split_sweep.py).
+static int scan_split(long long cars, int n_cu) {
+    if (cars > 16LL * n_cu) return 1;
+    return (int)std::min<long long>(17, std::max<long long>(1, 48LL * n_cu / std::max<long long>(cars, 1)));
+}
+
 // Persistent workgroups: as many as stay resident (2 x 1024 threads = 32 waves/CU is the hardware maximum).
 void set_launch_geometry(rc_env *env) {
     RcLaunchInfo &li = env->launch;
@@ -318,15 +324,13 @@ void set_launch_geometry(rc_env *env) {
         //     6144     31.3   34.7   32.7
         //     8192     36.6   41.3   39.8   44.7   43.6   46.7   56.6
         //    16384     62.8   72.2   68.7   81.6   80.2   84.2  105.8
-        // as many waves as the chip holds at once (32 per CU) and never more (a wave's fixed cost - the car's state and
-        // first-trip line, 1.3 us - is paid once per wave, and a second generation of waves waits for the first):
-        // floor(32 n_cu / cars), which is 1 from 4 097 cars up (rounds 2-4 took ceil(48 n_cu / cars): 8 192 cars in two
-        // waves each, 41 us instead of 37; 6 144 cars 35 instead of 31).
+        // Two regimes.  More than 16 cars per CU (half the wave slots): one wave per car - a second wave per car pays the
+        // fixed cost (the car's state and first-trip line, 1.3 us) twice and, past 32 waves per CU, waits for a slot
+        // (6 144 cars 31 us in one wave each, 35 in two; 8 192 cars 37 / 41: what the rule of rounds 2-4,
+        // ceil(48 n_cu / cars) for every batch, chose).  Up to 16 cars per CU the chain of a car's 17 rounds is the
+        // launch's duration: floor(48 n_cu / cars) waves per car (4 096 cars in three: 24.5 us against 27.0).
         int split = env->dbg[RC_DBG_RAY_SPLIT];
-        if (split < 1 || split > 17) {
-            const long long want = 32LL * li.n_cu, n = env->n_cars;
-            split = (int)std::min<long long>(17, std::max<long long>(1, want / n));
-        }
+        if (split < 1 || split > 17) split = scan_split(env->n_cars, li.n_cu);
         li.car_split = split;
     } else if (li.raycast_variant >= 4) {
         const int threads = env->dbg[RC_DBG_RAY_THREADS];
@@ -1113,9 +1117,8 @@ static int group_step(rc_env **envs, int32_t n, const float *actions_dev, int32_
     g.wave_start[n] = waves;
     TIMED(lead, RC_K_DYNAMICS, rck_launch_dynamics_group(g, lead->cfg.cars_per_env, repeat, ra, lead->stream));
     // scan: a wave = one car (or 1 / split of one); the split follows the group's total, as one handle of that size would
-    const long long want = 32LL * lead->launch.n_cu;
     int split = lead->dbg[RC_DBG_RAY_SPLIT];
-    if (split < 1 || split > 17) split = (int)std::min<long long>(17, std::max<long long>(1, want / cars));
+    if (split < 1 || split > 17) split = scan_split(cars, lead->launch.n_cu);
     waves = 0;
     for (int b = 0; b < n; ++b) {
         g.wave_start[b] = waves;
