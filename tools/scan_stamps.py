@@ -4,7 +4,10 @@
 Runs the benchmark workload with the instrumented build of the one-wave-per-car kernel (`rc_debug_scan_stamps`): every
 wave stamps the shader clock (s_memtime) at fixed points - entry, car state arrived, first round prepared, end of each of
 its 17 rounds, rounds done, flush issued - and counts its wave-level trips.  Prints the mean / percentiles of each phase
-in shader cycles and the cycles per wave-level trip; analysis only, the instrumentation itself costs a few per cent."""
+in shader cycles and the cycles per wave-level trip; analysis only.  Read shares and ratios off it, not times: the instrumented
+build holds 6 waves per SIMD instead of 8 and reads the clock six times per round - its launch takes 1.9 x the production kernel's
+(316 us against 166 at 65 536 cars, tools/small_batch_stamps.py); and `s_memtime` is a per-CU counter (stamps of two CUs are not
+comparable: slots 6 / 7 hold the chip-wide 100 MHz clock for that)."""
 import argparse
 import os
 import sys
