@@ -7,6 +7,7 @@
 //                                   (LDS / global), 5 per-cell distance table, 6 per-cell, per-quadrant rectangles - all
 //                                   bit-identical to the shipped scan, which is what tests/test_gpu_parity.py checks
 //   rc_raycast_car_stamps_kernel    the shipped scan (scan_car, racecar_scan.h) with shader-clock stamps (tools/scan_stamps.py)
+//   rclab_cohabit_kernel            a co-tenant of chosen size for the scan (tools/cohabit_sweep.py: what a collective beside it costs)
 //
 // Numerics as in racecar_kernels.hip: one IEEE operation per written operator (-ffp-contract=off).
 #include "racecar_scan.h"
@@ -398,6 +399,32 @@ __global__ __launch_bounds__(256) void rc_raycast_car_stamps_kernel(RcParams p, 
     if (car >= (unsigned)p.n_cars) return;
     scan_car<1, true>(p, car, part, split, lane, lds_row, wave < (unsigned)n_waves ? stamps + (size_t)wave * RC_STAMP_SLOTS : nullptr);
 }
+// A co-tenant for the scan (tools/cohabit_sweep.py): `gridDim.x` workgroups that stay resident for `ticks` of the chip-wide 100 MHz
+// clock - mode 0 asleep (they hold wave slots and nothing else), mode 1 copying the first half of `buf` to its second half over
+// and over, 16 bytes per lane (what a collective's or a copy's workgroups do), mode 2 the same with non-temporal loads and
+// stores.  Every wave leaves when the time is up.
+__global__ __launch_bounds__(1024) void rclab_cohabit_kernel(unsigned long long ticks, uint4 *buf, unsigned long long n_vec, int mode,
+                                                           unsigned long long *copied) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long half = n_vec / 2, stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, done = 0;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+        if (mode == 0 || half == 0) {
+            __builtin_amdgcn_s_sleep(32);
+        } else {
+#pragma unroll 1
+            for (int i = 0; i < 8; ++i) {
+                if (k >= half) k -= (k / half) * half;
+                if (mode == 2) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const v4u *>(buf) + k), reinterpret_cast<v4u *>(buf) + half + k);      // streamed past L2's retention
+                else buf[half + k] = buf[k];
+                k += stride;
+            }
+            done += 8;
+        }
+    }
+    if (copied != nullptr && done != 0) atomicAdd(copied, done);          // 16-byte vectors this lane moved
+}
+
 template <typename K, typename... Args>
 inline void launch(hipEvent_t a, hipEvent_t b, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, Args... args) {
     hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, s, a, b, 0u, args...);
@@ -437,6 +464,17 @@ int rclab_set_lds_limits(size_t lds_bytes) {
     if (e != hipSuccess) return (int)e;
     if (fa.sharedSizeBytes != 0) return (int)hipErrorInvalidValue;
     return (int)hipSuccess;
+}
+
+// The co-tenant kernel on `s`: workgroups x threads, resident for `microseconds` (at most 100 000); copied_dev (device, may be
+// null) receives the number of 16-byte vectors moved.
+int rclab_launch_cohabit(hipStream_t s, int workgroups, int threads, unsigned microseconds, void *buf, size_t bytes, int mode,
+                         unsigned long long *copied_dev) {
+    if (workgroups < 1 || workgroups > 65536 || threads < 64 || threads > 1024 || threads % 64 || microseconds > 100000u) return (int)hipErrorInvalidValue;
+    if (mode != 0 && (buf == nullptr || bytes < 64 || ((uintptr_t)buf & 15u))) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(rclab_cohabit_kernel, dim3(workgroups), dim3(threads), 0, s, (unsigned long long)microseconds * 100ull,
+                       reinterpret_cast<uint4 *>(buf), (unsigned long long)(bytes / 16), mode, copied_dev);
+    return (int)hipGetLastError();
 }
 
 // One scan launch of a lab kernel on `s`: what rck_launch_raycast (racecar_kernels.hip) hands over when the handle's variant is
