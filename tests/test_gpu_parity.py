@@ -173,6 +173,39 @@ def test_raycast_variants_from_arbitrary_poses(track_name):
     env.close()
 
 
+@pytest.mark.parametrize("n", [257, 4096, 4097])
+def test_the_scan_is_the_same_however_a_cars_rounds_are_dealt_to_waves(n):
+    """Small batches deal a car's 17 rounds of 64 beams to several waves (racecar_abi.hip, scan_split: floor(48 n_cu / cars) up to
+    16 cars per CU, one wave per car above).  Both sides of the rule's edge and every way of dealing - 1, 2, 5, 16 and 17 waves per
+    car (17: one round each, the last wave with 56 lanes), the overlapped build (> 1) and the plain one - return the oracle's
+    ranges, and so does the uint16 copy of the rows."""
+    import torch
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track("treitlstrasse_v2")
+    rng = np.random.default_rng(n)
+    free = np.argwhere(t.drivable)
+    pick = free[rng.integers(0, len(free), n)]
+    poses = np.stack([t.origin[0] + (pick[:, 1] + rng.uniform(0, 1, n)) * t.resolution,
+                      t.origin[1] + (pick[:, 0] + rng.uniform(0, 1, n)) * t.resolution,
+                      rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+    want = _oracle_scan(t, poses)
+    env = BatchedRaceEnv(t, n, 1)
+    env.reset()
+    env.enable_compact(buffers=1)
+    name = env.scan_kernel_name()
+    assert name.endswith("true, false>") == (n <= 4096), (n, name)             # the rule: split > 1 runs the overlapped build
+    for split in (0, 1, 2, 5, 16, 17):
+        env.debug_set("ray_split", split)
+        got = env.set_pose(poses)["lidar"]
+        torch.cuda.synchronize()
+        assert np.array_equal(got.cpu().numpy().reshape(n, 1080), want), (n, split)
+        q = env.compact[:env.compact_layout[0]].cpu().numpy().view(np.uint16).reshape(n, 1080)
+        assert np.array_equal(q, ro.quantise_lidar_u16(want, 0)), (n, split)
+        env.compact.zero_()
+    env.close()
+
+
 @pytest.mark.parametrize("track_name", ["austria", "barcelona", "columbia"])
 def test_default_raycast_dense_poses(track_name):
     """Every raycast variant against the oracle from 24 576 poses per track: uniform over the grid, hugging the walls
