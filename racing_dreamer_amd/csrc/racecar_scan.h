@@ -442,10 +442,12 @@ __device__ __forceinline__ uint32_t quantise_pair(float a, float b, float off, f
 constexpr unsigned kCarRowBytes = ((RC_N_BEAMS + 63) / 64) * 64 * 4;   // LDS per wave of rc_raycast_car_kernel: its car's ranges ...
 constexpr unsigned kCarLdsBytes = kCarRowBytes + 2 * RC_FIRST_PLANES;  // ... and the start cell's line of the first-trip table
 
-// STAMPS: the instrumented build (rc_debug_scan_stamps): shader-clock values at fixed points of the wave's life and two
-// counters, RC_STAMP_SLOTS uint64 per wave - slot 0 entry, 1 car state arrived, 2 first-trip line staged and first round
-// prepared, 3 + i end of the wave's i-th round, 20 rounds done, 21 flush issued, 22 wave-level trips, 23 of which took
-// the exact path, 24 HW_ID, 5 XCC_ID, 6 / 7 the chip-wide 100 MHz clock at entry / flush, 25 / 26 trips per round (a nibble each).
+// STAMPS: the instrumented build (rc_debug_scan_stamps): RC_STAMP_SLOTS uint64 per wave.  Shader-clock values (s_memtime: a
+// per-CU counter, comparable within a wave only) at fixed points of the wave's life - slot 0 entry, 1 car state arrived,
+// 2 first-trip line staged and first round prepared, 20 rounds done, 21 flush issued; the chip-wide 100 MHz clock
+// (s_memrealtime) at entry / flush in 6 / 7; the phases of a round summed over the wave's rounds in 27 (wait), 28 (prepare),
+// 29 (traversal), 3 (inter-car returns, transform), 4 (store to LDS), 30 (the rest); 22 wave-level trips, 23 lanes that ever
+// took the exact path, 25 / 26 trips per round (a nibble each), 24 HW_ID, 5 XCC_ID.
 // OVERLAP: the next round is prepared under the first request of the current one (ray_traverse's `between`) instead of
 // ahead of the traversal.
 template <int A, bool STAMPS = false, bool OVERLAP = false, bool GUARD = true>
@@ -667,7 +669,7 @@ __device__ __forceinline__ void scan_car(const RcParams &p, const unsigned car, 
         stamp_value(25, nib_lo);
         stamp_value(26, nib_hi);
         stamp_value(24, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((32 - 1) << 11)));   // HW_ID
-        stamp_value(5, (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((32 - 1) << 11)));   // XCC_ID (the clocks of two XCDs are not comparable)
+        stamp_value(5, (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((32 - 1) << 11)));   // XCC_ID
     }
 }
 
