@@ -96,6 +96,43 @@ def run(name, track_name, cars, policy, kw, mode, repeat, steps, n):
     return True
 
 
+def run_mixed(steps, n):
+    """BASELINE configs[4]'s track mix in ONE batch (MixedTrackEnv: one launch per kernel over all blocks, rc_step_group) against
+    one C oracle per block with that block's global env offset."""
+    from racing_dreamer_amd.batched_env import MixedTrackEnv
+    names, cars = ["columbia", "austria", "barcelona"], 2
+    sizes = [n // 3, n // 3, n - 2 * (n // 3)]
+    env = MixedTrackEnv(names, sizes, cars_per_env=cars, auto_reset=True)
+    oras = []
+    for nm, m, (a, b) in zip(names, sizes, env.blocks):
+        t = load_track(nm)
+        oras.append(c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution,
+                                        ro.OracleConfig(num_envs=m, cars_per_env=cars, auto_reset=True, first_env=a), threads=min(16, os.cpu_count() or 1)))
+    dv = env.reset(mode="random_ball", seed=21)
+    ovs = [o.reset(mode=spec.RESET_RANDOM_BALL, seed=21) for o in oras]
+    names_out = EXACT_INT + EXACT_FLOAT
+    t0, dones = time.perf_counter(), 0
+    for k in range(-1, steps):
+        if k >= 0:
+            act = ro.random_actions(3, k, n * cars)
+            act[:, 0] = np.abs(act[:, 0])
+            dv = env.step(torch.from_numpy(act).to(env.device).view(n, cars, 2), repeat=2)
+            ovs = [o.step(act[cars * a:cars * b], repeat=2) for o, (a, b) in zip(oras, env.blocks)]
+            dones += sum(int(ov["done"].sum()) for ov in ovs)
+        torch.cuda.synchronize()
+        for (a, b), ov, nm in zip(env.blocks, ovs, names):
+            for f in names_out:
+                d = dv[f][a:b].cpu().numpy().reshape(-1)
+                o = np.asarray(ov[f]).reshape(-1).astype(d.dtype)
+                if not np.array_equal(d.view(np.uint8), o.view(np.uint8)):
+                    bad = np.nonzero(d != o)[0]
+                    print(f"  DIFFERENCE at step {k} in `{f}` of block [{a}, {b}) on {nm}: {bad.size} elements, first {bad[:4]}: device {d[bad[:4]]} oracle {o[bad[:4]]}", flush=True)
+                    return False
+    print(f"  identical over {steps} steps x {n} envs x {cars} cars in three track blocks, repeat 2 ({time.perf_counter() - t0:.0f} s): {dones} episode ends", flush=True)
+    env.close()
+    return True
+
+
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
@@ -108,6 +145,9 @@ def main():
         if not run(*c, steps=steps, n=n):
             ok = False
             break
+    if ok and (only is None or only in "track mix"):
+        print("track mix in one batch (MixedTrackEnv): columbia / austria / barcelona, 2 cars, policy forward, reset random_ball", flush=True)
+        ok = run_mixed(steps, n)
     print("lockstep soak ok" if ok else "lockstep soak FAILED")
     sys.exit(0 if ok else 1)
 
