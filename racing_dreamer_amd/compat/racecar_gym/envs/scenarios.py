@@ -22,7 +22,7 @@ DEFAULT_SENSORS = ["lidar", "pose", "velocity"]
 # whose scenes exist upstream only; the asset is the map of docs/maps/maps that the tree points to - weaker evidence than for the five
 # above, stated per entry - so that the reference's own scenario files load instead of failing:
 SCENE_ASSETS = {
-    "circle_cw": "circle",                      # the only circle map (docs/maps/maps/circle.png); "cw" = the direction it is driven in
+    "circle_cw": "circle",                      # the only circle map (docs/maps/maps/circle.png); its compiled centre line runs clockwise (tested)
     "plechaty": "plechaty1",                    # docs/maps/costmaps/Makefile:12: the authors' costmap batch builds plechaty1
     "torino": "torino_redraw_small",            # ... and torino_redraw_small (Makefile:17), their redraw of the raw torino.pgm
     "treitlstrasse": "Treitlstrasse_3-U_v1",    # the first version of the track whose v2 is treitlstrasse_v2 (same 51.65 m loop)

@@ -92,6 +92,8 @@ def test_every_scenario_file_of_the_reference_loads_on_the_shim(ref_wrappers):
         track = multi.world.track
         assert track.name == name and track.map_name == asset.map_name and np.array_equal(track.occ_words, asset.occ_words)
     assert seen == {"austria", "barcelona", "circle_cw", "columbia", "gbr", "plechaty", "torino", "treitlstrasse", "treitlstrasse_v2"}
+    c = np.asarray(load_track("circle").centerline, np.float64)             # "circle_cw": the compiled circle is driven clockwise
+    assert 0.5 * np.sum(c[:, 0] * np.roll(c[:, 1], -1) - np.roll(c[:, 0], -1) * c[:, 1]) < -100.0
     W = ref_wrappers                                                        # and one of the resolved scenes steps
     env = W.RaceCarWrapper(W.RaceCarBaseEnv(track="plechaty", task="max_progress"), agent_id="A")
     obs = env.reset(mode="grid")
