@@ -4,7 +4,7 @@ world.name, agents[].id, vehicle.sensors, task.{task_name, params}."""
 from __future__ import annotations
 
 import os
-from dataclasses import dataclass, field
+from dataclasses import dataclass, field, replace
 from types import SimpleNamespace
 from typing import Dict, List
 
@@ -34,8 +34,7 @@ def resolve_scene(world_name: str) -> Track:
     `scenario.world._config.name` with the names they asked for: dreamer/evaluations/run_evaluation.py:48)."""
     track = load_track(SCENE_ASSETS.get(world_name, world_name))
     if track.name != world_name:
-        import dataclasses
-        track = dataclasses.replace(track, name=world_name)
+        track = replace(track, name=world_name)
     return track
 
 
