@@ -26,12 +26,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
-import contextlib
-import signal
-import socket
-import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -40,6 +35,10 @@ if ROOT not in sys.path:
 # dmabuf IPC (what RCCL and hipIpc* need on this driver): also for ranks an outside launcher started, and before anything
 # initialises the HIP runtime (torch is imported inside main)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+T_START = time.time()            # when THIS process started; the outermost one hands its own down to its ranks (RC_BENCH_T0)
+from racing_dreamer_amd.bench_guard import (EXIT_CHECK_MISMATCH, EXIT_LEG_LOST, T0_ENV, LineGuard,   # noqa: E402
+                                            die_with_parent, self_launch)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 RAYCAST_BYTES_PER_CAR = 4 * 1080 + 16       # lidar row written + (x, y, cos, sin) read, DESIGN.md §5
@@ -76,9 +75,16 @@ def parse_args():
                          "(4 396 B/car); summary = the 76 B/car alone; none = no collective.  The per-step gathers of "
                          "whole records are xGMI-bound by an order of magnitude at this simulation rate: DESIGN.md 6")
     ap.add_argument("--leg-timeout", type=float, default=150.0,
-                    help="seconds a secondary leg may take before the line is printed with what has been measured and the "
-                         "run ends (rc 0): a leg that hangs - a collective that has never run across devices - must not "
-                         "cost the headline")
+                    help="the most seconds ONE leg may take (capped by what is left of --time-budget) before the line is printed "
+                         "with what has been measured and the run ends (exit 5; exit 3 if that leg was the rendezvous or the "
+                         "headline itself): a collective that has never run across devices may hang, and must not cost the line")
+    ap.add_argument("--time-budget", type=float, default=520.0,
+                    help="seconds the WHOLE run may take, counted from the start of the outermost process (the driver ends a run "
+                         "after 600 s): legs are given deadlines from what is left, and legs for which too little is left are "
+                         "skipped and listed in `legs_skipped`")
+    ap.add_argument("--observable-seconds", type=float, default=12.0,
+                    help="N = 1: wall time of the `steady` window (the headline's loop continued), sized from the measured rate so "
+                         "that an outside sampler polling every 5 s sees the GPU busy at least twice; 0 = the 2 000-step window only")
     ap.add_argument("--gather-every", type=int, default=1,
                     help="N>1: steps per all-gather (each collective carries that many per-step records: same bytes, "
                          "fewer launches; needs staging copies, so 1 - no copy, the collective reads the record in "
@@ -95,8 +101,10 @@ def parse_args():
                     help="run the all-gather path even with one rank (needs a torch.distributed.run launch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only for functional tests on one GPU)")
-    ap.add_argument("--launch-timeout", type=float, default=1500.0,
-                    help="N>1 started without a launcher: seconds after which the ranks this process started are killed")
+    ap.add_argument("--launch-timeout", type=float, default=540.0,
+                    help="N>1 started without a launcher: seconds after the start at which the ranks this process started are "
+                         "ended (SIGTERM to their process group - rank 0 prints the line it has - then SIGKILL); inside the "
+                         "driver's 600 s, behind --time-budget")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ftg", dest="no_cpu_baseline_ftg", action="store_true", help="skip the follow-the-gap secondary figure")
     ap.add_argument("--no-configs", action="store_true", help="N=1: skip the other single-GPU configurations of BASELINE.json")
@@ -109,163 +117,10 @@ def parse_args():
     return ap.parse_args()
 
 
-def self_launch(n_ranks, timeout_s):
-    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves - one child running
-    `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` - BEFORE this process has touched the
-    GPU (nothing above imports torch), pass the ranks' output through (rank 0 prints the JSON line), and exit with the
-    child's code: non-zero if any rank failed, 124 if the ranks did not finish within `timeout_s` (the whole process
-    group this function started is then killed - by its id, nothing else).  Never re-executes a process that has
-    initialised the GPU."""
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL and hipIpc* need on this driver
-    env.setdefault("OMP_NUM_THREADS", "1")
-    child = subprocess.Popen(cmd, env=env, start_new_session=True)
-    try:
-        rc = child.wait(timeout=timeout_s)
-    except subprocess.TimeoutExpired:
-        print(f"bench.py: the {n_ranks} ranks did not finish within {timeout_s:.0f} s - killing them", file=sys.stderr)
-        try:
-            os.killpg(child.pid, signal.SIGTERM)
-            child.wait(timeout=10)
-        except (ProcessLookupError, subprocess.TimeoutExpired):
-            try:
-                os.killpg(child.pid, signal.SIGKILL)
-            except ProcessLookupError:
-                pass
-        rc = 124
-    except KeyboardInterrupt:
-        os.killpg(child.pid, signal.SIGTERM)
-        rc = 130
-    sys.exit(rc)
-
-
 def cpu_baseline(track, cars, obs_type, repeat, n_envs):
     """The CPU oracle timed on this host's cores on a bounded sample of the same workload."""
     from oracle import cpu_baseline as cb
     return cb.run(track, cars=cars, occupancy=(obs_type == "lidar_occupancy"), repeat=repeat, n_envs=n_envs)
-
-
-class LineGuard:
-    """Rank 0 prints exactly ONE JSON line, whatever happens after the headline leg.
-
-    `arm(line)` is called once the headline has been measured.  From then on every leg runs inside `with guard.leg(name)`:
-    a deadline is set for it, and a watchdog thread (in every rank) ends the run when the deadline passes or when any rank
-    has reported a failed leg through the job's key-value store: rank 0 prints the line with what has been measured so far
-    plus `aborted: {leg, reason}`, and every rank leaves with exit code 0 - a hung collective cannot be recovered in-process,
-    and a rank that raised has left the others' collective sequence.  SIGTERM (a driver's time-out) prints the line too.
-    Only the headline leg itself, and a failed self-check of the HEADLINE payload, make the run fail.  At N = 1 a failed leg
-    is recorded (`errors`) and the run goes on: there is nobody to fall out of step with."""
-
-    KEY = "rc_bench_abort"
-
-    def __init__(self, rank, world, timeout_s):
-        self.rank, self.world, self.timeout = rank, world, float(timeout_s)
-        self.line, self.store = None, None
-        self.lock = threading.RLock()
-        self.printed = False
-        self.leg_name, self.deadline = None, None
-        self.errors = {}
-        self._stop = False
-        self._sigterm = False
-        self.armed = False
-
-    def arm(self, line, store=None):
-        self.line, self.store, self.armed = line, store, True
-        threading.Thread(target=self._watch, daemon=True).start()
-        try:
-            # the handler runs in the main thread, possibly while that thread is inside emit() / finalise() holding the lock:
-            # it only raises a flag, the watchdog thread prints the line (ADVICE r4)
-            signal.signal(signal.SIGTERM, lambda *_: setattr(self, "_sigterm", True))
-        except ValueError:
-            pass
-
-    def _store_reason(self):
-        if self.store is None:
-            return None
-        try:
-            if self.store.check([self.KEY]):
-                return self.store.get(self.KEY).decode(errors="replace")
-        except Exception as exc:                       # the store lives in another process: gone = the job is ending
-            return f"key-value store unreachable ({type(exc).__name__})"
-        return None
-
-    def _watch(self):
-        while not self._stop:
-            time.sleep(0.25)
-            if self._sigterm:
-                self.finalise("signal", "SIGTERM")
-            d, name = self.deadline, self.leg_name
-            if d is not None and time.monotonic() > d:
-                self.finalise(name, f"exceeded its deadline of {self.timeout:.0f} s")
-            why = self._store_reason() if self.world > 1 else None
-            if why:
-                time.sleep(0.3)
-                self.finalise(*(why.split("|", 1) if "|" in why else (self.leg_name, why)))
-
-    def finalise(self, leg, reason):
-        with self.lock:
-            if self.rank == 0 and self.line is not None and not self.printed:
-                self.line["aborted"] = {"leg": leg, "reason": reason,
-                                        "note": "the run was ended after the headline leg: everything above was measured; legs that had not run are absent"}
-                if self.errors:
-                    self.line["leg_errors"] = self.errors
-                print(json.dumps(self.line), flush=True)
-                self.printed = True
-            print(f"bench.py: rank {self.rank}: run ended in leg {leg!r}: {reason}", file=sys.stderr, flush=True)
-            sys.stdout.flush()
-            os._exit(0)
-
-    @contextlib.contextmanager
-    def leg(self, name):
-        self.leg_name, self.deadline = name, (time.monotonic() + self.timeout if self.armed else None)
-        hook = os.environ.get("RC_BENCH_FAIL_LEG", "").split(":")          # tests: "<leg>[:<rank>]" raises, "RC_BENCH_HANG_LEG" sleeps
-        hang = os.environ.get("RC_BENCH_HANG_LEG", "").split(":")
-        try:
-            if hook[0] == name and (len(hook) < 2 or int(hook[1]) == self.rank):
-                raise RuntimeError("RC_BENCH_FAIL_LEG")
-            if hang[0] == name and (len(hang) < 2 or int(hang[1]) == self.rank):
-                time.sleep(1e6)
-            yield
-        except Exception as exc:                           # noqa: BLE001 - every failure of a secondary leg is data, not fatal
-            msg = f"{type(exc).__name__}: {exc}"
-            self.errors[name] = msg
-            print(f"bench.py: rank {self.rank}: leg {name!r} failed: {msg}", file=sys.stderr, flush=True)
-            if not self.armed:
-                raise                                      # (not armed: this is the headline itself)
-            if self.world > 1:
-                first = self._store_reason()               # another rank failed first: this exception is its echo (a peer that left)
-                if first and "|" in first:
-                    self.finalise(*first.split("|", 1))
-                try:
-                    if self.store is not None:
-                        self.store.set(self.KEY, f"{name}|rank {self.rank}: {msg}")
-                except Exception:                          # noqa: BLE001
-                    pass
-                time.sleep(2.0)                            # let the others read the reason before this rank's exit breaks their collective
-                self.finalise(name, f"rank {self.rank}: {msg}")
-        finally:
-            self.leg_name, self.deadline = None, None
-
-    def emit(self, shutdown_s=30.0):
-        """Print the line (rank 0, once).  The watchdog stays on for the shutdown that follows - the closing barrier, the
-        process group's destruction: a rank that never arrives there must not turn a finished run into a time-out - and ends
-        the process quietly (rc 0) if that takes longer than `shutdown_s`; `done()` switches it off."""
-        with self.lock:
-            if self.rank == 0 and not self.printed and self.line is not None:
-                if self.errors:
-                    self.line["leg_errors"] = self.errors
-                print(json.dumps(self.line), flush=True)
-                self.printed = True
-            self.leg_name, self.deadline = "shutdown", time.monotonic() + shutdown_s
-
-    def done(self):
-        self._stop = True
-        self.deadline = None
 
 
 def _checksum(t):
@@ -734,11 +589,9 @@ def time_track(track_name, envs, steps, warmup, settle):
 
 def main():
     args = parse_args()
+    t0_run = float(os.environ.get(T0_ENV, T_START))           # the outermost process's start: the time budget counts from there
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus, args.launch_timeout)          # does not return
-    import torch
-    import torch.distributed as dist
-
+        self_launch(args.gpus, args.launch_timeout, __file__, sys.argv[1:], t0=T_START)          # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -746,24 +599,35 @@ def main():
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     distributed = world > 1 or (args.force_gather and "RANK" in os.environ)
+    # from here on a signal, a deadline or a failed leg leaves through the guard: rank 0 prints the line it has (none yet)
+    guard = LineGuard(rank, world if distributed else 1, args.leg_timeout, deadline=t0_run + args.time_budget)
+    guard.install()
+    if "RANK" in os.environ:
+        die_with_parent()                                      # a launcher that is killed outright takes this rank with it
+    try:
+        run(args, guard, rank, local_rank, world, distributed, t0_run)
+    except Exception as exc:                                   # noqa: BLE001
+        # an exception OUTSIDE a guarded leg (the code between two legs): once there is a line, it is printed - with what failed -
+        # and the exit code is the guard's (3 before the headline, 5 after it); before that an exception is an exception
+        if guard.armed:
+            import traceback
+            traceback.print_exc()
+            guard.finalise(guard.leg_name or "between legs", f"rank {rank}: {type(exc).__name__}: {exc}")
+        raise
+
+
+def run(args, guard, rank, local_rank, world, distributed, t0_run):
+    # test hook (tests/test_distributed.py, no GPU there): the local stage is a stand-in, the rendezvous is real, and the
+    # headline leg has no env to run on - what is exercised is the launcher, the guard and the exit codes
+    fake_local = os.environ.get("RC_BENCH_FAKE_LOCAL") == "1" and distributed
+    import torch
+    import torch.distributed as dist
+
     dev = local_rank % max(torch.cuda.device_count(), 1)      # ranks > GPUs only in --backend gloo functional tests
-    torch.cuda.set_device(dev)
+    if not fake_local:
+        torch.cuda.set_device(dev)
     comm_ranks = None
     store = None
-    if distributed:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
-        else:
-            dist.init_process_group("gloo")
-        # what the communicator itself says about its size: one contribution per rank, summed by the collective
-        one = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(one)
-        comm_ranks = int(one.item())
-        try:
-            store = dist.distributed_c10d._get_default_store()
-        except Exception:                                      # noqa: BLE001 - without it a failed leg is still caught by the deadline
-            store = None
-    guard = LineGuard(rank, world if distributed else 1, args.leg_timeout)
 
     from racing_dreamer_amd import _lib as L
     from racing_dreamer_amd.batched_env import BatchedRaceEnv
@@ -773,18 +637,20 @@ def main():
     track_name = ["columbia", "austria", "barcelona"][rank % 3] if args.mixed_tracks else args.track
     track = load_track(track_name)
     shard = shard_envs(args.envs * world, rank, world)
-    env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
-                         device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
-    if args.raycast_variant is not None:
-        env.set_raycast_variant(args.raycast_variant)      # (variants 0-6: lab kernels, built on this request)
-    for kv in args.debug_knob:
-        name, _, val = kv.partition("=")
-        env.debug_set(name, int(val))
-    env.reset(mode="random", seed=0)
-    # every loop below works on the env's own stream: with torch's current stream another one, each step pays two cross-stream
-    # event waits (BatchedRaceEnv._enter / _exit) - what the 25 us per step of "non-scan time" in round 4's fresh_reset leg were
-    # (that leg ran before this call; `profiles/r05_e_fresh_window*.log` has the kernel timeline of the window)
-    torch.cuda.set_stream(env.stream)
+    env = None
+    if not fake_local:
+        env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
+                             device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
+        if args.raycast_variant is not None:
+            env.set_raycast_variant(args.raycast_variant)      # (variants 0-6: lab kernels, built on this request)
+        for kv in args.debug_knob:
+            name, _, val = kv.partition("=")
+            env.debug_set(name, int(val))
+        env.reset(mode="random", seed=0)
+        # every loop below works on the env's own stream: with torch's current stream another one, each step pays two cross-stream
+        # event waits (BatchedRaceEnv._enter / _exit) - what the 25 us per step of "non-scan time" in round 4's fresh_reset leg were
+        # (that leg ran before this call; `profiles/r05_e_fresh_window*.log` has the kernel timeline of the window)
+        torch.cuda.set_stream(env.stream)
     # the first steps after a reset, timed on their own (N = 1): what `--settle 0` would put into the timed window
     fresh = None
     if not distributed and not args.no_configs:
@@ -832,14 +698,87 @@ def main():
     gather_mode = "none" if (args.no_gather or not distributed) else args.gather
     via = args.gather_via
     abi_ranks = None
-    if distributed and via == "abi":
-        if args.backend != "nccl":
-            via = "torch"                       # RCCL wants one GPU per rank; the gloo functional tests share one
+    total_envs = args.envs * world
+
+    def contract_line(value, seconds_per_step, gather_txt):
+        """The keys the driver's contract names, for the provisional line and for the measured one."""
+        return {
+            "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": seconds_per_step * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": f"synthetic (random-action rollout, {args.settle} untimed settling steps after reset, then the warm-up)",
+            "config": {
+                "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
+                            f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
+                            f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
+                            f"auto-reset, action_repeat {args.repeat}; {gather_txt}",
+                "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
+                "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
+                "obs_type": args.obs_type, "action_repeat": args.repeat, "settle_steps": args.settle,
+                "parallelism": f"env-sharded x{world}", "gather": gather_mode,
+            },
+        }
+
+    # ------------------------------------------------------------------ N > 1, stage 1: what this rank can do ALONE
+    # A simulation-only window on this rank's own GPU - no collective, nothing a peer can hold up - gives rank 0 something to
+    # print BEFORE the first collective this code has ever issued across devices: the guard is armed with a PROVISIONAL line
+    # (`headline_pending`), and the rendezvous, the ring prefill and the timed headline window then run under deadlines of their
+    # own.  If one of them hangs or raises, that line is printed with `aborted` and every rank exits 3 (VERDICT r5 #1b).
+    step_no = 0
+    local = None
+    if distributed:
+        if fake_local:
+            dt_local = 1e-3 * args.steps
         else:
-            ids = [BatchedRaceEnv.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            env.comm_init(ids[0], rank, world)
-            abi_ranks = env.comm_count()
+            for k in range(args.settle):
+                env.step_random(seed=2, step=k)
+            for k in range(args.warmup):
+                env.step_random(seed=1, step=args.settle + k)
+            env.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(args.steps):
+                env.step_random(seed=1, step=args.settle + args.warmup + k)
+            env.sync()
+            torch.cuda.synchronize()
+            dt_local = time.perf_counter() - t0
+            step_no = args.settle + args.warmup + args.steps
+        local = {"steps": args.steps, "ms_per_step": dt_local / args.steps * 1e3,
+                 "env_steps_per_s_this_rank": shard.num_envs * args.steps * args.repeat / dt_local,
+                 "note": "rank 0's own simulation-only window (settle, warm-up, then the timed steps; no collective), taken before the "
+                         "rendezvous"}
+        prov = contract_line(total_envs * args.steps * args.repeat / dt_local, dt_local / args.steps,
+                             "PROVISIONAL: rank 0's own simulation-only window x the number of ranks - printed only if the run "
+                             "ends before the headline has been measured")
+        prov["provisional"] = local
+        guard.arm(prov if rank == 0 else None, pending=True)
+        # ---------------------------------------------------------------- stage 2a: the rendezvous, under its own deadline
+        with guard.leg("rendezvous", budget_s=min(args.leg_timeout, 120.0)):
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            else:
+                dist.init_process_group("gloo")
+            # what the communicator itself says about its size: one contribution per rank, summed by the collective
+            one = torch.ones(1, dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(one)
+            comm_ranks = int(one.item())
+            try:
+                store = dist.distributed_c10d._get_default_store()
+            except Exception:                                      # noqa: BLE001 - without it a failed leg is still caught by the deadline
+                store = None
+            guard.set_store(store)
+            if via == "abi":
+                if args.backend != "nccl":
+                    via = "torch"                       # RCCL wants one GPU per rank; the gloo functional tests share one
+                else:
+                    ids = [BatchedRaceEnv.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    env.comm_init(ids[0], rank, world)
+                    abi_ranks = env.comm_count()
+        if rank == 0:
+            print(f"bench.py: {world} ranks joined ({args.backend}), {guard.time_left():.0f} s of the time budget left; rank 0 alone: "
+                  f"{local['env_steps_per_s_this_rank'] / 1e6:.1f} M env-steps/s", file=sys.stderr, flush=True)
     every = max(1, args.gather_every)
     if via == "p2p" and every != 1:
         raise SystemExit("--gather-via p2p sends one record per gather (--gather-every 1)")
@@ -883,7 +822,8 @@ def main():
 
     # the rollout loop works on the env's own stream (no cross-stream event waits between the step's kernels and
     # the collective's dependency on them); `barrier()` synchronises the whole device
-    torch.cuda.set_stream(env.stream)
+    if env is not None:
+        torch.cuda.set_stream(env.stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -919,10 +859,6 @@ def main():
         return max_over_ranks(t3 - t0)
 
     # ------------------------------------------------------------------ the headline leg (a failure here fails the run)
-    step_no = 0
-    gather = make_collector(gather_mode)
-    if gather_mode == "sharded":
-        step_no += gather.prefill(step_no)
     # The synthetic data is a random-action rollout that HAS SETTLED, and the chip is at its working clocks: `--settle` untimed
     # steps of the very loop that is timed, right in front of the warm-up.  Two things ride on them: the cars
     # leave the post-reset poses (long rays), and the GPU leaves the power state an idle spell puts it into - after 0.5 s
@@ -933,41 +869,61 @@ def main():
         for k in range(n):
             g.step(k0 + k)
         return n
-    step_no += preheat(gather, step_no)
-    for k in range(args.warmup):
-        gather.step(step_no + k)
-    step_no += args.warmup
-    finish(gather)
-    env.reset_kernel_times()
-    # start / stop timestamps attached to every launch of the DOMINANT kernel (the scan) on the stream it runs on;
-    # timing the two small kernels as well would cost the timed region 6 us per step, so they get a pass of their
-    # own after it
-    env.set_profiling(True, kernels=[L.K_RAYCAST])
-    dt = timed(gather, step_no, args.steps)
-    step_no += args.steps
-    env.set_profiling(False)
-    ktimes = env.kernel_times()
-    scan_symbol = env.scan_kernel_name()
+
+    # N > 1, stage 2b: ring prefill, settling, warm-up and the timed window - the first collectives on the data path - under a
+    # deadline; the guard still holds the provisional line.  N = 1: the guard is not armed, an exception here is an exception.
+    with guard.leg("headline"):
+        if fake_local:
+            raise RuntimeError("RC_BENCH_FAKE_LOCAL: there is no env to measure a headline on")
+        gather = make_collector(gather_mode)
+        if gather_mode == "sharded":
+            step_no += gather.prefill(step_no)
+        step_no += preheat(gather, step_no)
+        for k in range(args.warmup):
+            gather.step(step_no + k)
+        step_no += args.warmup
+        finish(gather)
+        env.reset_kernel_times()
+        # start / stop timestamps attached to every launch of the DOMINANT kernel (the scan) on the stream it runs on;
+        # timing the two small kernels as well would cost the timed region 6 us per step, so they get a pass of their
+        # own after it
+        env.set_profiling(True, kernels=[L.K_RAYCAST])
+        dt = timed(gather, step_no, args.steps)
+        step_no += args.steps
+        env.set_profiling(False)
+        ktimes = env.kernel_times()
+        scan_symbol = env.scan_kernel_name()
     # a long steady-state figure of the SAME env and loop right behind the driver's window (a 20-step window is
     # 3.7 ms, too short for an outside observer; this one is >= 2 000 steps, ~0.4 s, and contains its share of order re-sorts)
-    steady = None
+    steady = steady_long = None
     if not distributed and not args.no_configs:
+        def window(n):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ev0.record(env.stream)
+            for k in range(n):
+                gather.step(step_no + k)
+            ev1.record(env.stream)
+            finish(gather)
+            torch.cuda.synchronize()
+            dts = time.perf_counter() - t0
+            return {"steps": n, "seconds": dts, "ms_per_step": dts / n * 1e3, "env_steps_per_s": shard.num_envs * n * args.repeat / dts,
+                    "gpu_ms_per_step": ev0.elapsed_time(ev1) / n}
         n_steady = max(2000, 10 * args.steps)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ev0.record(env.stream)
-        for k in range(n_steady):
-            gather.step(step_no + k)
-        ev1.record(env.stream)
-        finish(gather)
-        torch.cuda.synchronize()
-        dts = time.perf_counter() - t0
+        steady = window(n_steady)
         step_no += n_steady
-        steady = {"steps": n_steady, "ms_per_step": dts / n_steady * 1e3, "env_steps_per_s": shard.num_envs * n_steady * args.repeat / dts,
-                  "gpu_ms_per_step": ev0.elapsed_time(ev1) / n_steady,
-                  "note": "the headline's env and loop, continued for a window an observer can see (no timers on); host-timed like the "
-                          "headline, gpu_ms_per_step between two events on the env's stream"}
+        steady["note"] = ("the headline's env and loop, continued for a window an observer can see (no timers on); host-timed like the "
+                          "headline, gpu_ms_per_step between two events on the env's stream")
+        # ... and one an OUTSIDE observer can see: the driver's sampler polls the GPU's busy figure every ~5 s and
+        # has never caught this benchmark at work (the 2 000-step window is 0.36 s).  The same loop for --observable-seconds of
+        # wall time, sized from the rate just measured: two or more polls fall inside it.
+        if args.observable_seconds > 0 and guard.time_left() > 4 * args.observable_seconds + 120:
+            n_long = int(args.observable_seconds / (steady["ms_per_step"] * 1e-3)) + 1
+            steady_long = window(n_long)
+            step_no += n_long
+            steady_long["note"] = (f"the same loop for about {args.observable_seconds:.0f} s of wall time without a pause (no timers, no host "
+                                   f"synchronisation inside): long enough for a sampler that polls the GPU every 5 s to see it busy twice")
     # the other kernels of the step: a short untimed pass with all timers on
     env.reset_kernel_times()
     env.set_profiling(True, kernels=[L.K_PATCH, L.K_DYNAMICS])
@@ -981,7 +937,6 @@ def main():
         if name != "rc_raycast_kernel":
             ktimes[name] = v
 
-    total_envs = args.envs * world
     value = total_envs * args.steps * args.repeat / dt
     n_cars = shard.num_envs * args.cars
     ray = ktimes["rc_raycast_kernel"]
@@ -1016,27 +971,16 @@ def main():
                       f"per step, {'read in place from a double-buffered source' if gather.in_place else 'from staging copies'}, "
                       f"one gather per {every} step{'s' if every > 1 else ''}, {how}, overlapped with the "
                       f"following step; the gathered buffer is overwritten two gathers later - no consumer in this benchmark)")
-    out = {
-        "metric": "env-steps/sec at 65 536 parallel envs, 1080-beam LiDAR, 1/2/4/8 MI355X",
-        "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32",
-        "data": f"synthetic (random-action rollout, {args.settle} untimed settling steps after reset, then the warm-up)",
-        "config": {
-            "workload": f"{args.envs} envs/GPU x {args.cars} car, track "
-                        f"{'mixed columbia/austria/barcelona by rank' if args.mixed_tracks else args.track}, obs_type={args.obs_type}, "
-                        f"1080-beam lidar every sub-step, random-action rollouts (Philox on device), "
-                        f"auto-reset, action_repeat {args.repeat}; {gather_txt}",
-            "envs_per_gpu": args.envs, "total_envs": total_envs, "cars_per_env": args.cars,
-            "track": "mixed: [columbia, austria, barcelona][rank mod 3]" if args.mixed_tracks else args.track,
-            "obs_type": args.obs_type, "action_repeat": args.repeat, "settle_steps": args.settle,
-            "parallelism": f"env-sharded x{world}", "gather": gather_mode,
-            "gather_via": (gather.via if distributed else None), "gather_detail": (gather.includes if distributed else None),
-            # the size of the job as the communicator reports it (sum over ranks of 1 through the backend's own
-            # all-reduce; ncclCommCount of the C-ABI's communicator when that transport is used)
-            "rccl_ranks": comm_ranks if (distributed and args.backend == "nccl") else None,
-            "comm_backend": args.backend if distributed else None, "comm_ranks": comm_ranks, "abi_comm_ranks": abi_ranks,
-        },
+    out = contract_line(value, dt / args.steps, gather_txt)
+    out["config"].update({
+        "gather_via": (gather.via if distributed else None), "gather_detail": (gather.includes if distributed else None),
+        # the size of the job as the communicator reports it (sum over ranks of 1 through the backend's own
+        # all-reduce; ncclCommCount of the C-ABI's communicator when that transport is used)
+        "rccl_ranks": comm_ranks if (distributed and args.backend == "nccl") else None,
+        "comm_backend": args.backend if distributed else None, "comm_ranks": comm_ranks, "abi_comm_ranks": abi_ranks,
+        "time_budget_s": args.time_budget,
+    })
+    out.update({
         "roofline": {
             "bound": "hbm", "kernel": scan_symbol, "achieved": achieved, "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
@@ -1056,9 +1000,23 @@ def main():
         },
         "kernels_ms": {k: round(v["avg_ms"], 4) for k, v in ktimes.items() if v["launches"]},
         "kernels_sum_ms": round(sum(v["avg_ms"] for v in ktimes.values() if v["launches"]), 4),
-    }
+    })
     if steady is not None:
         out["steady"] = steady
+    if steady_long is not None:
+        out["steady_long"] = steady_long
+    if local is not None:
+        out["rank0_alone_before_the_rendezvous"] = local
+        # which number answers the north star: the north star names "an RCCL all-gather over xGMI only for
+        # the trajectory-buffer concat"; `value` is timed with the concat at the granularity its consumer reads it
+        out["north_star_answer"] = (
+            "`value` = all ranks' env-steps/s with the trajectory store SHARDED (every step's 76 B/car summary all-gathered, one 50 x 50 "
+            "training batch all-gathered every 10th step; whole records stay in the rank that produced them) - the scaling figure to "
+            "compare with N = 1.  The literal concat of WHOLE per-step records on every rank is `gather_modes.full` / `full-u16` (a "
+            "record per sub-step) and `gather_modes_repeat_4` (a record per agent step of 4 sub-steps, the reference's cadence, "
+            "dreamer/wrappers.py:107-116,213-219): measured in this run beside their xGMI link bounds, link-bound by an order of "
+            "magnitude at this simulation rate (DESIGN.md 6).  BASELINE configs[4] (rank r on [columbia, austria, barcelona][r mod 3]) "
+            "is `configs4_track_mix`.")
     if fresh is not None:
         out["fresh_reset"] = fresh
     if distributed:
@@ -1082,7 +1040,11 @@ def main():
         if gather_mode == "sharded":
             out["gather_modes"]["sharded"].update(batches_in_timed_window=gather.batches, batch_every=gather.batch_every,
                                                   batch_windows=gather.windows, batch_length=gather.length)
-    guard.arm(out if rank == 0 else None, store)
+    # N > 1, stage 3: the measured headline replaces the provisional line
+    if distributed:
+        guard.promote(out if rank == 0 else None)
+    else:
+        guard.arm(out if rank == 0 else None, store)
     if rank == 0 and distributed:
         print("bench.py headline (the one JSON line on stdout follows at the end of the run): "
               + json.dumps({k: out[k] for k in ("value", "unit", "n_gpus", "ms_per_step")} | {"gather": gather_mode}),
@@ -1102,114 +1064,29 @@ def main():
     if checks and checks[gather_mode]["ok"] is False:
         guard.emit()
         print(f"bench.py: rank {rank}: a gathered record differs from what its sender sent: {checks}", file=sys.stderr, flush=True)
-        guard.done()                   # (a failed self-check of the headline payload is the one thing that fails the run: exit 4, not 0)
+        guard.done()                   # (a failed self-check of the headline payload: exit 4)
         if distributed:
             dist.barrier()
-        sys.exit(4)
+        sys.exit(EXIT_CHECK_MISMATCH)
 
-    # ------------------------------------------------------------------ secondary legs, each under the guard
-    # the reference's own setting, action_repeat 4 with the scan once per agent step (dreamer/dream.py:55; SURVEY.md H9)
-    with guard.leg("action_repeat_4"):
-        r4_steps = max(args.steps // 4, 5)
-        g = make_collector("none")
-        step_no += preheat(g, step_no, 40)
-        dt4 = timed(g, step_no, r4_steps, repeat=4)
-        step_no += r4_steps
-        if rank == 0:
-            out["action_repeat_4"] = {"env_steps_per_s": total_envs * r4_steps * 4 / dt4,
-                                      "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
-                                      "note": "same envs with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55), no exchange"}
-
-    # the headline payload over a window ten times as long: a 20-step window (3 - 5 ms) carries the pipeline's start and
-    # drain and the closing barrier at full weight; this is the steady state next to it
-    if distributed and gather_mode != "none":
-        with guard.leg("steady_state"):
-            n_long = max(10 * args.steps, 200)
-            g = make_collector(gather_mode)
-            if gather_mode == "sharded":
-                step_no += g.prefill(step_no)
-            step_no += preheat(g, step_no)
-            finish(g)
-            t = timed(g, step_no, n_long)
-            step_no += n_long
-            g.close()
-            if rank == 0:
-                out["gather_modes"][gather_mode]["steady_state"] = {"steps": n_long, "ms_per_step": t / n_long * 1e3,
-                                                                    "env_steps_per_s": total_envs * n_long * args.repeat / t}
-
-    # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
-    # sequence): what the headline's choice costs or saves, measured rather than argued, each next to its link bound
-    # (xGMI full mesh, 7 links x 76.8 GB/s inbound per GPU).  Each leg sets the env up for its own payload only
-    # (`includes` says what its step carried); `none` is the pure simulation rate; `batch` = sharded without the per-step
-    # summary.  Cheapest and most informative first: a leg that fails ends the run with the legs before it in the line.
-    if distributed and not args.no_gather_modes:
-        n_leg = max(args.steps // 4, 5)
-        order = [m for m in ("none", "batch", "sharded", "summary", "full-u16", "full") if m != gather_mode]
-        for m in order:
-            with guard.leg(m):
-                if m == "batch":
-                    g = ShardedCollector(env, dist, rank, summary=False)
-                else:
-                    g = make_collector(m)
-                n_leg = max(args.steps // 4, 5)
-                if m in ("batch", "sharded"):
-                    step_no += g.prefill(step_no)
-                    n_leg = max(n_leg, 2 * g.batch_every)        # (a leg without a batch in it would not be this payload)
-                step_no += preheat(g, step_no)
-                finish(g)
-                t = timed(g, step_no, n_leg)
-                step_no += n_leg
-                e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
-                e.update(ms_per_step=t / n_leg * 1e3, env_steps_per_s=total_envs * n_leg * args.repeat / t, steps=n_leg,
-                         includes=g.includes)
-                if m not in ("none",) and not args.no_gather_check:
-                    c = g.check(step_no, dist)
-                    step_no += 8
-                    e["check"] = c
-                    checks[m] = c
-                g.close()
-                if rank == 0:
-                    out["gather_modes"][m] = e
-                    out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
-    # The whole-record gathers at the REFERENCE's cadence (VERDICT r4 #3): Collect records one transition per AGENT step
-    # (dreamer/wrappers.py:107-116 ActionRepeat inside, :213-219 Collect outside), the reference runs action_repeat 4
-    # (dreamer/dream.py:55) - so one record crosses the links per 4 sub-steps, the scan runs once per record, and the link
-    # bound is set against a step of four dynamics kernels + one scan.  (The legs above gather a record per sub-step.)
-    if distributed and not args.no_gather_modes:
-        out["gather_modes_repeat_4"] = {} if rank == 0 else None
-        for m in ("full-u16", "full"):
-            with guard.leg(m + "@repeat4"):
-                g = make_collector(m)
-                n_leg = max(args.steps // 4, 5)
-                step_no += preheat(g, step_no, 40)
-                finish(g)
-                t = timed(g, step_no, n_leg, repeat=4)
-                step_no += n_leg
-                e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
-                e["link_bound_ms_per_agent_step"] = e.pop("link_bound_ms_per_step")
-                e["bytes_per_gpu_per_agent_step"] = e.pop("bytes_per_gpu_per_step")
-                e["inbound_bytes_per_gpu_per_agent_step"] = e.pop("inbound_bytes_per_gpu_per_step")
-                e.update(action_repeat=4, ms_per_agent_step=t / n_leg * 1e3, agent_steps_per_s=total_envs * n_leg / t,
-                         env_steps_per_s=total_envs * n_leg * 4 / t, agent_steps=n_leg, includes=g.includes,
-                         cadence="one record per agent step of 4 sub-steps, the scan once per record (dreamer/wrappers.py:107-116,213-219; dream.py:55)")
-                if not args.no_gather_check:
-                    c = g.check(step_no, dist)
-                    step_no += 8
-                    e["check"] = c
-                    checks[m + "@repeat4"] = c
-                g.close()
-                if rank == 0:
-                    out["gather_modes_repeat_4"][m] = e
-                    out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
-    if getattr(env, "_p2p_mode", None) is not None:
-        with guard.leg("p2p_close"):
-            p2p_close()
+    # ------------------------------------------------------------------ secondary legs: each under the guard, each started only
+    # if the time budget has room for it (`guard.go`: rank 0 decides, every rank takes the same branch), in the order of what the
+    # line can least do without: N = 1 - the CPU baseline (the contract names it), then the other configurations; N > 1 - BASELINE
+    # configs[4] itself, the steady state of the headline payload, the whole-record concat at the reference's cadence, the
+    # per-sub-step payloads, and the simulation alone last.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        with guard.leg("cpu_baseline"):
+            from oracle import cpu_baseline as cb
+            out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
+            out["cpu_baseline"]["single_env"] = cb.run_single_env()      # BASELINE.json configs[0]: the B = 1 CPU step()
+            if not args.no_numpy_baseline:
+                out["cpu_baseline"]["numpy_batch"] = cb.run_numpy_batch(track, n_envs=args.numpy_envs)
 
     # BASELINE.json configs[4] inside the plain `--gpus N` run: rank r on [columbia, austria, barcelona][r mod 3],
     # the headline's payload (the sharded store) over the mix.  Each rank builds a SECOND env on its track of the mix (the
     # headline's env stays as it is); ranks on different tracks run steps of different length, so the closing barrier waits for
     # the slowest track - which is the point of the configuration.
-    if distributed and not args.mixed_tracks and not args.no_gather_modes:
+    if distributed and not args.mixed_tracks and not args.no_gather_modes and guard.go("configs4_track_mix", 40):
         with guard.leg("configs4_track_mix"):
             mix = ["columbia", "austria", "barcelona"]
             mine = mix[rank % 3]
@@ -1241,9 +1118,111 @@ def main():
                     "tracks_by_rank": tracks_by_rank, "steps": n_leg, "ms_per_step": t / n_leg * 1e3,
                     "env_steps_per_s": total_envs * n_leg * args.repeat / t, "gather": gather_mode}
 
+    # the headline payload over a window ten times as long: a 20-step window (3 - 5 ms) carries the pipeline's start and
+    # drain and the closing barrier at full weight; this is the steady state next to it
+    if distributed and gather_mode != "none" and guard.go("steady_state", 15, kind="gather"):
+        with guard.leg("steady_state", kind="gather"):
+            n_long = max(10 * args.steps, 200)
+            g = make_collector(gather_mode)
+            if gather_mode == "sharded":
+                step_no += g.prefill(step_no)
+            step_no += preheat(g, step_no)
+            finish(g)
+            t = timed(g, step_no, n_long)
+            step_no += n_long
+            g.close()
+            if rank == 0:
+                out["gather_modes"][gather_mode]["steady_state"] = {"steps": n_long, "ms_per_step": t / n_long * 1e3,
+                                                                    "env_steps_per_s": total_envs * n_long * args.repeat / t}
+
+    # The whole-record gathers at the REFERENCE's cadence (VERDICT r4 #3): Collect records one transition per AGENT step
+    # (dreamer/wrappers.py:107-116 ActionRepeat inside, :213-219 Collect outside), the reference runs action_repeat 4
+    # (dreamer/dream.py:55) - so one record crosses the links per 4 sub-steps, the scan runs once per record, and the link
+    # bound is set against a step of four dynamics kernels + one scan.  (The legs below gather a record per sub-step.)
+    if distributed and not args.no_gather_modes:
+        out["gather_modes_repeat_4"] = {} if rank == 0 else None
+        for m in ("full-u16", "full"):
+            if not guard.go(m + "@repeat4", 12, kind="gather"):
+                continue
+            with guard.leg(m + "@repeat4", kind="gather"):
+                g = make_collector(m)
+                n_leg = max(args.steps // 4, 5)
+                step_no += preheat(g, step_no, 40)
+                finish(g)
+                t = timed(g, step_no, n_leg, repeat=4)
+                step_no += n_leg
+                e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
+                e["link_bound_ms_per_agent_step"] = e.pop("link_bound_ms_per_step")
+                e["bytes_per_gpu_per_agent_step"] = e.pop("bytes_per_gpu_per_step")
+                e["inbound_bytes_per_gpu_per_agent_step"] = e.pop("inbound_bytes_per_gpu_per_step")
+                e.update(action_repeat=4, ms_per_agent_step=t / n_leg * 1e3, agent_steps_per_s=total_envs * n_leg / t,
+                         env_steps_per_s=total_envs * n_leg * 4 / t, agent_steps=n_leg, includes=g.includes,
+                         cadence="one record per agent step of 4 sub-steps, the scan once per record (dreamer/wrappers.py:107-116,213-219; dream.py:55)")
+                if not args.no_gather_check:
+                    c = g.check(step_no, dist)
+                    step_no += 8
+                    e["check"] = c
+                    checks[m + "@repeat4"] = c
+                g.close()
+                if rank == 0:
+                    out["gather_modes_repeat_4"][m] = e
+                    out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
+
+    # N > 1: the same loop with each of the other payloads, short legs with the same barriers (every rank runs the same
+    # sequence): what the headline's choice costs or saves, measured rather than argued, each next to its link bound
+    # (xGMI full mesh, 7 links x 76.8 GB/s inbound per GPU).  Each leg sets the env up for its own payload only
+    # (`includes` says what its step carried); `none` is the pure simulation rate; `batch` = sharded without the per-step
+    # summary.  Cheapest and most informative first: a leg that fails ends the run with the legs before it in the line.
+    if distributed and not args.no_gather_modes:
+        order = [m for m in ("none", "batch", "sharded", "summary", "full-u16", "full") if m != gather_mode]
+        for m in order:
+            if not guard.go(m, 12, kind="gather"):
+                continue
+            with guard.leg(m, kind="gather"):
+                if m == "batch":
+                    g = ShardedCollector(env, dist, rank, summary=False)
+                else:
+                    g = make_collector(m)
+                n_leg = max(args.steps // 4, 5)
+                if m in ("batch", "sharded"):
+                    step_no += g.prefill(step_no)
+                    n_leg = max(n_leg, 2 * g.batch_every)        # (a leg without a batch in it would not be this payload)
+                step_no += preheat(g, step_no)
+                finish(g)
+                t = timed(g, step_no, n_leg)
+                step_no += n_leg
+                e = dict(getattr(g, "model", None) or gather_link_model(sizes.get(m, 0), world))
+                e.update(ms_per_step=t / n_leg * 1e3, env_steps_per_s=total_envs * n_leg * args.repeat / t, steps=n_leg,
+                         includes=g.includes)
+                if m not in ("none",) and not args.no_gather_check:
+                    c = g.check(step_no, dist)
+                    step_no += 8
+                    e["check"] = c
+                    checks[m] = c
+                g.close()
+                if rank == 0:
+                    out["gather_modes"][m] = e
+                    out["gather_check"] = dict(ok=all(c["ok"] is not False for c in checks.values()), payloads=checks)
+    if getattr(env, "_p2p_mode", None) is not None:
+        with guard.leg("p2p_close"):
+            p2p_close()
+
+    # the reference's own setting, action_repeat 4 with the scan once per agent step (dreamer/dream.py:55; SURVEY.md H9)
+    if guard.go("action_repeat_4", 8):
+        with guard.leg("action_repeat_4"):
+            r4_steps = max(args.steps // 4, 5)
+            g = make_collector("none")
+            step_no += preheat(g, step_no, 40)
+            dt4 = timed(g, step_no, r4_steps, repeat=4)
+            step_no += r4_steps
+            if rank == 0:
+                out["action_repeat_4"] = {"env_steps_per_s": total_envs * r4_steps * 4 / dt4,
+                                          "agent_steps_per_s": total_envs * r4_steps / dt4, "steps": r4_steps,
+                                          "note": "same envs with action_repeat 4, LiDAR once per agent step (dreamer/dream.py:55), no exchange"}
+
     # secondary figure: cars driven along the track at speed by the reference's follow-the-gap law (its other prefill
     # policy, dreamer/dream.py:211-216) instead of crawling under random actions: single-GPU runs only
-    if world == 1 and not args.no_cpu_baseline_ftg:
+    if world == 1 and not args.no_cpu_baseline_ftg and guard.go("follow_the_gap", 10):
         with guard.leg("follow_the_gap"):
             mean_range_random = float(env.views["lidar"].float().mean().item())
             env.reset(mode="random", seed=0)
@@ -1275,20 +1254,21 @@ def main():
                         "(ros_agent/agents/follow_the_gap/src/agent.py:128-234) as a device agent - after 150 settling steps "
                         "(cars at 4 m/s instead of crawling under random actions); includes the agent's kernel"}
     env.close()
-    if rank == 0 and world == 1:
-        if not args.no_configs:
-            # BASELINE.json configs[1..3], each a few ms of GPU time (configs[0] is the CPU plumbing case, configs[4]
-            # the 8-GPU run: `--gpus 8 --mixed-tracks`)
-            cfgs = [("configs[1]: 4 096 envs, columbia, 1080-beam lidar", "columbia", 4096, 1, "lidar", 400, 40, "random"),
-                    ("configs[2]: 65 536 envs, austria, obs_type=lidar_occupancy (64x64 render)", "austria", 65536, 1,
-                     "lidar_occupancy", 100, 10, "random"),
-                    ("configs[3]: 32 768 envs x 2 cars, treitlstrasse_v2, inter-car raycast + collision",
-                     "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
+    if rank == 0 and world == 1 and not args.no_configs:
+        # BASELINE.json configs[1..3], each a few ms of GPU time (configs[0] is the CPU plumbing case, configs[4]
+        # the 8-GPU run: `--gpus 8 --mixed-tracks`)
+        cfgs = [("configs[1]: 4 096 envs, columbia, 1080-beam lidar", "columbia", 4096, 1, "lidar", 400, 40, "random"),
+                ("configs[2]: 65 536 envs, austria, obs_type=lidar_occupancy (64x64 render)", "austria", 65536, 1,
+                 "lidar_occupancy", 100, 10, "random"),
+                ("configs[3]: 32 768 envs x 2 cars, treitlstrasse_v2, inter-car raycast + collision",
+                 "treitlstrasse_v2", 32768, 2, "lidar", 100, 10, "random_ball")]
+        if guard.go("configs", 40):
             with guard.leg("configs"):
                 out["configs"] = [time_config(*c, settle=args.settle) for c in cfgs]
                 out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10, settle=args.settle))
-            # the scan across tracks at the headline's batch size: small tables (columbia) to the largest (gbr: 506 MB of
-            # first-trip table) - the range the headline's one track sits in
+        # the scan across tracks at the headline's batch size: small tables (columbia) to the largest (gbr: 506 MB of
+        # first-trip table) - the range the headline's one track sits in
+        if guard.go("tracks", 40):
             with guard.leg("tracks"):
                 out["tracks"] = [time_track(t, args.envs, 60, 10, args.settle) for t in ("columbia", "barcelona", "gbr") if t != track_name]
                 out["tracks"].insert(0, {"track": track_name, "envs": args.envs, "ms_per_step": out["ms_per_step"],
@@ -1298,13 +1278,8 @@ def main():
                 out["roofline"]["raycast_ms_range_over_tracks"] = [min(rm), max(rm)]
                 out["roofline"]["frac_range_over_tracks"] = [RAYCAST_BYTES_PER_CAR * args.envs / (max(rm) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                              RAYCAST_BYTES_PER_CAR * args.envs / (min(rm) * 1e-3) / 1e9 / HBM_PEAK_GBS]
-        if not args.no_cpu_baseline:
-            with guard.leg("cpu_baseline"):
-                from oracle import cpu_baseline as cb
-                out["cpu_baseline"] = cpu_baseline(track, args.cars, args.obs_type, args.repeat, args.cpu_envs)
-                out["cpu_baseline"]["single_env"] = cb.run_single_env()      # BASELINE.json configs[0]: the B = 1 CPU step()
-                if not args.no_numpy_baseline:
-                    out["cpu_baseline"]["numpy_batch"] = cb.run_numpy_batch(track, n_envs=args.numpy_envs)
+    if rank == 0:
+        out["seconds_since_start"] = round(time.time() - t0_run, 1)
     guard.emit()
     if distributed:
         dist.barrier()
@@ -1312,6 +1287,8 @@ def main():
     guard.done()
     if any(c["ok"] is False for c in checks.values()):
         print(f"bench.py: rank {rank}: a gathered record of a secondary payload differs from what its sender sent: {checks}", file=sys.stderr)
+        sys.exit(EXIT_LEG_LOST)
+    sys.exit(guard.exit_code())           # 0, or 5 when a leg after the headline failed (N = 1: recorded in `leg_errors`, the run went on)
 
 
 if __name__ == "__main__":

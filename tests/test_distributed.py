@@ -273,8 +273,9 @@ def _run_guard_snippet(body, timeout=60):
 
 def test_line_guard_prints_the_one_line_whatever_a_later_leg_does():
     """bench.py's LineGuard without a GPU: once armed with the headline, (a) a leg that raises at N = 1 is recorded and the run
-    goes on, the final line carries `leg_errors`; (b) a leg that overruns its deadline ends the process with rc 0 and the line
-    with `aborted`; (c) before it is armed - the headline leg itself - an exception is an exception."""
+    goes on, the final line carries `leg_errors` and the exit code says a leg was lost (5); (b) a leg that overruns its deadline
+    ends the process with the line + `aborted`, exit 5; (c) before it is armed - the N = 1 headline leg itself - an exception is
+    an exception; (d) a leg for which the time budget has no room is skipped and listed, which is not an error."""
     r = _run_guard_snippet('''
 g = bench.LineGuard(0, 1, 30.0)
 line = {"metric": "m", "value": 1.0}
@@ -284,13 +285,20 @@ with g.leg("configs"):
 with g.leg("tracks"):
     line["tracks"] = [1, 2]
 g.emit(shutdown_s=1.0)
-time.sleep(5)            # a shutdown that hangs (a rank that never reaches the closing barrier): the process ends, rc 0, one line
+time.sleep(5)            # a shutdown that hangs (a rank that never reaches the closing barrier): the process ends, one line
 print("not reached")
 ''')
-    assert r.returncode == 0, r.stderr
+    assert r.returncode == 5, r.stderr
     out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(out) == 1 and out[0]["value"] == 1.0 and out[0]["tracks"] == [1, 2]
     assert "boom" in out[0]["leg_errors"]["configs"] and "aborted" not in out[0] and "not reached" not in r.stdout
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 30.0)
+g.arm({"metric": "m", "value": 1.5})
+g.emit(shutdown_s=1.0)
+time.sleep(5)            # the same hung shutdown behind a COMPLETE line: exit 0
+''')
+    assert r.returncode == 0 and json.loads(r.stdout)["value"] == 1.5, (r.stdout, r.stderr)
     r = _run_guard_snippet('''
 g = bench.LineGuard(0, 1, 1.0)
 g.arm({"metric": "m", "value": 2.0})
@@ -298,12 +306,139 @@ with g.leg("cpu_baseline"):
     time.sleep(30)
 print("not reached")
 ''')
-    assert r.returncode == 0 and "not reached" not in r.stdout, (r.stdout, r.stderr)
+    assert r.returncode == 5 and "not reached" not in r.stdout, (r.stdout, r.stderr)
     out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(out) == 1 and out[0]["value"] == 2.0 and out[0]["aborted"]["leg"] == "cpu_baseline" and "deadline" in out[0]["aborted"]["reason"]
+    assert out[0]["aborted"]["exit_code"] == 5
     r = _run_guard_snippet('''
 g = bench.LineGuard(0, 1, 30.0)
 with g.leg("headline"):
     raise RuntimeError("the headline itself")
 ''')
     assert r.returncode != 0 and "the headline itself" in r.stderr and not r.stdout.strip()
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 30.0, deadline=time.time() + 40.0)
+line = {"metric": "m", "value": 3.0}
+g.arm(line)
+assert g.go("quick", 5.0)
+with g.leg("quick", kind="gather"):
+    time.sleep(0.2)
+assert not g.go("long", 60.0)              # 40 s left, 12 s of them reserved for leaving
+assert 0.9 < g.budget() <= 30.0 and g.budget(500.0) <= 40.0 - g.RESERVE_S
+g.emit()
+g.done()
+sys.exit(g.exit_code())
+''')
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout)
+    assert "long" in out["legs_skipped"] and "leg_errors" not in out and "aborted" not in out
+
+
+def test_a_provisional_line_is_printed_when_the_headline_never_comes():
+    """VERDICT r5 #1b: armed with a PROVISIONAL line before the first collective, a rendezvous or headline leg that hangs or
+    raises prints that line - `headline_pending`, `aborted` - and exits 3, a code of its own; SIGTERM prints it too."""
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 1.0)
+g.install()
+g.arm({"metric": "m", "value": 8.0}, pending=True)
+with g.leg("rendezvous"):
+    time.sleep(30)
+''')
+    assert r.returncode == 3, (r.stdout, r.stderr)
+    out = json.loads(r.stdout)
+    assert out["headline_pending"] is True and out["aborted"]["leg"] == "rendezvous" and out["aborted"]["exit_code"] == 3
+    assert "BEFORE the headline" in out["aborted"]["note"]
+    r = _run_guard_snippet('''
+g = bench.LineGuard(0, 1, 30.0)
+g.install()
+g.arm({"metric": "m", "value": 8.0}, pending=True)
+with g.leg("headline"):
+    raise RuntimeError("first contact")
+''')
+    assert r.returncode == 3 and "first contact" in json.loads(r.stdout)["aborted"]["reason"], (r.stdout, r.stderr)
+    r = _run_guard_snippet('''
+import os, signal
+g = bench.LineGuard(0, 1, 30.0)
+g.install()
+g.arm({"metric": "m", "value": 8.0}, pending=True)
+g.promote({"metric": "m", "value": 9.0})
+with g.leg("full"):
+    os.kill(os.getpid(), signal.SIGTERM)
+    time.sleep(30)
+''')
+    assert r.returncode == 128 + 15, (r.stdout, r.stderr)
+    out = json.loads(r.stdout)
+    assert out["value"] == 9.0 and "headline_pending" not in out and out["aborted"]["leg"] == "signal"
+
+
+def _pids_alive(pids):
+    alive = []
+    for p in pids:
+        try:
+            with open(f"/proc/{p}/stat") as f:
+                if f.read().rsplit(")", 1)[1].split()[0] != "Z":
+                    alive.append(p)
+        except OSError:
+            pass
+    return alive
+
+
+@pytest.mark.parametrize("how", ["SIGTERM", "SIGKILL"])
+def test_no_rank_survives_its_launcher_and_the_line_is_printed(how, tmp_path):
+    """VERDICT r5 #1a, #1d: `python bench.py --gpus 2` (the self-launcher, as the driver starts it) with both ranks hung in the
+    headline leg - the first collective on the data path.  SIGTERM to the LAUNCHER alone (what a driver's time-out sends):
+    it forwards the signal to the ranks' session, rank 0 prints the ONE provisional line, every process of the tree is gone
+    when the launcher returns, and the exit code is 128 + 15.  SIGKILL to the launcher (no handler can run): the kernel's
+    parent-death signal ends the launcher child and the ranks all the same.  No GPU: the local stage is a stand-in
+    (RC_BENCH_FAKE_LOCAL), the rendezvous over gloo is real."""
+    import signal
+    import subprocess
+    import sys
+    import time
+    import psutil
+    out, err = tmp_path / "out", tmp_path / "err"
+    env = dict(os.environ, RC_BENCH_FAKE_LOCAL="1", RC_BENCH_HANG_LEG="headline")
+    with open(out, "w") as fo, open(err, "w") as fe:
+        p = subprocess.Popen([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--envs", "64"],
+                             cwd=ROOT, env=env, stdout=fo, stderr=fe)
+        try:
+            t_end = time.time() + 240
+            while time.time() < t_end and "ranks joined" not in err.read_text():      # both ranks are through the rendezvous
+                assert p.poll() is None, err.read_text()[-2000:]
+                time.sleep(0.5)
+            assert "ranks joined" in err.read_text(), err.read_text()[-2000:]
+            time.sleep(1.0)
+            tree = [c.pid for c in psutil.Process(p.pid).children(recursive=True)]
+            assert len(tree) >= 2                                 # the two ranks (and whatever they started)
+            p.send_signal(getattr(signal, how))
+            rc = p.wait(timeout=90)
+            t_end = time.time() + 30
+            while time.time() < t_end and _pids_alive(tree):
+                time.sleep(0.25)
+            assert _pids_alive(tree) == [], f"survivors of {how}: {_pids_alive(tree)}"
+        finally:
+            for q in psutil.Process().children(recursive=True):
+                q.kill()
+    lines = [l for l in out.read_text().splitlines() if l.startswith("{")]
+    if how == "SIGTERM":
+        assert rc == 128 + 15, err.read_text()[-2000:]
+    assert len(lines) == 1, (out.read_text()[-2000:], err.read_text()[-2000:])
+    d = json.loads(lines[0])
+    assert d["headline_pending"] is True and d["n_gpus"] == 2 and d["aborted"]["leg"] == "signal" and "provisional" in d
+    assert {"metric", "value", "unit", "steps", "warmup", "ms_per_step", "config"} <= set(d)
+
+
+def test_a_headline_that_hangs_costs_a_deadline_not_the_driver_s_time_out():
+    """The same two ranks hung in the headline leg, nobody signalling: the leg's own deadline (here 5 s) prints the provisional
+    line with `aborted` naming the leg and every rank exits 3; the launcher hands the failure on."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "4", "--warmup", "1", "--envs", "64",
+                        "--leg-timeout", "5"], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, RC_BENCH_FAKE_LOCAL="1", RC_BENCH_HANG_LEG="headline"))
+    assert r.returncode == 3, r.stderr[-2000:]                 # (the ranks' own exit code reaches the caller as it is)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["headline_pending"] is True and d["aborted"]["leg"] == "headline" and d["aborted"]["exit_code"] == 3
+    assert "deadline of 5 s" in d["aborted"]["reason"] and "exit 3" in r.stderr
