@@ -292,7 +292,14 @@ class ShardedCollector:
             env.disable_compact()
         self.batch_every, self.length, self.capacity = int(batch_every), int(length), int(capacity)
         self.windows = -(-int(windows) // self.world) * self.world
-        self.ring = TrajectoryRing(env, capacity)
+        # one ring per env, reused by every leg that collects on it: a 64-slot ring of 65 536 records is 18.4 GB, and a fresh one
+        # per leg left the freed ones cached in torch's allocator (the 6-rank rehearsal on one GPU ran out of memory in its
+        # third leg: profiles/r06_c_*)
+        self.ring = getattr(env, "_bench_ring", None)
+        if self.ring is None or self.ring.capacity != capacity:
+            self.ring = env._bench_ring = TrajectoryRing(env, capacity)
+        else:
+            self.ring.clear()
         self.rep = ShardedReplay(self.ring)
         self.gen = torch.Generator(device=env.device)
         self.gen.manual_seed(1234 + rank)
@@ -1109,6 +1116,7 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
                 env = head_env
                 torch.cuda.set_stream(env.stream)
                 env_mix.close()
+                env_mix._bench_ring = None          # (its ring goes back to the allocator)
             tracks_by_rank = [None] * world
             dist.all_gather_object(tracks_by_rank, mine)
             if rank == 0:

@@ -98,6 +98,11 @@ class TrajectoryRing:
         """Give the env its own arena back (the ring keeps its contents)."""
         self.env.set_arena(None)
 
+    def clear(self) -> None:
+        """Forget the records held (the memory stays): the next record goes to slot 0, windows are drawn from what is written
+        from now on.  For a caller that runs several collections over one env and wants ONE ring's worth of memory."""
+        self.head, self.count, self.steps_written = -1, 0, 0
+
     # ------------------------------------------------------------------ reading
     def _field_names(self, fields: Optional[Sequence[str]]) -> list:
         """The fields of a draw: the default set narrowed to what this ring records, or exactly what the caller named - a

@@ -22,8 +22,19 @@ LIDAR_X = 0.25                # sensor origin ahead of the rear axle [m]        
 # --- vehicle ----------------------------------------------------------------------
 WHEELBASE = 0.3302            # ros_agent/agents/follow_the_gap/src/agent.py:78
 MAX_STEER = 0.42              # ros_agent/models/dreamer/racing_dreamer.py:14 (nominal scale of the steering action)
-WHEEL_MAX = 0.19              # front-wheel angle at full command [rad]; a POSITIVE command steers RIGHT (clockwise): both
-STEER_GAIN = -WHEEL_MAX       # pinned by the reference's trained agents (tests/test_golden_policy.py)
+# Front-wheel angle of the BICYCLE model at full command, and its sign.  Two reference-held pins:
+#  (1) the reference's own deployment mapping from a simulator command to an Ackermann (bicycle) drive message:
+#        ros_agent/agents/dreamer/src/agent.py:111   steering = 0 - action['steering'] * 0.6 * 0.42   "working better in hardware"
+#        ros_agent/agents/dreamer/src/agent.py:112   ... * 0.7 * 0.42                                  "working better in simulation"
+#        ros_agent/agents/acme/src/agent.py:90, ros_agent/agents/sb3/src/agent.py:90   ... * 0.4 * 0.42
+#      the NEGATION against ROS's left-positive steering angle = a positive command steers RIGHT; the effective lock is
+#      0.4 .. 0.7 x 0.42 = 0.168 .. 0.294 rad - WHEEL_MAX lies inside (tests/golden/deployment_mapping.json,
+#      tests/test_golden_policy.py::test_the_references_deployment_mapping_*);
+#  (2) the reference's trained agents: the shipped austria agent laps here for a lock of 0.15 .. 0.19 rad and turns into the
+#      inner wall of the first hairpin from 0.21 rad on (so the upper half of the authors' band, 0.25 .. 0.29, is refuted for
+#      THIS kinematic model: profiles/r06_b_deployment_mapping.txt), the treitlstrasse agent for 0.18 .. 0.21.
+WHEEL_MAX = 0.19              # [rad]; a POSITIVE command steers RIGHT (clockwise)
+STEER_GAIN = -WHEEL_MAX       # command -> wheel angle, counter-clockwise positive
 MAX_FORCE = 0.5               # ros_agent/models/dreamer/racing_dreamer.py:15
 MAX_VEL = 5.0                 # ros_agent/models/dreamer/racing_dreamer.py:16
 FORCE_TO_ACCEL = 8.0          # m/s^2 per unit motor force                          (free)

@@ -37,6 +37,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from oracle import c_oracle                                    # noqa: E402
 from oracle import racecar_oracle as ro                       # noqa: E402
+from oracle.deployment_port import NodeFilter                # noqa: E402
 from oracle.dreamer_policy_port import DreamerPolicy          # noqa: E402
 from racing_dreamer_amd import spec                           # noqa: E402
 from racing_dreamer_amd.track_assets import load_track        # noqa: E402
@@ -46,41 +47,6 @@ PUBLISHED = {"austria": 1.31, "columbia": 2.23, "treitlstrasse_v2": 2.00}       
 NOMINAL = spec.MAX_STEER                                      # 0.42: ros_agent/models/dreamer/racing_dreamer.py:14
 
 
-class NodeFilter:
-    """What the deployment node does between the policy's command and the drive message, per decision (per env)."""
-
-    def __init__(self, n, scale, lowpass, motor_law):
-        self.scale, self.lowpass, self.motor_law = scale, lowpass, motor_law
-        self.steer = np.zeros(n)                 # the node's self._steering, as a fraction of the nominal 0.42 rad
-        self.speed = np.full(n, 1.7)             # the node's self._motor (a target speed), dreamer node :96-107
-
-    def __call__(self, raw, scan):
-        """raw: the actor's output in [-1, 1]^2 (motor, steering) before ReduceActionSpace; returns the same kind of array
-        for an env whose lock is NOMINAL and whose actions are remapped (dream.py:138)."""
-        motor = (raw[:, 0] + 1.0) / 2.0 * (1.0 - 0.005) + 0.005          # postprocess_action, racing_dreamer.py:53-59
-        cmd = raw[:, 1].astype(np.float64) * self.scale                   # fraction of 0.42 rad; sign: the env's own (positive = right)
-        if self.lowpass == "sim":                                          # :119  1/6 old + 5/6 new
-            self.steer = self.steer / 6.0 + cmd * 5.0 / 6.0
-        elif self.lowpass == "hw":                                         # :86-90, :114-118
-            r = np.clip(scan, None, 4.0)
-            r[:, 3:-3] = (r[:, 3:-3] + r[:, 2:-4] + r[:, 4:-2]) / 3.0
-            forward_max = r[:, 540 - 150:540 + 150].max(1)
-            val = 18.0 - forward_max * 3.0
-            self.steer = self.steer * (20.0 - val) / 20.0 + cmd * val / 20.0
-        elif self.lowpass == "acme":                                       # acme / sb3 :93-94
-            div = self.speed * 1.5 + 0.5
-            self.steer = self.steer * (div - 1.0) / div + cmd / div
-        else:
-            self.steer = cmd
-        out = raw.astype(np.float32).copy()
-        out[:, 1] = np.clip(self.steer, -1.0, 1.0)
-        if self.motor_law:
-            self.speed = np.clip(np.where(motor < 0.5, self.speed - 0.05, self.speed + 0.065), 1.7, 5.0)
-            m = self.speed / spec.MAX_VEL                                  # this env: throttle m settles at 5 m m/s
-            out[:, 0] = np.clip((m - 0.005) / 0.995 * 2.0 - 1.0, -1.0, 1.0)
-        return out
-
-
 def run(track_name, agent, n, repeat, seconds, mapping, seed=0):
     t = load_track(track_name)
     cfg = ro.OracleConfig(num_envs=n, auto_reset=False, remap_actions=True, laps=10, time_limit=180.0)
@@ -88,9 +54,9 @@ def run(track_name, agent, n, repeat, seconds, mapping, seed=0):
     policy = DreamerPolicy(np.load(os.path.join(GOLDEN, f"dreamer_policy_{agent}.npz")), sample=True, seed=seed)
     filt = None
     if mapping is not None:
-        scale, lowpass, motor_law = mapping
+        kind, motor_law = mapping
         c_oracle.set_dynamics(steer_gain=-NOMINAL)
-        filt = NodeFilter(n, scale, lowpass, motor_law)
+        filt = NodeFilter(n, kind, motor_law, max_vel=spec.MAX_VEL)
     out = env.reset(mode=ro.RESET_GRID, seed=1)
     state = policy.initial(n)
     alive = np.ones(n, bool)
@@ -115,15 +81,17 @@ def run(track_name, agent, n, repeat, seconds, mapping, seed=0):
 
 MAPPINGS = [
     ("spec: lock 0.19, direct, repeat 4", None, 4),
-    ("sim-0.7: 0.294 rad, 5/6 low-pass, ~10 Hz (repeat 10)", (0.7, "sim", False), 10),
-    ("sim-0.7 at repeat 8", (0.7, "sim", False), 8),
-    ("sim-0.7 at repeat 4 (the training cadence)", (0.7, "sim", False), 4),
-    ("0.7 x 0.42 direct feed, repeat 4 (lock 0.294 alone)", (0.7, None, False), 4),
-    ("hw-0.6: 0.252 rad, hardware low-pass, repeat 10", (0.6, "hw", False), 10),
-    ("acme-0.4: 0.168 rad, low-pass 1/(1.5 v + 0.5), repeat 10", (0.4, "acme", False), 10),
-    ("0.4 x 0.42 direct feed, repeat 4 (lock 0.168 alone)", (0.4, None, False), 4),
-    ("sim-0.7 + the node's speed law, repeat 10", (0.7, "sim", True), 10),
-    ("hw-0.6 + the node's speed law, repeat 10", (0.6, "hw", True), 10),
+    ("sim-0.7: 0.294 rad, 5/6 low-pass, ~10 Hz (repeat 10)", ("sim", False), 10),
+    ("sim-0.7 at repeat 8", ("sim", False), 8),
+    ("sim-0.7 at repeat 4 (the training cadence)", ("sim", False), 4),
+    ("0.7 x 0.42 direct feed, repeat 4 (lock 0.294 alone)", ("direct:0.7", False), 4),
+    ("hw-0.6: 0.252 rad, hardware low-pass, repeat 10", ("hw", False), 10),
+    ("0.6 x 0.42 direct feed, repeat 4 (lock 0.252 alone)", ("direct:0.6", False), 4),
+    ("acme-0.4: 0.168 rad, low-pass 1/(1.5 v + 0.5), repeat 10", ("acme", False), 10),
+    ("0.4 x 0.42 direct feed, repeat 4 (lock 0.168 alone)", ("direct:0.4", False), 4),
+    ("sim-0.7 + the node's speed law, repeat 10", ("sim", True), 10),
+    ("hw-0.6 + the node's speed law, repeat 10", ("hw", True), 10),
+    ("0.4 x 0.42 direct + the node's speed law, repeat 10", ("direct:0.4", True), 10),
 ]
 AGENTS = (("austria", "austria"), ("austria", "columbia"), ("treitlstrasse", "Treitlstrasse_3-U_v3"), ("treitlstrasse", "columbia"))
 
