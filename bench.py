@@ -1128,9 +1128,14 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
 
     # the headline payload over a window ten times as long: a 20-step window (3 - 5 ms) carries the pipeline's start and
     # drain and the closing barrier at full weight; this is the steady state next to it
-    if distributed and gather_mode != "none" and guard.go("steady_state", 15, kind="gather"):
-        with guard.leg("steady_state", kind="gather"):
-            n_long = max(10 * args.steps, 200)
+    def leg_weight(mode, n_steps):
+        """bytes a payload leg moves per rank: what its duration scales with when the links (or a host-staged test backend) bound it"""
+        per_step = {"sharded": sizes["summary"], "batch": 0, "none": 0}.get(mode, sizes.get(mode, 0)) if sizes else 0
+        return float(max(per_step, 1 << 20)) * n_steps
+
+    n_long = max(10 * args.steps, 200)
+    if distributed and gather_mode != "none" and guard.go("steady_state", 15, kind="gather", weight=leg_weight(gather_mode, n_long + args.settle)):
+        with guard.leg("steady_state", kind="gather", weight=leg_weight(gather_mode, n_long + args.settle)):
             g = make_collector(gather_mode)
             if gather_mode == "sharded":
                 step_no += g.prefill(step_no)
@@ -1150,11 +1155,12 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
     if distributed and not args.no_gather_modes:
         out["gather_modes_repeat_4"] = {} if rank == 0 else None
         for m in ("full-u16", "full"):
-            if not guard.go(m + "@repeat4", 12, kind="gather"):
+            n_leg = max(args.steps // 4, 5)
+            wgt = leg_weight(m, n_leg + 40 + 4)
+            if not guard.go(m + "@repeat4", 12, kind="gather", weight=wgt):
                 continue
-            with guard.leg(m + "@repeat4", kind="gather"):
+            with guard.leg(m + "@repeat4", kind="gather", weight=wgt):
                 g = make_collector(m)
-                n_leg = max(args.steps // 4, 5)
                 step_no += preheat(g, step_no, 40)
                 finish(g)
                 t = timed(g, step_no, n_leg, repeat=4)
@@ -1184,9 +1190,10 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
     if distributed and not args.no_gather_modes:
         order = [m for m in ("none", "batch", "sharded", "summary", "full-u16", "full") if m != gather_mode]
         for m in order:
-            if not guard.go(m, 12, kind="gather"):
+            wgt = leg_weight(m, max(args.steps // 4, 5 if m not in ("batch", "sharded") else 2 * BATCH_EVERY) + args.settle + 4)
+            if not guard.go(m, 12, kind="gather", weight=wgt):
                 continue
-            with guard.leg(m, kind="gather"):
+            with guard.leg(m, kind="gather", weight=wgt):
                 if m == "batch":
                     g = ShardedCollector(env, dist, rank, summary=False)
                 else:

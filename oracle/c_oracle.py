@@ -24,7 +24,11 @@ class OcTrack(C.Structure):
     _fields_ = [("occ", _bp), ("ring", _bp), ("drv", _bp), ("progress", _fp), ("centerline", _fp), ("beams", _fp),
                 ("foot", _fp), ("h", C.c_int32), ("w", C.c_int32), ("n_centerline", C.c_int32),
                 ("org_x", C.c_float), ("org_y", C.c_float), ("res", C.c_float), ("inv_res", C.c_float),
-                ("tmax", C.c_float), ("spawn_w", _fp), ("spawn_safe", _ip)]
+                ("tmax", C.c_float), ("spawn_w", _fp), ("spawn_safe", _ip), ("spawn_rows", _fp)]
+
+
+class OcFrame(C.Structure):
+    _fields_ = [("fh", C.c_int32), ("r_top", C.c_int32), ("c0", C.c_int32), ("ox", C.c_double), ("oy", C.c_double), ("res", C.c_double)]
 
 
 class OcCfg(C.Structure):
@@ -74,8 +78,13 @@ def load():
         lib.oc_random_actions.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.oc_spawn_width.argtypes = [P(OcTrack), C.c_void_p]
         lib.oc_spawn_safe.argtypes = [P(OcTrack), C.c_void_p]
+        lib.oc_spawn_rows.argtypes = [P(OcTrack), C.c_void_p]
+        lib.oc_patch_exact_range.argtypes = [P(OcTrack), P(OcFrame), P(OcState), C.c_void_p, C.c_int, C.c_int]
+        lib.oc_patch_exact_range.restype = None
+        lib.oc_resize_coefficients.argtypes = [C.c_void_p, C.c_void_p]
+        lib.oc_resize_coefficients.restype = None
         for f in (lib.oc_reset, lib.oc_step_range, lib.oc_raycast_range, lib.oc_patch_range, lib.oc_random_actions, lib.oc_spawn_width,
-                  lib.oc_spawn_safe):
+                  lib.oc_spawn_safe, lib.oc_spawn_rows):
             f.restype = None
         lib.oc_set_dynamics.argtypes = [C.c_float] * 5
         lib.oc_set_dynamics.restype = None
@@ -112,13 +121,16 @@ class COracleEnv:
         self.trk = OcTrack(_ptr(k["occ"], _bp), _ptr(k["ring"], _bp), _ptr(k["drv"], _bp), _ptr(k["progress"], _fp),
                            _ptr(k["centerline"], _fp), _ptr(k["beams"], _fp), _ptr(k["foot"], _fp), self.H, self.W,
                            len(k["centerline"]), np.float32(origin[0]), np.float32(origin[1]),
-                           np.float32(resolution), inv_res, np.float32(ro.MAX_RANGE * inv_res), None, None)
+                           np.float32(resolution), inv_res, np.float32(ro.MAX_RANGE * inv_res), None, None, None)
         k["spawn_w"] = np.zeros(len(k["centerline"]), np.float32)      # the C port builds its own table (oc_spawn_width)
         self.lib.oc_spawn_width(C.byref(self.trk), k["spawn_w"].ctypes.data)
         self.trk.spawn_w = _ptr(k["spawn_w"], _fp)
         k["spawn_safe"] = np.zeros(len(k["centerline"]), np.int32)     # ... and the anchors of multi-car starts (oc_spawn_safe)
         self.lib.oc_spawn_safe(C.byref(self.trk), k["spawn_safe"].ctypes.data)
         self.trk.spawn_safe = _ptr(k["spawn_safe"], _ip)
+        k["spawn_rows"] = np.zeros((len(k["centerline"]), 5), np.float32)      # ... and the table itself (oc_spawn_rows)
+        self.lib.oc_spawn_rows(C.byref(self.trk), k["spawn_rows"].ctypes.data)
+        self.trk.spawn_rows = _ptr(k["spawn_rows"], _fp)
         self.B, self.A = cfg.num_envs, cfg.cars_per_env
         n = self.NC = self.B * self.A
         self.ccfg = OcCfg(self.B, self.A, cfg.first_env & 0xFFFFFFFF, cfg.task, cfg.laps,
@@ -170,9 +182,18 @@ class COracleEnv:
     def _observe(self):
         self._par(lambda a, b: self.lib.oc_raycast_range(C.byref(self.trk), C.byref(self.ccfg), C.byref(self.state),
                                                          self.lidar.ctypes.data, a, b), self.NC)
-        if self.cfg.render_occupancy:
+        if self.cfg.render_occupancy == "reference":       # obs_type lidar_occupancy_reference (oracle/patch_reference.py)
+            self._par(lambda a, b: self.lib.oc_patch_exact_range(C.byref(self.trk), C.byref(self.frame), C.byref(self.state),
+                                                                 self.patch.ctypes.data, a, b), self.NC)
+        elif self.cfg.render_occupancy:
             self._par(lambda a, b: self.lib.oc_patch_range(C.byref(self.trk), C.byref(self.state),
                                                            self.patch.ctypes.data, a, b), self.NC)
+
+    def set_frame(self, track):
+        """Where the track's grid lies in the source image (for render_occupancy='reference')."""
+        from . import patch_reference as px
+        fh, ox, oy, r_top, c0 = px.frame_of(track)
+        self.frame = OcFrame(fh, r_top, c0, ox, oy, float(track.resolution))
 
     def reset(self, mask=None, mode=ro.RESET_GRID, seed=0):
         self.ccfg.reset_mode = int(mode)

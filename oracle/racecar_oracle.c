@@ -61,6 +61,8 @@ void oc_set_dynamics(float accel_max, float drag, float max_vel, float steer_gai
 #define SPAWN_MARGIN 0.60f       /* [m] footprint's farthest corner (0.474) + the two half cell diagonals (0.071) */
 #define SPAWN_W_MAX 1.5f
 #define HEADING_JITTER 0.35f
+#define SPAWN_FOOT_R 5           /* cells searched around a footprint point of a centre-line pose without lateral room */
+static const float HEADING_ROOM[6] = {0.0f, 0.0f, 0.05f, 0.155f, 0.26f, 0.35f};   /* [rad] by footprint clearance 0 .. 5 cells */
 #define SPAWN_SAFE_SEARCH 256    /* several cars: bins searched forward for a start whose centre-line poses do not overlap */
 #define MAX_CARS 4
 #define NSTEP_MAX 16
@@ -79,6 +81,7 @@ typedef struct {
     float org_x, org_y, res, inv_res, tmax;
     const float *spawn_w;    /* [n] lateral room of a random start at centre-line point i (oc_spawn_width) */
     const int32_t *spawn_safe; /* [n] where a multi-car start drawn at bin i really goes (oc_spawn_safe) */
+    const float *spawn_rows; /* [n][5] the spawn table: x, y, theta, lateral room, heading room of row i (oc_spawn_rows) */
 } oc_track;
 
 typedef struct {
@@ -189,6 +192,72 @@ void oc_spawn_width(const oc_track *t, float *out) {
     }
 }
 
+/* The 34 footprint probes of H5 on a pose (racecar_oracle.py, _wall_hit_poses): cell of probe n into (*ix, *iy). */
+static inline void foot_cell(const oc_track *t, float x, float y, float ct, float st, int n, int *ix, int *iy) {
+    const float k = FOOT_STEP * t->inv_res;
+    const float gx = (x - t->org_x) * t->inv_res, gy = (y - t->org_y) * t->inv_res;
+    const int32_t ex = (int32_t)rintf((ct * k) * 65536.0f), ey = (int32_t)rintf((st * k) * 65536.0f);
+    const int32_t x0 = (int32_t)rintf(gx * 65536.0f), y0 = (int32_t)rintf(gy * 65536.0f);
+    const int li = n < 24 ? n % 12 : (n < 29 ? 0 : 11);
+    const int lj = n < 12 ? 0 : (n < 24 ? 6 : (n < 29 ? n - 23 : n - 28));
+    *ix = (x0 + (li - 2) * ex - (lj - 3) * ey) >> 16;
+    *iy = (y0 + (li - 2) * ey + (lj - 3) * ex) >> 16;
+}
+
+/* racecar_oracle.py, spawn_usable: the centre-line pose of bin i touches no wall. */
+static int bin_usable(const oc_track *t, int i) {
+    float sn, cs;
+    sincos32(t->centerline[4 * i + 2], &sn, &cs);
+    for (int n = 0; n < N_FOOT; ++n) {
+        int ix, iy;
+        foot_cell(t, t->centerline[4 * i], t->centerline[4 * i + 1], cs, sn, n, &ix, &iy);
+        if (!inb(t, ix, iy) || t->occ[(size_t)iy * t->w + ix]) return 0;
+    }
+    return 1;
+}
+
+/* racecar_oracle.py, spawn_heading_room: HEADING_JITTER where bin i has lateral room `w`, else HEADING_ROOM[k], k = the
+ * smallest over the 34 footprint points of isqrt(squared cell distance to the nearest non-drivable cell within SPAWN_FOOT_R). */
+static float bin_heading_room(const oc_track *t, int i, float w) {
+    if (w > 0.0f) return HEADING_JITTER;
+    const int R = SPAWN_FOOT_R;
+    float sn, cs;
+    sincos32(t->centerline[4 * i + 2], &sn, &cs);
+    int kmin = R;
+    for (int n = 0; n < N_FOOT; ++n) {
+        int ix, iy;
+        foot_cell(t, t->centerline[4 * i], t->centerline[4 * i + 1], cs, sn, n, &ix, &iy);
+        int d2 = (R + 1) * (R + 1);
+        if (!inb(t, ix, iy)) d2 = 0;
+        else
+            for (int dy = -R; dy <= R; ++dy)
+                for (int dx = -R; dx <= R; ++dx) {
+                    const int jx = ix + dx, jy = iy + dy;
+                    const int blocked = !inb(t, jx, jy) || !t->drv[(size_t)jy * t->w + jx];
+                    if (blocked && dx * dx + dy * dy < d2) d2 = dx * dx + dy * dy;
+                }
+        int k = 0;
+        while ((k + 1) * (k + 1) <= d2) ++k;
+        kmin = k < kmin ? k : kmin;
+    }
+    return HEADING_ROOM[kmin];
+}
+
+/* The spawn table (racecar_oracle.py, spawn_rows): row i = bin u(i), the first usable bin among i, i + 1, ... (around the lap,
+ * SPAWN_SAFE_SEARCH of them; i itself if none): x, y, theta, lateral room, heading room.  Needs t->spawn_w. */
+void oc_spawn_rows(const oc_track *t, float *out) {
+    const int n = t->n_centerline;
+    for (int i = 0; i < n; ++i) {
+        int u = i;
+        for (int k = 0; k < SPAWN_SAFE_SEARCH && k < n; ++k)
+            if (bin_usable(t, (i + k) % n)) { u = (i + k) % n; break; }
+        float *r = out + 5 * (size_t)i;
+        r[0] = t->centerline[4 * u]; r[1] = t->centerline[4 * u + 1]; r[2] = t->centerline[4 * u + 2];
+        r[3] = t->spawn_w[u];
+        r[4] = bin_heading_room(t, u, t->spawn_w[u]);
+    }
+}
+
 static inline float unit_pm1(uint32_t w) { return ((float)(w >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f; }   /* [-1, 1), exact */
 
 static int obb_overlap_pose(const float *pa, const float *pb) {          /* pose = x, y, theta, sin, cos */
@@ -208,8 +277,8 @@ static int obb_overlap_pose(const float *pa, const float *pb) {          /* pose
 }
 
 /* Where a multi-car start drawn at bin i goes (racecar_oracle.py, spawn_safe): the first bin j among i, i + 1, ...,
- * i + SPAWN_SAFE_SEARCH - 1 (around the lap) at which the centre-line poses of MAX_CARS cars, BALL_GAP bins apart, do not overlap
- * pairwise; i itself if there is none. */
+ * i + SPAWN_SAFE_SEARCH - 1 (around the lap) at which the centre-line poses of MAX_CARS cars, BALL_GAP bins apart, touch no wall
+ * and do not overlap pairwise; i itself if there is none. */
 void oc_spawn_safe(const oc_track *t, int32_t *out) {
     const int n = t->n_centerline;
     uint8_t *sound = (uint8_t *)malloc((size_t)n);
@@ -222,6 +291,11 @@ void oc_spawn_safe(const oc_track *t, int32_t *out) {
             sincos32(pose[a][2], &pose[a][3], &pose[a][4]);
         }
         int clash = 0;
+        for (int a = 0; a < MAX_CARS; ++a) {
+            int idx = (j - a * BALL_GAP) % n;
+            if (idx < 0) idx += n;
+            clash |= !bin_usable(t, idx);                       /* a bin whose centre-line pose touches a wall anchors nothing */
+        }
         for (int a = 0; a < MAX_CARS; ++a)
             for (int b = a + 1; b < MAX_CARS; ++b) clash |= obb_overlap_pose(pose[a], pose[b]);
         sound[j] = (uint8_t)!clash;
@@ -234,8 +308,9 @@ void oc_spawn_safe(const oc_track *t, int32_t *out) {
     free(sound);
 }
 
-/* Reset law (H6; racecar_oracle.py, _reset_envs): bin from word 0; car a at bin idx0 - a * BALL_GAP, moved sideways by
- * u * spawn_w and turned by v * HEADING_JITTER; if two proposed cars overlap, all cars of the env take the centre-line poses. */
+/* Reset law (H6; racecar_oracle.py, _reset_envs): bin from word 0; car a at row idx0 - a * BALL_GAP of the spawn table, moved
+ * sideways by u * (the row's lateral room) and turned by v * (its heading room); if two proposed cars overlap, all cars of the env
+ * take the centre-line poses. */
 static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
     const int A = c->cars_per_env, n = t->n_centerline;
     uint32_t r[3][4];
@@ -246,21 +321,22 @@ static void reset_env(const oc_track *t, const oc_cfg *c, oc_state *s, int e) {
     s->episode[e] += 1u;
     const int jitter = c->reset_mode != 0;
     int idx0 = !jitter ? BALL_GAP * (A - 1) + GRID_LEAD : (int)(((uint64_t)r[0][0] * (uint64_t)n) >> 32);
-    if (jitter && A > 1) idx0 = t->spawn_safe[idx0];           /* never anchor several cars where the centre line folds */
+    if (A > 1) idx0 = t->spawn_safe[idx0];                     /* never anchor several cars where the centre line folds (the grid too) */
     float centre[4][5], prop[4][5];
     for (int a = 0; a < A; ++a) {
         int idx = (idx0 - a * BALL_GAP) % n;
         if (idx < 0) idx += n;
         float *ce = centre[a], *pr = prop[a];
-        ce[0] = t->centerline[4 * idx]; ce[1] = t->centerline[4 * idx + 1]; ce[2] = t->centerline[4 * idx + 2];
+        const float *row = t->spawn_rows + 5 * (size_t)idx;
+        ce[0] = row[0]; ce[1] = row[1]; ce[2] = row[2];
         sincos32(ce[2], &ce[3], &ce[4]);
         if (!jitter) { for (int k = 0; k < 5; ++k) pr[k] = ce[k]; continue; }
         const uint32_t wu = a == 0 ? r[0][1] : r[1 + (a - 1) / 2][2 * ((a - 1) % 2)];
         const uint32_t wv = a == 0 ? r[0][2] : r[1 + (a - 1) / 2][2 * ((a - 1) % 2) + 1];
-        const float off = unit_pm1(wu) * t->spawn_w[idx];
+        const float off = unit_pm1(wu) * row[3];
         pr[0] = ce[0] - off * ce[3];
         pr[1] = ce[1] + off * ce[4];
-        float th = ce[2] + unit_pm1(wv) * HEADING_JITTER;
+        float th = ce[2] + unit_pm1(wv) * row[4];
         th = th > PI_F ? th - TWO_PI_F : th;
         th = th < -PI_F ? th + TWO_PI_F : th;
         pr[2] = th;
@@ -556,6 +632,167 @@ void oc_patch_range(const oc_track *t, const oc_state *s, uint8_t *patch, int c0
             }
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * obs_type lidar_occupancy_reference: the reference's OccupancyMapObs.step (dreamer/wrappers.py:396-406 = to_pixel, 220 x 220
+ * crop, scipy.ndimage.rotate, centre 200 x 200, PIL resize to 64 x 64) restated down to the binary64 operation.  The spec, with
+ * the library lines each step follows, is oracle/patch_reference.py (render_patch_exact); this is the same arithmetic in C. */
+#define PX_CROP 220
+#define PX_WIN 200
+#define PX_Z (-0.2679491924311227)            /* scipy ni_splines.c: the pole of the cubic spline, sqrt(3) - 2 correctly rounded */
+#define PX_ZN (-5.539710763905135e-126)       /* pow(PX_Z, 219) */
+#define PX_PI180 1.74532925199432957692e-2
+#define PX_KSIZE 15                           /* ceil(2 * 3.125) * 2 + 1 */
+#define PX_BITS 22
+
+typedef struct {
+    int32_t fh, r_top, c0;                    /* source image height; north-up pixel (R, C) = cell (gx, gy) = (C - c0, r_top - R) */
+    double ox, oy, res;                       /* world position of the full frame's lower left corner; metres per cell */
+} oc_frame;
+
+static void px_filter_line(double *c, int stride) {          /* one line of PX_CROP samples, `stride` doubles apart */
+    const double z = PX_Z, zn = PX_ZN;
+    const int n = PX_CROP;
+    const double gain = (1.0 - 1.0 / z) * (1.0 - z);
+    for (int i = 0; i < n; ++i) c[(size_t)i * stride] *= gain;
+    double c0 = c[0] + zn * c[(size_t)(n - 1) * stride], zi = z;
+    for (int i = 1; i < n - 1; ++i) {
+        c0 = c0 + zi * (c[(size_t)i * stride] + zn * c[(size_t)(n - 1 - i) * stride]);
+        zi *= z;
+    }
+    c[0] = c0 / (1.0 - zn * zn);
+    for (int i = 1; i < n; ++i) c[(size_t)i * stride] += z * c[(size_t)(i - 1) * stride];
+    c[(size_t)(n - 1) * stride] = (z * c[(size_t)(n - 2) * stride] + c[(size_t)(n - 1) * stride]) * z / (z * z - 1.0);
+    for (int i = n - 2; i >= 0; --i) c[(size_t)i * stride] = z * (c[(size_t)(i + 1) * stride] - c[(size_t)i * stride]);
+}
+
+static void px_sincos_deg(double x, double *cosv, double *sinv) {       /* x >= 0 degrees: patch_reference.py, sincos_degrees */
+    double y = floor(x / 45.0);
+    int j = (int)(y - 8.0 * floor(y / 8.0));
+    if (j & 1) { y = y + 1.0; j += 1; }
+    j &= 7;
+    const double z = (x - y * 45.0) * PX_PI180, zz = z * z;
+    const double sp = z + z * (zz * (-1.0 / 6.0 + zz * (1.0 / 120.0 + zz * (-1.0 / 5040.0 + zz * (1.0 / 362880.0 + zz * (-1.0 / 39916800.0 + zz * (
+        1.0 / 6227020800.0 + zz * (-1.0 / 1307674368000.0))))))));
+    const double cp = 1.0 - zz * (0.5 - zz * (1.0 / 24.0 - zz * (1.0 / 720.0 - zz * (1.0 / 40320.0 - zz * (1.0 / 3628800.0 - zz * (1.0 / 479001600.0 - zz * (
+        1.0 / 87178291200.0 - zz * (1.0 / 20922789888000.0))))))));
+    *cosv = j == 0 ? cp : (j == 2 ? -sp : (j == 4 ? -cp : sp));
+    *sinv = j == 0 ? sp : (j == 2 ? cp : (j == 4 ? -sp : -cp));
+}
+
+static inline void px_weights(double cc, double *w) {
+    const double y = cc - floor(cc), z = 1.0 - y;
+    w[1] = ((y * y) * (y - 2.0) * 3.0 + 4.0) / 6.0;
+    w[2] = ((z - 2.0) * (z * z) * 3.0 + 4.0) / 6.0;
+    w[0] = ((z * z) * z) / 6.0;
+    w[3] = ((1.0 - w[0]) - w[1]) - w[2];
+}
+
+static inline int px_mirror(int i) {
+    i = i < 0 ? -i : i;
+    return i >= PX_CROP ? 2 * PX_CROP - 2 - i : i;
+}
+
+static double px_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+/* Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for 200 -> 64 pixels, bicubic. */
+void oc_resize_coefficients(int32_t *kk /* [64][15] */, int32_t *bounds /* [64][2] */) {
+    const double scale = (double)PX_WIN / PATCH, filterscale = scale, support = 2.0 * filterscale, ss = 1.0 / filterscale;
+    for (int xx = 0; xx < PATCH; ++xx) {
+        const double center = 0 + (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > PX_WIN) xmax = PX_WIN;
+        xmax -= xmin;
+        double k[PX_KSIZE], ww = 0.0;
+        for (int x = 0; x < xmax; ++x) { k[x] = px_bicubic((x + xmin - center + 0.5) * ss); ww += k[x]; }
+        for (int x = 0; x < PX_KSIZE; ++x) {
+            double w = x < xmax ? k[x] : 0.0;
+            if (x < xmax && ww != 0.0) w /= ww;
+            kk[xx * PX_KSIZE + x] = w < 0 ? (int32_t)(-0.5 + w * (1 << PX_BITS)) : (int32_t)(0.5 + w * (1 << PX_BITS));
+        }
+        bounds[2 * xx] = xmin;
+        bounds[2 * xx + 1] = xmax;
+    }
+}
+
+void oc_patch_exact_range(const oc_track *t, const oc_frame *f, const oc_state *s, uint8_t *patch, int c0, int c1) {
+    int32_t kk[PATCH * PX_KSIZE], bounds[PATCH * 2];
+    oc_resize_coefficients(kk, bounds);
+    double *coef = (double *)malloc(sizeof(double) * PX_CROP * PX_CROP);
+    uint8_t *win = (uint8_t *)malloc(PX_WIN * PX_WIN), *tmp = (uint8_t *)malloc(PX_WIN * PATCH);
+    for (int car = c0; car < c1; ++car) {
+        uint8_t *out = patch + (size_t)car * PATCH * PATCH;
+        if (s->fresh[car]) { memset(out, 0, PATCH * PATCH); continue; }
+        const double x = (double)s->x[car], y = (double)s->y[car], yaw = (double)s->theta[car];
+        const int pr = (int)((double)f->fh - (y - f->oy) / f->res), pc = (int)((x - f->ox) / f->res);
+        /* 1. the crop, north-up, as float64 samples */
+        for (int r = 0; r < PX_CROP; ++r)
+            for (int c = 0; c < PX_CROP; ++c) {
+                const int gy = f->r_top - (pr - PX_CROP / 2 + r), gx = (pc - PX_CROP / 2 + c) - f->c0;
+                coef[r * PX_CROP + c] = (inb(t, gx, gy) && t->drv[(size_t)gy * t->w + gx]) ? 1.0 : 0.0;
+            }
+        /* 2. spline coefficients: along axis 0 (columns), then along axis 1 (rows) */
+        for (int c = 0; c < PX_CROP; ++c) px_filter_line(coef + c, PX_CROP);
+        for (int r = 0; r < PX_CROP; ++r) px_filter_line(coef + (size_t)r * PX_CROP, 1);
+        /* 3. the rotation */
+        double cs, sn;
+        px_sincos_deg((2.0 * 3.141592653589793 - yaw) * (180.0 / 3.141592653589793), &cs, &sn);
+        const double n = (double)PX_CROP;
+        const double b0[4] = {cs * 0.0 + sn * 0.0, cs * 0.0 + sn * n, cs * n + sn * 0.0, cs * n + sn * n};
+        const double b1[4] = {-sn * 0.0 + cs * 0.0, -sn * 0.0 + cs * n, -sn * n + cs * 0.0, -sn * n + cs * n};
+        double lo0 = b0[0], hi0 = b0[0], lo1 = b1[0], hi1 = b1[0];
+        for (int k = 1; k < 4; ++k) {
+            lo0 = b0[k] < lo0 ? b0[k] : lo0; hi0 = b0[k] > hi0 ? b0[k] : hi0;
+            lo1 = b1[k] < lo1 ? b1[k] : lo1; hi1 = b1[k] > hi1 ? b1[k] : hi1;
+        }
+        const int S0 = (int)((hi0 - lo0) + 0.5), S1 = (int)((hi1 - lo1) + 0.5);
+        const double h0 = (double)(S0 - 1) / 2, h1 = (double)(S1 - 1) / 2;
+        const double off0 = (double)(PX_CROP - 1) / 2 - (cs * h0 + sn * h1), off1 = (double)(PX_CROP - 1) / 2 - (-sn * h0 + cs * h1);
+        /* 4. the centre window of the rotated image */
+        for (int i = 0; i < PX_WIN; ++i)
+            for (int j = 0; j < PX_WIN; ++j) {
+                const double o0 = (double)(S0 / 2 - PX_WIN / 2 + i), o1 = (double)(S1 / 2 - PX_WIN / 2 + j);
+                const double cc0 = ((0.0 + o0 * cs) + o1 * sn) + off0, cc1 = ((0.0 + o0 * (-sn)) + o1 * cs) + off1;
+                double tv = 0.0;
+                if (!(cc0 < 0 || cc0 > PX_CROP - 1 || cc1 < 0 || cc1 > PX_CROP - 1)) {
+                    double w0[4], w1[4];
+                    px_weights(cc0, w0);
+                    px_weights(cc1, w1);
+                    const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
+                    for (int a = 0; a < 4; ++a) {
+                        const double *row = coef + (size_t)px_mirror(st0 + a) * PX_CROP;
+                        for (int b = 0; b < 4; ++b) tv = tv + (row[px_mirror(st1 + b)] * w0[a]) * w1[b];
+                    }
+                }
+                tv = tv > 0 ? tv + 0.5 : 0.0;
+                win[i * PX_WIN + j] = (uint8_t)(tv > 255.0 ? 255.0 : tv);
+            }
+        /* 5. Pillow's 8-bit resize: horizontal pass, then vertical */
+        for (int r = 0; r < PX_WIN; ++r)
+            for (int xx = 0; xx < PATCH; ++xx) {
+                int32_t acc = 1 << (PX_BITS - 1);
+                for (int k = 0; k < bounds[2 * xx + 1]; ++k) acc += (int32_t)win[r * PX_WIN + bounds[2 * xx] + k] * kk[xx * PX_KSIZE + k];
+                acc >>= PX_BITS;
+                tmp[r * PATCH + xx] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+            }
+        for (int yy = 0; yy < PATCH; ++yy)
+            for (int xx = 0; xx < PATCH; ++xx) {
+                int32_t acc = 1 << (PX_BITS - 1);
+                for (int k = 0; k < bounds[2 * yy + 1]; ++k) acc += (int32_t)tmp[(bounds[2 * yy] + k) * PATCH + xx] * kk[yy * PX_KSIZE + k];
+                acc >>= PX_BITS;
+                out[yy * PATCH + xx] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+            }
+    }
+    free(coef); free(win); free(tmp);
 }
 
 /* CPU-share calibration for bench.py's cpu_baseline leg (oracle/cpu_baseline.py): a fixed amount of dependent integer

@@ -97,6 +97,13 @@ SPAWN_MARGIN = f32(0.60)         # [m] kept between the rear-axle point and that
                                  # (0.474 m) + the two half cell diagonals (0.071 m) the cell-centre distance cannot see
 SPAWN_W_MAX = f32(1.5)           # [m] cap of the lateral offset
 HEADING_JITTER = f32(0.35)       # [rad] the heading is drawn within +- this of the track's direction
+# ... where the track leaves lateral room.  Where it leaves none (w = 0: a corridor narrower than SPAWN_MARGIN either side), the
+# heading may only turn as far as the footprint's own clearance allows: level k = the smallest, over the 34 footprint points of
+# the centre-line pose, of isqrt(squared cell distance to the nearest non-drivable cell within +- SPAWN_FOOT_R), capped at 5;
+# a point at most 0.474 m from the rear axle moves by at most 0.474 |dtheta|, and k cells between cell centres leave
+# 0.05 k - 0.0707 m between the point and a blocked cell's area: dtheta < (0.05 k - 0.0707 - 0.005) / 0.474.
+SPAWN_FOOT_R = 5
+HEADING_ROOM = np.array([0.0, 0.0, 0.05, 0.155, 0.26, 0.35], f32)      # [rad] by level k = 0 .. 5
 MAX_CARS = 4                     # cars per env at most (include/racecar_hip.h RC_MAX_CARS)
 SPAWN_SAFE_SEARCH = 256          # several cars: bins searched forward for a start whose centre-line poses do not overlap
 PI = f32(3.14159274101257324)
@@ -451,9 +458,88 @@ class OracleRaceEnv:
         self._spawn_w = w.astype(f32)
         return self._spawn_w
 
+    def _wall_hit_poses(self, x, y, ct, st):
+        """`_wall_hit` on poses instead of car slots (the same 34 fixed-point probes)."""
+        k = FOOT_STEP * self.inv_res
+        ex = np.rint((ct * k) * Q16).astype(np.int64)
+        ey = np.rint((st * k) * Q16).astype(np.int64)
+        x0 = np.rint(((x - self.org_x) * self.inv_res) * Q16).astype(np.int64)
+        y0 = np.rint(((y - self.org_y) * self.inv_res) * Q16).astype(np.int64)
+        hit = np.zeros(len(x0), bool)
+        for i, j in FOOT_LATTICE:
+            px = x0 + (i - 2) * ex - (j - 3) * ey
+            py = y0 + (i - 2) * ey + (j - 3) * ex
+            hit |= self._lookup(self.occ, (px >> 16).astype(i32), (py >> 16).astype(i32), True)
+        return hit
+
+    def spawn_usable(self):
+        """bool [n_centerline]: the centre-line pose of bin i touches no wall (the footprint test of H5 on the table's own
+        pose).  On hand-drawn maps with boxes on the track or one-cell corridors the most central cell of a BFS distance bin can
+        lie where a car does not fit; such a bin is never a start (`spawn_rows`)."""
+        if getattr(self, "_spawn_usable", None) is None:
+            sn, cs = sincos32(self.centerline[:, 2])
+            self._spawn_usable = ~self._wall_hit_poses(self.centerline[:, 0], self.centerline[:, 1], cs, sn)
+        return self._spawn_usable
+
+    def spawn_heading_room(self):
+        """float32 [n_centerline]: how far a start at bin i may turn off the track's direction.  HEADING_JITTER where the bin has
+        lateral room (spawn_width > 0: the margin argument holds for every heading); where it has none, HEADING_ROOM[k] with
+        k = the smallest footprint-point clearance of the centre-line pose in cells (integers, see HEADING_ROOM)."""
+        if getattr(self, "_spawn_h", None) is not None:
+            return self._spawn_h
+        R = SPAWN_FOOT_R
+        n = len(self.centerline)
+        sn, cs = sincos32(self.centerline[:, 2])
+        k = FOOT_STEP * self.inv_res
+        ex = np.rint((cs * k) * Q16).astype(np.int64)
+        ey = np.rint((sn * k) * Q16).astype(np.int64)
+        x0 = np.rint(((self.centerline[:, 0] - self.org_x) * self.inv_res) * Q16).astype(np.int64)
+        y0 = np.rint(((self.centerline[:, 1] - self.org_y) * self.inv_res) * Q16).astype(np.int64)
+        blocked = np.pad(~self.drv, R + 1, constant_values=True)
+        off = np.arange(-R, R + 1)
+        dist2 = (off[:, None] ** 2 + off[None, :] ** 2).astype(np.int64)[None]
+        big = (R + 1) ** 2
+        kmin = np.full(n, R, np.int64)
+        for i, j in FOOT_LATTICE:
+            ix = ((x0 + (i - 2) * ex - (j - 3) * ey) >> 16)
+            iy = ((y0 + (i - 2) * ey + (j - 3) * ex) >> 16)
+            inside = (ix >= 0) & (ix < self.W) & (iy >= 0) & (iy < self.H)
+            jx, jy = np.clip(ix, 0, self.W - 1), np.clip(iy, 0, self.H - 1)
+            win = blocked[(jy + 1)[:, None, None] + np.arange(2 * R + 1)[None, :, None], (jx + 1)[:, None, None] + np.arange(2 * R + 1)[None, None, :]]
+            d2 = np.where(win, dist2, big).reshape(n, -1).min(1)
+            d2 = np.where(inside, d2, 0)
+            kk = np.floor(np.sqrt(d2.astype(np.float64))).astype(np.int64)
+            kk = np.where((kk + 1) ** 2 <= d2, kk + 1, np.where(kk * kk > d2, kk - 1, kk))       # exact integer square root
+            kmin = np.minimum(kmin, kk)
+        h = np.where(self.spawn_width() > f32(0.0), HEADING_JITTER, HEADING_ROOM[np.clip(kmin, 0, R)])
+        self._spawn_h = h.astype(f32)
+        return self._spawn_h
+
+    def spawn_rows(self):
+        """The spawn table: (x, y, theta, lateral room w, heading room h) float32 [n_centerline] each.  Row i is bin u(i) = the
+        first USABLE bin among i, i + 1, ..., i + SPAWN_SAFE_SEARCH - 1 around the lap (i itself if there is none): a start drawn
+        at a bin whose centre-line pose touches a wall goes to the next bin where a car fits.  On every track a scenario of the
+        reference names u(i) = i."""
+        if getattr(self, "_spawn_rows", None) is not None:
+            return self._spawn_rows
+        n = len(self.centerline)
+        usable = self.spawn_usable()
+        i = np.arange(n)
+        u, found = i.copy(), usable.copy()
+        for k in range(1, min(SPAWN_SAFE_SEARCH, n)):
+            j = (i + k) % n
+            take = ~found & usable[j]
+            u[take] = j[take]
+            found |= take
+        self._spawn_u = u
+        self._spawn_rows = (self.centerline[u, 0], self.centerline[u, 1], self.centerline[u, 2], self.spawn_width()[u],
+                            self.spawn_heading_room()[u])
+        return self._spawn_rows
+
     def spawn_safe(self):
-        """int64 [n_centerline]: where a multi-car start drawn at bin i really goes.  Bin j is SOUND if the centre-line poses of
-        RC_MAX_CARS = 4 cars at bins j, j - 12, j - 24, j - 36 do not overlap pairwise (the rectangle test of H5 on the table's
+        """int64 [n_centerline]: where a multi-car start drawn at bin i really goes.  Bin j is SOUND if bins j, j - 12, j - 24,
+        j - 36 are all usable (`spawn_usable`) and the centre-line poses of RC_MAX_CARS = 4 cars there do not overlap pairwise
+        (the rectangle test of H5 on the table's
         own poses); safe[i] = the first sound bin among i, i + 1, ..., i + SPAWN_SAFE_SEARCH - 1 (around the lap), i itself if
         there is none.  A centre line is the most central cell per BFS distance bin, and where the BFS wavefronts of the
         progress grid fold - the raw columbia.pgm's (track `columbia_slam`) last bins run back along the bins before them, the start pixel lying in an open area
@@ -466,6 +552,9 @@ class OracleRaceEnv:
         sn, cs = sincos32(self.centerline[:, 2])
         i = np.arange(n)
         sound = np.ones(n, bool)
+        usable = self.spawn_usable()
+        for a in range(MAX_CARS):
+            sound &= usable[(i - a * BALL_GAP_BINS) % n]
         for a in range(MAX_CARS):
             for b in range(a + 1, MAX_CARS):
                 ia, ib = (i - a * BALL_GAP_BINS) % n, (i - b * BALL_GAP_BINS) % n
@@ -502,8 +591,9 @@ class OracleRaceEnv:
     def _reset_envs(self, envs):
         """Reset law (H6).  `grid`: the cars on the centre line behind the start, BALL_GAP_BINS apart.  `random` (one car) and
         `random_ball` (several): one Philox draw per env picks a centre-line bin uniformly over the lap; car a stands at bin
-        idx0 - a * BALL_GAP_BINS, moved SIDEWAYS by u * w (u uniform in [-1, 1), w = that bin's spawn_width: the clearance the
-        track leaves there) and turned by v * HEADING_JITTER off the track's direction (v uniform in [-1, 1)) - "a random pose
+        idx0 - a * BALL_GAP_BINS (row idx of the spawn table: `spawn_rows`), moved SIDEWAYS by u * w (u uniform in [-1, 1), w = that
+        row's lateral room: the clearance the track leaves there) and turned by v * h off the track's direction (v uniform in
+        [-1, 1), h = the row's heading room: HEADING_JITTER wherever there is lateral room) - "a random pose
         on the track with a minimum wall distance, heading along the track" (SURVEY.md H6 and appendix A); the cars of an env
         lie within a ball of 1.2 (A - 1) m + the track's width around the drawn point ("sample in random points close within
         a ball", dreamer/dream.py:105-108).  Should two of the proposed cars overlap (rectangle test of H5), ALL cars of that
@@ -524,14 +614,14 @@ class OracleRaceEnv:
             idx0 = np.full(envs.size, BALL_GAP_BINS * (self.A - 1) + GRID_LEAD_BINS, np.int64)
         else:
             idx0 = ((r0.astype(u64) * u64(n_cl)) >> u64(32)).astype(np.int64)
-            if self.A > 1:
-                idx0 = self.spawn_safe()[idx0]          # never anchor several cars where the centre line folds: spawn_safe
+        if self.A > 1:
+            idx0 = self.spawn_safe()[idx0]              # never anchor several cars where the centre line folds: spawn_safe (the grid too)
         unit = lambda w: (w >> u32(8)).astype(f32) * f32(5.9604644775390625e-8) * f32(2.0) - f32(1.0)     # [-1, 1), exact
-        width = self.spawn_width()
+        row_x, row_y, row_th, width, heading = self.spawn_rows()
         centre, proposed = [], []
         for a in range(self.A):
             idx = (idx0 - a * BALL_GAP_BINS) % n_cl
-            cx, cy, th = self.centerline[idx, 0], self.centerline[idx, 1], self.centerline[idx, 2]
+            cx, cy, th = row_x[idx], row_y[idx], row_th[idx]
             st0, ct0 = sincos32(th)
             centre.append((cx, cy, th, st0, ct0))
             if not jitter:
@@ -542,7 +632,7 @@ class OracleRaceEnv:
             off = unit(wu) * width[idx]
             x = cx - off * st0
             y = cy + off * ct0
-            th2 = th + unit(wv) * HEADING_JITTER
+            th2 = th + unit(wv) * heading[idx]
             th2 = np.where(th2 > PI, th2 - TWO_PI, th2)
             th2 = np.where(th2 < -PI, th2 + TWO_PI, th2)
             st2, ct2 = sincos32(th2)
@@ -717,8 +807,21 @@ class OracleRaceEnv:
     # ------------------------------------------------------------------ observations
     def _observe(self):
         self.lidar = self.raycast()
-        if self.cfg.render_occupancy:
+        if self.cfg.render_occupancy == "reference":
+            self.patch = self.render_patch_exact()
+        elif self.cfg.render_occupancy:
             self.patch = self.render_patch()
+
+    def render_patch_exact(self):
+        """obs_type `lidar_occupancy_reference`: the reference's own crop -> spline rotation -> bicubic resize restated to the
+        binary64 operation (oracle/patch_reference.py, the spec; dreamer/wrappers.py:396-406); zeros on the first observation
+        of an episode (:413).  Needs `self.frame_track` = the Track (its crop of the source image places the north-up pixel
+        frame the reference indexes)."""
+        from . import patch_reference as px
+        poses = np.stack([self.x, self.y, self.theta], 1).astype(np.float64)
+        out = px.render_patch_exact(self.frame_track, poses)
+        out[self.fresh != 0] = 0
+        return out
 
     def raycast(self, chunk_cars=2048):
         out = np.empty((self.NC, N_BEAMS), f32)

@@ -287,14 +287,15 @@ class LineGuard:
         want = self.timeout if want_s is None else float(want_s)
         return max(min(want, self.time_left() - self.RESERVE_S), 1.0)
 
-    def go(self, name, need_s, kind=None):
-        """Is there time for leg `name`, which needs about `need_s` seconds (or 1.3 x the longest leg of the same `kind` so
-        far, if that is more)?  The same answer on every rank."""
+    def go(self, name, need_s, kind=None, weight=1.0):
+        """Is there time for leg `name`, which needs about `need_s` seconds - or, if that is more, 1.3 x what the legs of the same
+        `kind` so far took per unit of `weight` (for the payload legs: bytes per step x steps, so a record twice as large is
+        expected to take twice as long), times this leg's weight?  The same answer on every rank."""
         i, self._go_no = self._go_no, self._go_no + 1
         if kind is not None:
-            seen = [v for k, v in self.leg_seconds.items() if k.startswith(kind + ":")]
+            seen = [sec / w for k, (sec, w) in self.leg_seconds.items() if k.startswith(kind + ":")]
             if seen:
-                need_s = max(need_s, 1.3 * max(seen))
+                need_s = max(need_s, 1.3 * max(seen) * weight)
         key = f"rc_bench_go_{i}"
         if self.world > 1 and self.store is not None and self.rank != 0:
             try:
@@ -367,7 +368,7 @@ class LineGuard:
 
     # ------------------------------------------------------------------ legs
     @contextlib.contextmanager
-    def leg(self, name, budget_s=None, kind=None):
+    def leg(self, name, budget_s=None, kind=None, weight=1.0):
         self._leg_budget = self.budget(budget_s)
         self.leg_name, self.deadline = name, (time.monotonic() + self._leg_budget if self.armed else None)
         t_in = time.monotonic()
@@ -379,7 +380,7 @@ class LineGuard:
             if hang[0] == name and (len(hang) < 2 or int(hang[1]) == self.rank):
                 time.sleep(1e6)
             yield
-            self.leg_seconds[(kind + ":" if kind else "") + name] = time.monotonic() - t_in
+            self.leg_seconds[(kind + ":" if kind else "") + name] = (time.monotonic() - t_in, float(weight))
         except Exception as exc:                           # noqa: BLE001 - every failure of a guarded leg is data
             msg = f"{type(exc).__name__}: {exc}"
             self.errors[name] = msg

@@ -111,29 +111,58 @@ __device__ __forceinline__ int obb_overlap(const Car &a, const Car &b) {
 // nearly every wave of a random-action rollout).  `apply_reset` installs the prepared poses when the env did finish.
 struct Spawn { float x, y, th, ct, st, pr; int cp; };
 
-// The spawn table (RcTrackDev::spawn): per centerline index the pose, sin / cos of its heading (the spec's sincos32),
-// the progress value of its cell, its checkpoint (+ the anchor bin of a multi-car start, see below) and the lateral room a random start has there - computed once per track ON
-// THE DEVICE with the very functions a reset would call, so the centre-line part of a reset is one 32-byte gather with no
-// arithmetic behind it.  Lateral room (oracle: spawn_width): d2 = squared cell distance from the point's cell to the nearest
-// cell that is not drivable (outside the grid included) in the window of +- RCS_SPAWN_CLEAR_R cells, at most (R + 1)^2;
+// The spawn table (RcTrackDev::spawn): per row the pose, sin / cos of its heading (the spec's sincos32), the progress value of
+// its cell, its checkpoint (+ the anchor bin of a multi-car start, see below), and the room a random start has there - computed
+// once per track ON THE DEVICE with the very functions a reset would call, so the centre-line part of a reset is one 32-byte
+// gather with no arithmetic behind it.
+//   Row i is centre-line bin u(i) = the first USABLE bin among i, i + 1, ... (around the lap, RCS_SPAWN_SAFE_SEARCH of them; i if
+// none): usable = the footprint test of H5 on the bin's own pose finds no wall (oracle: spawn_usable, spawn_rows).  On hand-drawn
+// maps with boxes on the track the most central cell of a BFS distance bin can lie where a car does not fit; no start goes there.
+//   Lateral room (oracle: spawn_width): d2 = squared cell distance from the point's cell to the nearest cell that is not drivable
+// (outside the grid included) in the window of +- RCS_SPAWN_CLEAR_R cells, at most (R + 1)^2;
 // w = clamp(isqrt(d2) * res - RCS_SPAWN_MARGIN, 0, RCS_SPAWN_W_MAX) - integers up to the last two operations.
+//   Heading room (oracle: spawn_heading_room): RCS_HEADING_JITTER where w > 0 (the margin holds for every heading); where w = 0,
+// HEADING_ROOM[k], k = the smallest over the 34 footprint points of isqrt(squared cell distance to the nearest non-drivable cell
+// within +- RCS_SPAWN_FOOT_R), capped at 5.  The row's last word holds w if w > 0, else - (heading room): one float, no bit fields.
+__device__ __forceinline__ void foot_cell(const RcTrackDev &t, float x, float y, float ct, float st, int li, int lj, int &ix, int &iy) {
+    const float k = RCS_FOOT_STEP * t.inv_res;
+    const float gx = (x - t.org_x) * t.inv_res, gy = (y - t.org_y) * t.inv_res;
+    const int ex = (int)__builtin_rintf((ct * k) * 65536.0f), ey = (int)__builtin_rintf((st * k) * 65536.0f);
+    const int x0 = (int)__builtin_rintf(gx * 65536.0f), y0 = (int)__builtin_rintf(gy * 65536.0f);
+    ix = (x0 + (li - 2) * ex - (lj - 3) * ey) >> 16;
+    iy = (y0 + (li - 2) * ey + (lj - 3) * ex) >> 16;
+}
+
+template <typename F>
+__device__ __forceinline__ void for_each_foot_point(F &&f) {
+    for (int i = 0; i < 12; ++i) { f(i, 0); f(i, 6); }
+    for (int j = 1; j < 6; ++j) { f(0, j); f(11, j); }
+}
+
+__device__ __noinline__ bool bin_usable(const RcTrackDev &t, int i) {
+    Car c;
+    c.x = t.centerline[4 * i]; c.y = t.centerline[4 * i + 1];
+    sincos32(t.centerline[4 * i + 2], c.st, c.ct);
+    return wall_hit(t, c) == 0;
+}
+
 __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float4 *__restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= t.n_centerline) return;
-    const float x = t.centerline[4 * i], y = t.centerline[4 * i + 1], th = t.centerline[4 * i + 2];
+    const int n = t.n_centerline;
+    if (i >= n) return;
+    int u = i;
+    for (int s = 0; s < RCS_SPAWN_SAFE_SEARCH && s < n; ++s)
+        if (bin_usable(t, (i + s) % n)) { u = (i + s) % n; break; }
+    const float x = t.centerline[4 * u], y = t.centerline[4 * u + 1], th = t.centerline[4 * u + 2];
     float sn, cs;
     sincos32(th, sn, cs);
     float pr = progress_at(t, x, y);
     pr = pr < 0.0f ? 0.0f : pr;
     int cp = (int)(pr * (float)RCS_N_CHECKPOINTS);
     cp = cp < RCS_N_CHECKPOINTS - 1 ? cp : RCS_N_CHECKPOINTS - 1;
-    int ix, iy;
-    cell_of(t, x, y, ix, iy);
-    const int R = RCS_SPAWN_CLEAR_R;
-    int d2 = (R + 1) * (R + 1);
-    if (!((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)) {
-        d2 = 0;
-    } else {
+    auto clearance2 = [&](int ix, int iy, int R) {           // squared cell distance to the nearest non-drivable cell within +- R
+        int d2 = (R + 1) * (R + 1);
+        if (!((unsigned)ix < (unsigned)t.w && (unsigned)iy < (unsigned)t.h)) return 0;
         for (int dy = -R; dy <= R; ++dy)
             for (int dx = -R; dx <= R; ++dx) {
                 const int jx = ix + dx, jy = iy + dy;
@@ -142,27 +171,41 @@ __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float
                 const int q = dx * dx + dy * dy;
                 d2 = (blocked && q < d2) ? q : d2;
             }
+        return d2;
+    };
+    auto isqrt = [](int d2) { int k = 0; while ((k + 1) * (k + 1) <= d2) ++k; return k; };
+    int ix, iy;
+    cell_of(t, x, y, ix, iy);
+    const float w = clampf((float)isqrt(clearance2(ix, iy, RCS_SPAWN_CLEAR_R)) * t.res - RCS_SPAWN_MARGIN, 0.0f, RCS_SPAWN_W_MAX);
+    float room = w;
+    if (!(w > 0.0f)) {
+        int kmin = RCS_SPAWN_FOOT_R;
+        for_each_foot_point([&](int li, int lj) {
+            int px, py;
+            foot_cell(t, x, y, cs, sn, li, lj, px, py);
+            const int k = isqrt(clearance2(px, py, RCS_SPAWN_FOOT_R));
+            kmin = k < kmin ? k : kmin;
+        });
+        const float rooms[6] = RCS_HEADING_ROOM_INIT;
+        room = -rooms[kmin];
     }
-    int k = 0;
-    while ((k + 1) * (k + 1) <= d2) ++k;
-    const float w = clampf((float)k * t.res - RCS_SPAWN_MARGIN, 0.0f, RCS_SPAWN_W_MAX);
     // Where a multi-car start drawn at this bin really goes (oracle: spawn_safe): the first bin j among i, i + 1, ... (around the
-    // lap, RCS_SPAWN_SAFE_SEARCH of them) at which the centre-line poses of RC_MAX_CARS cars RCS_BALL_GAP_BINS apart do not
-    // overlap pairwise; i itself if there is none.  Where the progress grid's wavefronts fold (columbia_slam's last bins run back
-    // along the bins before them) bins 1.2 m apart along the table are centimetres apart on the ground.
-    const int n = t.n_centerline;
+    // lap, RCS_SPAWN_SAFE_SEARCH of them) at which the centre-line poses of RC_MAX_CARS cars RCS_BALL_GAP_BINS apart touch no wall
+    // and do not overlap pairwise; i itself if there is none.  Where the progress grid's wavefronts fold (columbia_slam's last bins
+    // run back along the bins before them) bins 1.2 m apart along the table are centimetres apart on the ground.
     int safe = i;
     for (int s = 0; s < RCS_SPAWN_SAFE_SEARCH && s < n; ++s) {
         const int j = (i + s) % n;
         Car c[4];
+        int clash = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             int idx = (j - a * RCS_BALL_GAP_BINS) % n;
             if (idx < 0) idx += n;
             c[a].x = t.centerline[4 * idx]; c[a].y = t.centerline[4 * idx + 1];
             sincos32(t.centerline[4 * idx + 2], c[a].st, c[a].ct);
+            clash |= bin_usable(t, idx) ? 0 : 1;
         }
-        int clash = 0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -170,7 +213,7 @@ __global__ __launch_bounds__(256) void rc_build_spawn_kernel(RcTrackDev t, float
         if (!clash) { safe = j; break; }
     }
     out[2 * i] = make_float4(x, y, th, cs);
-    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp | (safe << 8)), w);      // checkpoint < 256; the bin above it
+    out[2 * i + 1] = make_float4(sn, pr, __int_as_float(cp | (safe << 8)), room);      // checkpoint < 256; the bin above it
 }
 
 __device__ __forceinline__ float unit_pm1(uint32_t w) { return ((float)(w >> 8) * 5.9604644775390625e-8f) * 2.0f - 1.0f; }   // [-1, 1), exact
@@ -184,8 +227,8 @@ __device__ __forceinline__ int obb_overlap_spawn(const Spawn &a, const Spawn &b)
 
 // The reset law (H6; oracle: _reset_envs).  `grid`: the cars on the centre line behind the start.  `random` / `random_ball`:
 // word 0 of Philox(global env id, episode, 0, 0) picks a centre-line bin uniformly over the lap; car a stands at bin
-// idx0 - a * BALL_GAP, moved sideways by u * w (w: the bin's lateral room) and turned by v * RCS_HEADING_JITTER off the
-// track's direction; (u, v) = words 1, 2 of call 0 for car 0, words (0, 1) / (2, 3) of call 1 + (a - 1) / 2 for the others.
+// idx0 - a * BALL_GAP (row of the spawn table), moved sideways by u * w (w: the row's lateral room) and turned by v * h (h: its
+// heading room, RCS_HEADING_JITTER wherever w > 0) off the track's direction; (u, v) = words 1, 2 of call 0 for car 0, words (0, 1) / (2, 3) of call 1 + (a - 1) / 2 for the others.
 // If two proposed cars overlap, ALL cars of the env take the centre-line poses.
 template <int A>
 __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t ep, Spawn (&sp)[A]) {
@@ -200,7 +243,7 @@ __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t
     }
     const int n = t.n_centerline;
     int idx0 = !jitter ? RCS_BALL_GAP_BINS * (A - 1) + RCS_GRID_LEAD_BINS : (int)__umulhi(r[0].x, (uint32_t)n);
-    if (A > 1 && jitter) idx0 = __float_as_int(t.spawn[2 * idx0 + 1].z) >> 8;      // never anchor several cars where the centre line folds
+    if (A > 1) idx0 = __float_as_int(t.spawn[2 * idx0 + 1].z) >> 8;      // never anchor several cars where the centre line folds (the grid too)
     Spawn centre[A];
 #pragma unroll
     for (int a = 0; a < A; ++a) {
@@ -215,11 +258,12 @@ __device__ __forceinline__ void prepare_reset(const RcParams &p, int e, uint32_t
             const rcd::u32x4 &q = r[a == 0 ? 0 : 1 + (a - 1) / 2];
             const uint32_t wu = a == 0 ? q.y : (((a - 1) & 1) ? q.z : q.x);
             const uint32_t wv = a == 0 ? q.z : (((a - 1) & 1) ? q.w : q.y);
-            const float off = unit_pm1(wu) * s1.w;
+            const float room = s1.w;                     // w > 0: lateral room, any heading; else - (heading room), no lateral room
+            const float off = unit_pm1(wu) * fmaxf(room, 0.0f);
             Spawn &j = sp[a];
             j.x = c.x - off * c.st;
             j.y = c.y + off * c.ct;
-            float th = c.th + unit_pm1(wv) * RCS_HEADING_JITTER;
+            float th = c.th + unit_pm1(wv) * (room > 0.0f ? RCS_HEADING_JITTER : -room);
             th = th > RCS_PI ? th - RCS_TWO_PI : th;
             th = th < -RCS_PI ? th + RCS_TWO_PI : th;
             j.th = th;

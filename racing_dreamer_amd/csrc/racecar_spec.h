@@ -28,7 +28,9 @@
 #define RCS_SPAWN_CLEAR_R 40      // random starts: cells searched around a centre-line point for the nearest non-drivable cell
 #define RCS_SPAWN_MARGIN 0.60f    // [m] the footprint's farthest corner (0.474) + the two half cell diagonals (0.071)
 #define RCS_SPAWN_W_MAX 1.5f      // [m] cap of the lateral offset
-#define RCS_HEADING_JITTER 0.35f  // [rad] heading within +- this of the track's direction
+#define RCS_HEADING_JITTER 0.35f  // [rad] heading within +- this of the track's direction - where the track leaves lateral room;
+#define RCS_SPAWN_FOOT_R 5        // where it leaves none: by the footprint's own clearance k = 0 .. 5 cells (oracle: HEADING_ROOM)
+#define RCS_HEADING_ROOM_INIT {0.0f, 0.0f, 0.05f, 0.155f, 0.26f, 0.35f}
 #define RCS_SPAWN_SAFE_SEARCH 256 // several cars: bins searched forward for a start whose four centre-line poses do not overlap
 #define RCS_N_FOOTPRINT 34
 #define RCS_FOOT_STEP 0.05f      // pitch of the footprint lattice [m] (12 x 7 nodes, rear axle at node (2, 3))

@@ -67,6 +67,10 @@ SPAWN_CLEAR_R = 40            # cells searched for the nearest non-drivable cell
 SPAWN_MARGIN = 0.60           # [m] footprint's farthest corner 0.474 + two half cell diagonals 0.071  (derived)
 SPAWN_W_MAX = 1.5             # [m] cap of the lateral offset                                   (free)
 HEADING_JITTER = 0.35         # [rad]                                                           (free)
+# where a bin leaves no lateral room the heading turns only as far as the footprint's own clearance k (cells, 0 .. 5) allows:
+# a point <= 0.474 m from the rear axle moves <= 0.474 |dtheta|; k cells between centres leave 0.05 k - 0.0707 m  (derived)
+SPAWN_FOOT_R = 5
+HEADING_ROOM = (0.0, 0.0, 0.05, 0.155, 0.26, 0.35)
 SPAWN_SAFE_SEARCH = 256       # bins searched forward for a start at which four cars 1.2 m apart do not overlap   (free)
 
 # --- action remap (dreamer/dream.py:138) ---------------------------------------------

@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: GPU tests that take tens of seconds each (the NumPy oracle beside large batches, soaks): "
+                                        "NOT part of `-m gpu`, which has to fit the driver's step limit; run them with `-m gpu_slow` on the GPU box")
+
+
+def pytest_collection_modifyitems(config, items):
+    """`gpu_slow` tests are GPU tests too (they carry `gpu` as well), but `-m gpu` - the driver's run, which has a step limit -
+    SKIPS them: they run only when the marker expression names them (`-m gpu_slow`)."""
+    asked = "gpu_slow" in (config.getoption("-m") or "")
+    skip = pytest.mark.skip(reason="gpu_slow: run with `pytest -m gpu_slow` on the GPU box")
+    for item in items:
+        if "gpu_slow" in item.keywords and not asked:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -10,8 +10,10 @@ TOL = 1e-5   # BASELINE.json north_star: within 1e-5 fp32 on pose and LiDAR rang
 
 
 def make_oracle(track, **kw):
-    return ro.OracleRaceEnv(track.occ, track.drivable, track.progress, track.centerline, track.origin,
-                            track.resolution, ro.OracleConfig(**kw))
+    env = ro.OracleRaceEnv(track.occ, track.drivable, track.progress, track.centerline, track.origin,
+                           track.resolution, ro.OracleConfig(**kw))
+    env.frame_track = track            # (render_occupancy='reference' indexes the source image's pixel frame)
+    return env
 
 
 def compare_outputs(dev_views, ora_out, n_envs, n_cars_per_env, context=""):

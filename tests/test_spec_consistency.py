@@ -45,6 +45,15 @@ def test_constants_agree():
     assert spec.BALL_GAP_BINS == ro.BALL_GAP_BINS == int(c["BALL_GAP"]) == int(dev["BALL_GAP_BINS"])
     assert spec.GRID_LEAD_BINS == ro.GRID_LEAD_BINS == int(c["GRID_LEAD"]) == int(dev["GRID_LEAD_BINS"])
     assert spec.SPAWN_CLEAR_R == ro.SPAWN_CLEAR_R == int(c["SPAWN_CLEAR_R"]) == int(dev["SPAWN_CLEAR_R"])
+    # the heading room of a bin without lateral room: the same six levels everywhere, each inside what the geometry allows
+    src = open(os.path.join(ROOT, "racing_dreamer_amd", "csrc", "racecar_spec.h")).read()
+    dev_rooms = [float(v.rstrip("f")) for v in re.search(r"#define RCS_HEADING_ROOM_INIT \{([^}]*)\}", src).group(1).split(",")]
+    c_rooms = [float(v.rstrip("f")) for v in re.search(r"HEADING_ROOM\[6\] = \{([^}]*)\}", open(os.path.join(ROOT, "oracle", "racecar_oracle.c")).read()).group(1).split(",")]
+    assert [f(v) for v in spec.HEADING_ROOM] == [f(v) for v in dev_rooms] == [f(v) for v in c_rooms] == list(ro.HEADING_ROOM)
+    assert spec.SPAWN_FOOT_R == ro.SPAWN_FOOT_R == int(c["SPAWN_FOOT_R"]) == int(dev["SPAWN_FOOT_R"]) == len(spec.HEADING_ROOM) - 1
+    reach = np.hypot(spec.X_FRONT, spec.HALF_W)
+    for k, room in enumerate(spec.HEADING_ROOM):
+        assert room <= spec.HEADING_JITTER and room * reach <= max(0.05 * k - 2 * 0.05 * np.sqrt(0.5) - 0.004, 0.0) + 1e-9, (k, room)
     # the margin covers the footprint's farthest corner from the rear axle plus what a cell-centre distance cannot see
     assert spec.SPAWN_MARGIN >= np.hypot(spec.X_FRONT, spec.HALF_W) + 2 * 0.05 * np.sqrt(0.5) + 0.05
     assert spec.N_BEAMS == ro.N_BEAMS == 1080 and spec.N_FOOTPRINT == int(dev["N_FOOTPRINT"]) == 34
