@@ -48,7 +48,8 @@
 extern "C" {
 #endif
 
-#define RC_ABI_VERSION 2      /* 2 (round 4): rc_build_id, reset laws of SURVEY H6, outbound ordering of the peer-copy gather */
+#define RC_ABI_VERSION 3      /* 3 (round 6): RC_OBS_LIDAR_OCCUPANCY_REFERENCE + rc_set_source_frame; starts never touch a wall on narrow maps
+                               * 2 (round 4): rc_build_id, reset laws of SURVEY H6, outbound ordering of the peer-copy gather */
 #define RC_N_BEAMS 1080
 #define RC_PATCH 64
 #define RC_MAX_CARS 4
@@ -70,7 +71,12 @@ enum { RC_TASK_MAX_PROGRESS = 0, RC_TASK_MAX_SPEED = 1,             /* scenario 
                                           100 x total progress gained over the last n_steps sub-steps; never done */
 #define RC_NSTEP_MAX 16
 enum { RC_RESET_GRID = 0, RC_RESET_RANDOM = 1, RC_RESET_RANDOM_BALL = 2 };  /* dream.py:105-108,120 */
-enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1 };              /* dream.py obs_type */
+enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1,                  /* dream.py obs_type */
+       RC_OBS_LIDAR_OCCUPANCY_REFERENCE = 2 };   /* lidar_occupancy computed EXACTLY as the reference's OccupancyMapObs.step does
+                                                  * (dreamer/wrappers.py:396-406: to_pixel, 220 x 220 crop, cubic-spline rotation,
+                                                  * centre crop, antialiased bicubic resize) instead of by the one-tap sampler of
+                                                  * RC_OBS_LIDAR_OCCUPANCY: bit-identical to the reference's patches, ~100 x the cost;
+                                                  * needs rc_set_source_frame */
 /* what RC_F_LIDAR holds: metres, or the caller-side scaling fused into the scan's store */
 enum { RC_LIDAR_METRES = 0,
        RC_LIDAR_DREAMER = 1,      /* range / 15 - 0.5              tools.preprocess, dreamer/tools.py:274          */
@@ -163,6 +169,16 @@ int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivab
                   const float *progress, int32_t h, int32_t w, int32_t pitch,
                   float resolution, float origin_x, float origin_y,
                   const float *centerline, int32_t n_centerline);
+
+/*
+ * Where the track's grid lies in the source image it was cropped from - what the reference's GridMap.to_pixel indexes
+ * (dreamer/wrappers.py:396: row = int(H - (y - oy) / res), col = int((x - ox) / res), north-up, the whole image).  Needed by
+ * RC_OBS_LIDAR_OCCUPANCY_REFERENCE only, before the first reset: full_height = H; a north-up pixel (R, C) of the image is cell
+ * (gx, gy) = (C - col0, row_top - R) of the grid rc_load_track was given; (origin_x, origin_y) = world position of the image's
+ * lower left corner; resolution in metres per cell - all three as binary64, as the reference computes with them.
+ */
+int rc_set_source_frame(rc_env *env, int32_t full_height, int32_t row_top, int32_t col0, double origin_x, double origin_y,
+                        double resolution);
 
 /* Reset the envs selected by the host mask (uint8 [num_envs], NULL = all) and produce their
  * first observation. */

@@ -12,7 +12,7 @@ import os
 LIB_DIR = os.path.join(os.path.dirname(__file__), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libracecar_hip.so")
 
-RC_ABI_VERSION = 2          # include/racecar_hip.h
+RC_ABI_VERSION = 3          # include/racecar_hip.h
 RC_N_BEAMS = 1080
 RC_PATCH = 64
 RC_MAX_CARS = 4
@@ -61,6 +61,7 @@ SYMBOLS = {
     "rc_destroy": (None, [C.c_void_p]),
     "rc_load_track": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int32]),
+    "rc_set_source_frame": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "rc_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64]),
     "rc_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "rc_step_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),

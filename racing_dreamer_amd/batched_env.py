@@ -50,7 +50,9 @@ _FIELD_VIEWS = {
     "action_in": (L.F_ACTION_IN, torch.float32, (2,)),
 }
 
-OBS_TYPES = {"lidar": 0, "lidar_occupancy": 1}
+# lidar_occupancy_reference: the 64 x 64 patch computed EXACTLY as the reference's OccupancyMapObs.step does (dreamer/wrappers.py:
+# 396-406; spline rotation + antialiased bicubic resize restated to the binary64 operation) instead of by the one-tap sampler
+OBS_TYPES = {"lidar": 0, "lidar_occupancy": 1, "lidar_occupancy_reference": 2}
 # scaling fused into the scan's store: metres | dreamer (x/15 - 0.5, tools.py:274) | unit (x/15, single_agent.py:92-99)
 LIDAR_TRANSFORMS = {"metres": 0, "dreamer": 1, "unit": 2}
 TASKS = {"maximize_progress": spec.TASK_MAX_PROGRESS, "max_progress": spec.TASK_MAX_PROGRESS,
@@ -136,7 +138,7 @@ class BatchedRaceEnv:
         self._host_layout = {}
         base = self._arena_view.data_ptr()
         for name, (fid, dtype, tail) in _FIELD_VIEWS.items():
-            if fid == L.F_OCCUPANCY and obs_type != "lidar_occupancy":
+            if fid == L.F_OCCUPANCY and obs_type == "lidar":
                 continue
             ptr, nb = C.c_void_p(), C.c_size_t()
             L.check(self._lib.rc_get(self._h, fid, C.byref(ptr), C.byref(nb)))
@@ -167,6 +169,12 @@ class BatchedRaceEnv:
         L.check(self._lib.rc_load_track(
             self._h, occ.ctypes.data, drv.ctypes.data, prog.ctypes.data, t.height, t.width, t.pitch,
             np.float32(t.resolution), np.float32(t.origin[0]), np.float32(t.origin[1]), cl.ctypes.data, len(cl)))
+        if self.obs_type == "lidar_occupancy_reference":
+            # where the grid lies in the source image the reference's GridMap.to_pixel indexes (compat/racecar_gym/core/gridmaps.py)
+            r0, c0, fh, _fw = t.crop
+            res = float(t.resolution)
+            L.check(self._lib.rc_set_source_frame(self._h, int(fh), int(r0 + t.height - 1), int(c0), C.c_double(float(t.origin[0]) - c0 * res),
+                                                  C.c_double(float(t.origin[1]) - (fh - (r0 + t.height)) * res), C.c_double(res)))
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -11,7 +11,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libracecar_hip.so")
 SOURCES = ["racecar_kernels.hip", "racecar_abi.hip"]
-HEADERS = ["racecar_device.h", "racecar_internal.h", "racecar_spec.h", "racecar_scan.h", os.path.join("..", "..", "include", "racecar_hip.h")]
+HEADERS = ["racecar_device.h", "racecar_internal.h", "racecar_spec.h", "racecar_scan.h", "racecar_patch_exact.h", os.path.join("..", "..", "include", "racecar_hip.h")]
 # The lab library: scan variants 0-6 and the instrumented build of the scan (racecar_lab.hip).  NOT part of the shipped
 # library; built by build_lab() - which tools/ and the variant tests call - and loaded by libracecar_hip.so on first use.
 LAB_PATH = os.path.join(LIB_DIR, "libracecar_lab.so")

@@ -220,6 +220,12 @@ struct rc_env {
     hipEvent_t ev_ready = nullptr, ev_gathered = nullptr;
     bool gather_pending = false;
     P2p *p2p = nullptr;                // peer-copy all-gather (rc_p2p_setup), else null
+    // obs_type lidar_occupancy_reference (racecar_patch_exact.h): the source frame (rc_set_source_frame), the spline
+    // coefficients' scratch for one chunk of cars, Pillow's integer tables on the device
+    RcExactParams exact{};
+    bool has_frame = false;
+    int exact_chunk = 0;
+    void *exact_mem = nullptr;
     float *ftg_prev = nullptr;         // rc_follow_the_gap_reference: previous heading per car (NaN = none), allocated on first use
     void *order_mem = nullptr;         // RcStateDev::order + the sort's bucket counters (batches of RC_ORDER_MIN_CARS cars and more)
     uint32_t order_age = 0;            // observations since the cars were last sorted by track position
@@ -423,6 +429,20 @@ int sort_cars_if_due(rc_env *env) {
     return RC_OK;
 }
 
+// obs_type lidar_occupancy_reference: the reference's own render (racecar_patch_exact.h), a chunk of cars at a time
+int render_reference_patches(rc_env *env) {
+    if (!env->has_frame)
+        return fail(RC_ERR_INVALID, "obs_type lidar_occupancy_reference needs rc_set_source_frame (where the grid lies in its source "
+                                  "image) before the first observation");
+    RcExactParams &x = env->exact;
+    const RcParams &p = env->params;
+    x.drv_words = p.trk.drv_words; x.pitch = p.trk.pitch; x.h = p.trk.h; x.w = p.trk.w;
+    x.x = p.st.x; x.y = p.st.y; x.theta = p.st.theta; x.fresh = p.st.fresh;
+    x.patch = p.out.patch;                                   // (rc_set_arena may have moved the outputs)
+    TIMED(env, RC_K_PATCH, rck_launch_patch_exact(x, env->exact_chunk, env->stream));
+    return RC_OK;
+}
+
 int observe(rc_env *env) {
     int rc_sort = sort_cars_if_due(env);
     if (rc_sort) return rc_sort;
@@ -430,6 +450,10 @@ int observe(rc_env *env) {
     env->last_scan_rows = env->params.out.lidar;
     if (env->params.render_patch)
         TIMED(env, RC_K_PATCH, rck_launch_patch(env->params, env->launch, env->stream));
+    if (env->cfg.obs_type == RC_OBS_LIDAR_OCCUPANCY_REFERENCE) {
+        int rc_px = render_reference_patches(env);
+        if (rc_px) return rc_px;
+    }
     if (env->compact_slab)      // the scan has written the uint16 rows; the 76 B/car summary follows them
         HIP_TRY(hipMemcpyAsync((char *)env->compact_slab + env->compact.lidar_bytes,
                                (const char *)env->out_arena + env->compact.summary_src_off, env->compact.summary_bytes,
@@ -517,7 +541,7 @@ int check_cfg(const rc_config *cfg) {
     } else if (cfg->arena_first_car != 0) {
         return fail(RC_ERR_INVALID, "arena_first_car without arena_total_cars");
     }
-    if (cfg->obs_type != RC_OBS_LIDAR && cfg->obs_type != RC_OBS_LIDAR_OCCUPANCY)
+    if (cfg->obs_type != RC_OBS_LIDAR && cfg->obs_type != RC_OBS_LIDAR_OCCUPANCY && cfg->obs_type != RC_OBS_LIDAR_OCCUPANCY_REFERENCE)
         return fail(RC_ERR_INVALID, "unknown obs_type %d", cfg->obs_type);
     if (cfg->lidar_transform < RC_LIDAR_METRES || cfg->lidar_transform > RC_LIDAR_UNIT)
         return fail(RC_ERR_INVALID, "unknown lidar_transform %d", cfg->lidar_transform);
@@ -634,7 +658,7 @@ void rc_default_config(rc_config *cfg) {
 size_t rc_arena_bytes(const rc_config *cfg) {
     if (!cfg || cfg->num_envs < 1 || cfg->cars_per_env < 1) return 0;
     const int n = cfg->arena_total_cars > 0 ? cfg->arena_total_cars : cfg->num_envs * cfg->cars_per_env;
-    return make_layout(n, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY).total;
+    return make_layout(n, cfg->obs_type != RC_OBS_LIDAR).total;
 }
 
 int rc_field_layout(const rc_config *cfg, int32_t field, size_t *section_offset, size_t *bytes_per_car) {
@@ -642,7 +666,7 @@ int rc_field_layout(const rc_config *cfg, int32_t field, size_t *section_offset,
     if (field < 0 || field >= RC_F_COUNT) return fail(RC_ERR_INVALID, "unknown field %d", field);
     if (cfg->num_envs < 1 || cfg->cars_per_env < 1) return fail(RC_ERR_INVALID, "num_envs and cars_per_env must be >= 1");
     const int n = cfg->arena_total_cars > 0 ? cfg->arena_total_cars : cfg->num_envs * cfg->cars_per_env;
-    const Layout l = make_layout(n, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY);
+    const Layout l = make_layout(n, cfg->obs_type != RC_OBS_LIDAR);
     *section_offset = l.offset[field];
     *bytes_per_car = l.bytes[field] ? kFieldBytes[field] : 0;
     return RC_OK;
@@ -662,7 +686,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     if (!env) return fail(RC_ERR_NOMEM, "out of host memory");
     env->cfg = *cfg;
     const int n = env->n_cars = cfg->num_envs * cfg->cars_per_env;
-    const bool occ = cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY;
+    const bool occ = cfg->obs_type != RC_OBS_LIDAR;           // both renders fill the OCCUPANCY section
     env->shared_arena = cfg->arena_total_cars > 0 && cfg->arena_total_cars != n;
     env->layout = cfg->arena_total_cars > 0 ? make_layout(cfg->arena_total_cars, occ, cfg->arena_first_car, n) : make_layout(n, occ);
     env->compact = make_compact(env->layout, n);
@@ -739,7 +763,7 @@ int rc_create(const rc_config *cfg, rc_env **out) {
     p.remap_actions = cfg->remap_actions;
     p.time_limit_steps = cfg->time_limit_steps;
     p.auto_reset = cfg->auto_reset;
-    p.render_patch = occ ? 1 : 0;
+    p.render_patch = cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY ? 1 : 0;      // (the fast sampler's per-car header; the reference render reads the state itself)
     p.lidar_transform = cfg->lidar_transform;
     p.time_limit = cfg->time_limit;
     p.collision_reward = cfg->collision_reward;
@@ -771,6 +795,7 @@ void rc_destroy(rc_env *env) {
     if (env->own_arena && env->arena) (void)hipFree(env->arena);
     if (env->state_mem) (void)hipFree(env->state_mem);
     if (env->ftg_prev) (void)hipFree(env->ftg_prev);
+    if (env->exact_mem) (void)hipFree(env->exact_mem);
     if (env->order_mem) (void)hipFree(env->order_mem);
     if (env->group_dev) (void)hipFree(env->group_dev);
     if (env->group_host) (void)hipHostFree(env->group_host);
@@ -779,6 +804,65 @@ void rc_destroy(rc_env *env) {
     if (env->mask_dev) (void)hipFree(env->mask_dev);
     if (env->own_stream && env->stream) (void)hipStreamDestroy(env->stream);
     delete env;
+}
+
+namespace {
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc (src/libImaging/Resample.c) for 200 -> 64 pixels with the bicubic filter
+// (a = -0.5): oracle/patch_reference.py resize_coefficients, oracle/racecar_oracle.c oc_resize_coefficients - the same doubles.
+double px_bicubic(double x) {
+    const double a = -0.5;
+    if (x < 0.0) x = -x;
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+void px_resize_tables(int32_t *tab) {          // [64][15] coefficients, then [64][2] bounds
+    const int in = 200, out = 64, ksize = 15, bits = 22;
+    const double scale = (double)in / out, filterscale = scale, support = 2.0 * filterscale, ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out; ++xx) {
+        const double center = 0 + (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in) xmax = in;
+        xmax -= xmin;
+        double k[15], ww = 0.0;
+        for (int x = 0; x < xmax; ++x) { k[x] = px_bicubic((x + xmin - center + 0.5) * ss); ww += k[x]; }
+        for (int x = 0; x < ksize; ++x) {
+            double w = x < xmax ? k[x] : 0.0;
+            if (x < xmax && ww != 0.0) w /= ww;
+            tab[xx * ksize + x] = w < 0 ? (int32_t)(-0.5 + w * (1 << bits)) : (int32_t)(0.5 + w * (1 << bits));
+        }
+        tab[out * ksize + 2 * xx] = xmin;
+        tab[out * ksize + 2 * xx + 1] = xmax;
+    }
+}
+}  // namespace
+
+int rc_set_source_frame(rc_env *env, int32_t full_height, int32_t row_top, int32_t col0, double origin_x, double origin_y,
+                        double resolution) {
+    if (!env) return fail(RC_ERR_INVALID, "env is NULL");
+    if (env->cfg.obs_type != RC_OBS_LIDAR_OCCUPANCY_REFERENCE)
+        return fail(RC_ERR_INVALID, "rc_set_source_frame is for obs_type lidar_occupancy_reference (this handle: %d)", env->cfg.obs_type);
+    if (full_height < 1 || !(resolution > 0.0)) return fail(RC_ERR_INVALID, "bad source frame: height %d, resolution %g", full_height, resolution);
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    if (!env->exact_mem) {
+        // a chunk of cars in flight: 774 400 B of spline coefficients each; 2 048 cars (1.6 GB) keep 8 workgroups per CU busy
+        env->exact_chunk = env->n_cars < 2048 ? env->n_cars : 2048;
+        const size_t tab_bytes = (size_t)RC_EXACT_TABLE_INTS * 4, scratch = (size_t)env->exact_chunk * RC_EXACT_CAR_DOUBLES * 8;
+        HIP_TRY(hipMalloc(&env->exact_mem, scratch + align_up(tab_bytes, 64)));
+        int32_t tab[RC_EXACT_TABLE_INTS];
+        px_resize_tables(tab);
+        HIP_TRY(hipMemcpy((char *)env->exact_mem + scratch, tab, tab_bytes, hipMemcpyHostToDevice));
+        env->exact.scratch = (double *)env->exact_mem;
+        env->exact.kk = (const int32_t *)((char *)env->exact_mem + scratch);
+    }
+    RcExactParams &x = env->exact;
+    x.fh = full_height; x.r_top = row_top; x.c0 = col0;
+    x.ox = origin_x; x.oy = origin_y; x.res = resolution;
+    x.n_cars = env->n_cars; x.car0 = 0;
+    env->has_frame = true;
+    return RC_OK;
 }
 
 int rc_load_track(rc_env *env, const uint32_t *occ_words, const uint32_t *drivable_words, const float *progress,
@@ -1127,9 +1211,14 @@ static int group_step(rc_env **envs, int32_t n, const float *actions_dev, int32_
     g.wave_start[n] = waves;
     TIMED(lead, RC_K_RAYCAST, rck_launch_raycast_group(g, lead->cfg.cars_per_env, split, lead->stream));
     for (int b = 0; b < n; ++b) envs[b]->last_scan_rows = envs[b]->params.out.lidar;
-    for (int b = 0; b < n; ++b)
+    for (int b = 0; b < n; ++b) {
         if (envs[b]->params.render_patch)
             TIMED(envs[b], RC_K_PATCH, rck_launch_patch(envs[b]->params, envs[b]->launch, envs[b]->stream));
+        if (envs[b]->cfg.obs_type == RC_OBS_LIDAR_OCCUPANCY_REFERENCE) {
+            int rc_px = render_reference_patches(envs[b]);
+            if (rc_px) return rc_px;
+        }
+    }
     return RC_OK;
 }
 
@@ -1456,7 +1545,7 @@ int rc_copy_from_device(rc_env *env, const void *dev_src, void *host_dst, size_t
 size_t rc_compact_bytes(const rc_config *cfg) {
     if (!cfg || cfg->num_envs < 1 || cfg->cars_per_env < 1) return 0;
     const int n = cfg->num_envs * cfg->cars_per_env;
-    return make_compact(make_layout(n, cfg->obs_type == RC_OBS_LIDAR_OCCUPANCY), n).total;
+    return make_compact(make_layout(n, cfg->obs_type != RC_OBS_LIDAR), n).total;
 }
 
 int rc_set_compact_slab(rc_env *env, void *slab, size_t bytes) {

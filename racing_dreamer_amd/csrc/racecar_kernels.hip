@@ -21,6 +21,7 @@
 #include <string>
 
 #include "racecar_scan.h"      // the traversal and scan_car (shared with the lab library, racecar_lab.hip)
+#include "racecar_patch_exact.h"   // obs_type lidar_occupancy_reference
 
 #define RC_PATCH 64
 
@@ -1971,6 +1972,21 @@ hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream
     const int blocks = (int)(need < resident ? need : resident);
     if (li.patch_variant & 2) launch(rc_patch_car_kernel<false>, dim3(blocks), dim3(1024), lds, s, p, padded);     // experiment: plain stores
     else launch(rc_patch_car_kernel<true>, dim3(blocks), dim3(1024), lds, s, p, padded);
+    return hipGetLastError();
+}
+
+hipError_t rck_launch_patch_exact(const RcExactParams &p0, int chunk_cars, hipStream_t s) {
+    // a chunk of cars at a time: 774 KB of spline coefficients per car in flight (two kernels per chunk: the prefilter, then the
+    // rotation + resize); the launch timer spans the first launch's start to the last one's end
+    const hipEvent_t a = g_ev_start, b = g_ev_stop;
+    g_ev_start = g_ev_stop = nullptr;
+    RcExactParams p = p0;
+    for (int c0 = 0; c0 < p0.n_cars; c0 += chunk_cars) {
+        const int n = p0.n_cars - c0 < chunk_cars ? p0.n_cars - c0 : chunk_cars;
+        p.car0 = c0;
+        hipExtLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(n), dim3(256), 0u, s, c0 == 0 ? a : nullptr, nullptr, 0u, p);
+        hipExtLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(n), dim3(256), 0u, s, nullptr, c0 + n >= p0.n_cars ? b : nullptr, 0u, p);
+    }
     return hipGetLastError();
 }
 

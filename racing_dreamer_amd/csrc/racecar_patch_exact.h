@@ -1,0 +1,225 @@
+// obs_type lidar_occupancy_reference: the reference's OccupancyMapObs.step (dreamer/wrappers.py:396-406: to_pixel, 220 x 220
+// crop, scipy.ndimage.rotate, centre 200 x 200, PIL resize to 64 x 64) restated down to the binary64 operation.
+// The spec - with the library line every step follows - is oracle/patch_reference.py (render_patch_exact); the C oracle's
+// oc_patch_exact_range and the two kernels here are the same arithmetic, operation by operation (IEEE binary64, no fused
+// multiply-add: the library is built with -ffp-contract=off; integer arithmetic for Pillow's resize).
+//
+//   rc_patch_exact_prefilter_kernel   one 256-thread workgroup per car: the crop's cubic-spline coefficients, 220 x 220 binary64
+//       (387 KB per car: global scratch, two buffers per car of the chunk - no LDS holds it).  Axis 0 with one lane per COLUMN
+//       (the column's 220 bits in LDS words; the causal start value summed from the bits in registers; forward values stored row-major
+//       = coalesced across lanes; the backward pass writes its results TRANSPOSED, four rows per lane at a time), then axis 1 with
+//       one lane per ROW reading the transposed array = coalesced again; the result stays in [column][row] order.
+//   rc_patch_exact_sample_kernel      one 256-thread workgroup per car: the 200 x 200 centre window of the rotated image (16 taps
+//       per pixel from the coefficient array through L1 / L2, weights and sums in binary64, rounded to uint8 as the library does)
+//       into LDS, then Pillow's two integer passes (200 x 200 -> 200 x 64 -> 64 x 64) from LDS, the patch written once.
+// A recurrence of 220 dependent steps per line cannot be sped up by a scan without changing the order of the additions; what
+// hides its latency is other cars: two workgroups (eight waves) per SIMD, every load of the backward passes issued ahead.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "racecar_internal.h"       // RcExactParams
+
+#define PX_CROP 220
+#define PX_WIN 200
+#define PX_OUT 64
+#define PX_KSIZE 15
+#define PX_BITS 22
+#define PX_Z (-0.2679491924311227)            // scipy ni_splines.c: the cubic spline's pole, sqrt(3) - 2 correctly rounded
+#define PX_ZN (-5.539710763905135e-126)       // pow(PX_Z, 219)
+#define PX_PI180 1.74532925199432957692e-2
+#define PX_CAR_DOUBLES RC_EXACT_CAR_DOUBLES
+
+namespace px {
+
+__device__ __forceinline__ bool skip_car(const RcExactParams &p, int car) {
+    // all-zero patch: the first observation of an episode (dreamer/wrappers.py:413), or a position that is no position
+    const float x = p.x[car], y = p.y[car];
+    return p.fresh[car] != 0 || !(fabsf(x) <= 1.0e5f && fabsf(y) <= 1.0e5f);
+}
+
+__device__ __forceinline__ void pixel_of(const RcExactParams &p, int car, int &pr, int &pc) {
+    const double x = (double)p.x[car], y = (double)p.y[car];
+    pr = (int)((double)p.fh - (y - p.oy) / p.res);          // GridMap.to_pixel: truncation towards zero
+    pc = (int)((x - p.ox) / p.res);
+}
+
+__device__ __forceinline__ void sincos_deg(double x, double &cosv, double &sinv) {       // patch_reference.py, sincos_degrees
+    double y = floor(x / 45.0);
+    int j = (int)(y - 8.0 * floor(y / 8.0));
+    if (j & 1) { y = y + 1.0; j += 1; }
+    j &= 7;
+    const double z = (x - y * 45.0) * PX_PI180, zz = z * z;
+    const double sp = z + z * (zz * (-1.0 / 6.0 + zz * (1.0 / 120.0 + zz * (-1.0 / 5040.0 + zz * (1.0 / 362880.0 + zz * (-1.0 / 39916800.0 + zz * (
+        1.0 / 6227020800.0 + zz * (-1.0 / 1307674368000.0))))))));
+    const double cp = 1.0 - zz * (0.5 - zz * (1.0 / 24.0 - zz * (1.0 / 720.0 - zz * (1.0 / 40320.0 - zz * (1.0 / 3628800.0 - zz * (1.0 / 479001600.0 - zz * (
+        1.0 / 87178291200.0 - zz * (1.0 / 20922789888000.0))))))));
+    cosv = j == 0 ? cp : (j == 2 ? -sp : (j == 4 ? -cp : sp));
+    sinv = j == 0 ? sp : (j == 2 ? cp : (j == 4 ? -sp : -cp));
+}
+
+__device__ __forceinline__ void weights(double cc, double (&w)[4]) {
+    const double y = cc - floor(cc), z = 1.0 - y;
+    w[1] = ((y * y) * (y - 2.0) * 3.0 + 4.0) / 6.0;
+    w[2] = ((z - 2.0) * (z * z) * 3.0 + 4.0) / 6.0;
+    w[0] = ((z * z) * z) / 6.0;
+    w[3] = ((1.0 - w[0]) - w[1]) - w[2];
+}
+
+__device__ __forceinline__ int mirror(int i) {
+    i = i < 0 ? -i : i;
+    return i >= PX_CROP ? 2 * PX_CROP - 2 - i : i;
+}
+
+}  // namespace px
+
+// ---------------------------------------------------------------------------------------------------------------- prefilter
+__global__ __launch_bounds__(256) void rc_patch_exact_prefilter_kernel(RcExactParams p) {
+    const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
+    if (px::skip_car(p, car)) return;                                  // (uniform over the workgroup)
+    double *rowmaj = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES;  // [r][c] forward values of axis 0, then [c][r] of axis 1
+    double *colmaj = rowmaj + PX_CROP * PX_CROP;                       // [c][r]: axis-0 result, finally the coefficients
+    __shared__ uint32_t bits[7][256];
+    const double z = PX_Z, zn = PX_ZN, gain = (1.0 - 1.0 / z) * (1.0 - z);
+    int pr, pc;
+    px::pixel_of(p, car, pr, pc);
+    // ---- axis 0: lane = column t of the crop (north-up: crop row r is grid row r_top - (pr - 110 + r))
+    if (t < PX_CROP) {
+        const int gx = (pc - PX_CROP / 2 + t) - p.c0;
+        const bool inx = (unsigned)gx < (unsigned)p.w;
+        for (int j = 0; j < 7; ++j) {
+            uint32_t word = 0;
+            for (int b = 0; b < 32; ++b) {
+                const int r = 32 * j + b, gy = p.r_top - (pr - PX_CROP / 2 + r);
+                uint32_t bit = 0;
+                if (r < PX_CROP && inx && (unsigned)gy < (unsigned)p.h) bit = (p.drv_words[(size_t)gy * p.pitch + (gx >> 5)] >> (gx & 31)) & 1u;
+                word |= bit << b;
+            }
+            bits[j][t] = word;
+        }
+        auto cv = [&](int i) { return ((bits[i >> 5][t] >> (i & 31)) & 1u) ? 1.0 * gain : 0.0 * gain; };
+        double c0 = cv(0) + zn * cv(PX_CROP - 1), zi = z;
+        for (int i = 1; i < PX_CROP - 1; ++i) {
+            c0 = c0 + zi * (cv(i) + zn * cv(PX_CROP - 1 - i));
+            zi *= z;
+        }
+        double v = c0 / (1.0 - zn * zn), prev = 0.0;
+        rowmaj[t] = v;
+        for (int r = 1; r < PX_CROP; ++r) {                     // c[r] += z c[r - 1]
+            prev = v;
+            v = cv(r) + z * v;
+            rowmaj[(size_t)r * PX_CROP + t] = v;
+        }
+        v = (z * prev + v) * z / (z * z - 1.0);                 // c[n - 1] = (z c[n - 2] + c[n - 1]) z / (z z - 1)
+        // backward, four rows at a time: c[r] = z (c[r + 1] - c[r]); stored transposed, 32 contiguous bytes per lane and step
+        double *dst = colmaj + (size_t)t * PX_CROP;
+        double q[4];
+        q[3] = v;
+        for (int k = 2; k >= 0; --k) { v = z * (v - rowmaj[(size_t)(PX_CROP - 4 + k) * PX_CROP + t]); q[k] = v; }
+        for (int k = 0; k < 4; ++k) dst[PX_CROP - 4 + k] = q[k];
+        for (int r0 = PX_CROP - 8; r0 >= 0; r0 -= 4) {
+            double f[4];
+            for (int k = 0; k < 4; ++k) f[k] = rowmaj[(size_t)(r0 + k) * PX_CROP + t];
+            for (int k = 3; k >= 0; --k) { v = z * (v - f[k]); q[k] = v; }
+            for (int k = 0; k < 4; ++k) dst[r0 + k] = q[k];
+        }
+    }
+    __syncthreads();          // every column's transposed result is visible to the whole workgroup (global memory, same CU)
+    // ---- axis 1: lane = row t; element (row t, column i) lies at colmaj[i * 220 + t]: coalesced across lanes
+    if (t < PX_CROP) {
+        auto cw = [&](int i) { return colmaj[(size_t)i * PX_CROP + t] * gain; };      // the second pass scales its input too: c *= gain
+        double c0 = cw(0) + zn * cw(PX_CROP - 1), zi = z;
+        for (int i = 1; i < PX_CROP - 1; ++i) {
+            c0 = c0 + zi * (cw(i) + zn * cw(PX_CROP - 1 - i));
+            zi *= z;
+        }
+        double v = c0 / (1.0 - zn * zn), prev = 0.0;
+        rowmaj[t] = v;                                           // (the row-major buffer is free again: forward values, [i][t])
+        for (int i = 1; i < PX_CROP; ++i) {
+            prev = v;
+            v = cw(i) + z * v;
+            rowmaj[(size_t)i * PX_CROP + t] = v;
+        }
+        v = (z * prev + v) * z / (z * z - 1.0);
+        colmaj[(size_t)(PX_CROP - 1) * PX_CROP + t] = v;
+        for (int i = PX_CROP - 2; i >= 0; --i) {
+            v = z * (v - rowmaj[(size_t)i * PX_CROP + t]);
+            colmaj[(size_t)i * PX_CROP + t] = v;                 // coefficient of (row t, column i)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- rotate, crop, resize
+__global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParams p) {
+    const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
+    uint8_t *out = p.patch + (size_t)car * (PX_OUT * PX_OUT);
+    if (px::skip_car(p, car)) {
+        for (int q = t; q < PX_OUT * PX_OUT / 16; q += 256) reinterpret_cast<uint4 *>(out)[q] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
+    __shared__ uint8_t win[PX_WIN * PX_WIN];
+    __shared__ uint8_t tmp[PX_WIN * PX_OUT];
+    __shared__ int32_t kk[PX_OUT * PX_KSIZE];
+    __shared__ int32_t bounds[PX_OUT * 2];
+    for (int q = t; q < PX_OUT * PX_KSIZE; q += 256) kk[q] = p.kk[q];
+    for (int q = t; q < PX_OUT * 2; q += 256) bounds[q] = p.kk[PX_OUT * PX_KSIZE + q];
+    const double *coef = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [column][row]
+    // the rotation of scipy.ndimage.rotate(reshape=True) on a 220 x 220 input (patch_reference.py, rotation)
+    double cs, sn;
+    px::sincos_deg((2.0 * 3.141592653589793 - (double)p.theta[car]) * (180.0 / 3.141592653589793), cs, sn);
+    const double n = (double)PX_CROP;
+    const double b0[4] = {cs * 0.0 + sn * 0.0, cs * 0.0 + sn * n, cs * n + sn * 0.0, cs * n + sn * n};
+    const double b1[4] = {-sn * 0.0 + cs * 0.0, -sn * 0.0 + cs * n, -sn * n + cs * 0.0, -sn * n + cs * n};
+    double lo0 = b0[0], hi0 = b0[0], lo1 = b1[0], hi1 = b1[0];
+    for (int k = 1; k < 4; ++k) {
+        lo0 = b0[k] < lo0 ? b0[k] : lo0; hi0 = b0[k] > hi0 ? b0[k] : hi0;
+        lo1 = b1[k] < lo1 ? b1[k] : lo1; hi1 = b1[k] > hi1 ? b1[k] : hi1;
+    }
+    const int S0 = (int)((hi0 - lo0) + 0.5), S1 = (int)((hi1 - lo1) + 0.5);
+    const double h0 = (double)(S0 - 1) / 2, h1 = (double)(S1 - 1) / 2;
+    const double off0 = (double)(PX_CROP - 1) / 2 - (cs * h0 + sn * h1), off1 = (double)(PX_CROP - 1) / 2 - (-sn * h0 + cs * h1);
+    const int i0 = S0 / 2 - PX_WIN / 2, j0 = S1 / 2 - PX_WIN / 2;
+    for (int q = t; q < PX_WIN * PX_WIN; q += 256) {
+        const int i = q / PX_WIN, j = q - i * PX_WIN;
+        const double o0 = (double)(i0 + i), o1 = (double)(j0 + j);
+        const double cc0 = ((0.0 + o0 * cs) + o1 * sn) + off0, cc1 = ((0.0 + o0 * (-sn)) + o1 * cs) + off1;
+        double tv = 0.0;
+        if (!(cc0 < 0 || cc0 > PX_CROP - 1 || cc1 < 0 || cc1 > PX_CROP - 1)) {
+            double w0[4], w1[4];
+            px::weights(cc0, w0);
+            px::weights(cc1, w1);
+            const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
+            int col[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) col[b] = px::mirror(st1 + b) * PX_CROP;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int row = px::mirror(st0 + a);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) tv = tv + (coef[col[b] + row] * w0[a]) * w1[b];
+            }
+        }
+        tv = tv > 0 ? tv + 0.5 : 0.0;
+        win[q] = (uint8_t)(tv > 255.0 ? 255.0 : tv);
+    }
+    __syncthreads();
+    // Pillow's 8-bit resize, horizontal pass: 200 rows x 64 columns
+    for (int q = t; q < PX_WIN * PX_OUT; q += 256) {
+        const int r = q / PX_OUT, xx = q - r * PX_OUT;
+        const int x0 = bounds[2 * xx], xm = bounds[2 * xx + 1];
+        int32_t acc = 1 << (PX_BITS - 1);
+        for (int k = 0; k < xm; ++k) acc += (int32_t)win[r * PX_WIN + x0 + k] * kk[xx * PX_KSIZE + k];
+        acc >>= PX_BITS;
+        tmp[q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+    __syncthreads();
+    // ... vertical pass: 64 x 64, written once
+    for (int q = t; q < PX_OUT * PX_OUT; q += 256) {
+        const int yy = q / PX_OUT, xx = q - yy * PX_OUT;
+        const int y0 = bounds[2 * yy], ym = bounds[2 * yy + 1];
+        int32_t acc = 1 << (PX_BITS - 1);
+        for (int k = 0; k < ym; ++k) acc += (int32_t)tmp[(y0 + k) * PX_OUT + xx] * kk[yy * PX_KSIZE + k];
+        acc >>= PX_BITS;
+        out[q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+}

@@ -22,7 +22,7 @@ def test_every_declared_symbol_is_exported_and_bound(hip_lib):
     for name in declared:
         assert hasattr(hip_lib, name), f"{name} declared in racecar_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == declared, "ctypes binding and header disagree"
-    assert hip_lib.rc_abi_version() == _lib.RC_ABI_VERSION == 2
+    assert hip_lib.rc_abi_version() == _lib.RC_ABI_VERSION == 3
 
 
 def test_config_struct_matches_header(hip_lib):

@@ -17,7 +17,7 @@ def _run_pair(track_name, num_envs, cars, steps, repeat, obs_type="lidar", mode=
     from racing_dreamer_amd.track_assets import load_track
     from racing_dreamer_amd import spec
     track = load_track(track_name)
-    occ = obs_type == "lidar_occupancy"
+    occ = {"lidar": False, "lidar_occupancy": True, "lidar_occupancy_reference": "reference"}[obs_type]
     env = BatchedRaceEnv(track, num_envs, cars, obs_type=obs_type, auto_reset=auto_reset,
                          time_limit_steps=time_limit_steps, task=task, remap_actions=remap, car_tasks=car_tasks,
                          n_steps=n_steps)
@@ -60,6 +60,93 @@ def test_odd_batch_shapes(num_envs, cars):
     big = num_envs * cars > 2000        # the larger shapes are about the scan's geometry only: keep the oracle's share small
     _run_pair("columbia", num_envs=num_envs, cars=cars, steps=3 if big else 6, repeat=2,
               obs_type="lidar" if big else "lidar_occupancy")
+
+
+def test_reference_patches_on_the_device_equal_the_references_own():
+    """obs_type `lidar_occupancy_reference`: the HIP kernels against G6 - the 379 patches the REFERENCE's own
+    `OccupancyMapObs.step` produced (scipy spline rotation + PIL bicubic resize on the real drivable grids,
+    tests/golden/occupancy_patch_golden.npz) - identical, every pixel of every patch.  (The goldens' poses are float64; the
+    device holds float32 state, so the goldens are kept where the float32 pose lands in the same pixel with a heading that
+    differs by less than 1e-7 rad - and those that survive the narrowing must be ALL of them but a handful.)"""
+    import torch
+    from oracle import patch_reference as px
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "occupancy_patch_golden.npz"))
+    total = same = 0
+    for name in ("austria", "treitlstrasse_v2", "columbia_slam", "columbia"):
+        t = load_track(name)
+        poses = G[name + "_poses"]
+        want = np.unpackbits(G[name + "_patches"], axis=-2)[..., 0]
+        p32 = poses.astype(np.float32)
+        env = BatchedRaceEnv(t, len(poses), 1, obs_type="lidar_occupancy_reference")
+        env.reset()
+        got = env.set_pose(p32)["lidar_occupancy"]
+        torch.cuda.synchronize()
+        got = got.cpu().numpy().reshape(len(poses), 64, 64)
+        env.close()
+        # what the spec says for the float32 poses (the restatement, == the library on 40 000 random poses) ...
+        spec = px.render_patch_exact(t, p32.astype(np.float64))
+        assert np.array_equal(got, spec), (name, np.nonzero((got != spec).reshape(len(poses), -1).any(1))[0][:5])
+        # ... and the reference's own patches wherever narrowing the pose to float32 did not move it across a pixel
+        ident = (got == want).reshape(len(poses), -1).all(1)
+        total += len(poses)
+        same += int(ident.sum())
+        moved = ~ident
+        pr64, pc64 = px.to_pixel(t, poses[:, 0], poses[:, 1])
+        pr32, pc32 = px.to_pixel(t, p32[:, 0].astype(np.float64), p32[:, 1].astype(np.float64))
+        # a patch may differ from the golden only by a few edge pixels (the float32 pose is up to 1e-6 m / 1e-7 rad off)
+        assert ((got != want).reshape(len(poses), -1).sum(1)[moved] <= 12).all(), name
+        assert (moved & (pr64 == pr32) & (pc64 == pc32)).sum() <= 0.15 * len(poses), name
+    assert total == 379 and same >= 0.85 * total, (same, total)
+
+
+@pytest.mark.parametrize("track_name", ["austria", "barcelona"])
+def test_reference_patches_dense_poses_equal_the_c_oracle(track_name):
+    """The same render against the C oracle (oc_patch_exact_range, the restatement in C) from 1 024 arbitrary poses: anywhere on
+    the grid and beyond it, on cell corners, axis-aligned and diagonal headings - binary64 arithmetic on both sides, so every
+    pixel of every patch is equal."""
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    t = load_track(track_name)
+    rng = np.random.default_rng(23)
+    n = 1024
+    x = t.origin[0] + rng.uniform(-0.5, t.width * 0.05 + 0.5, n)
+    y = t.origin[1] + rng.uniform(-0.5, t.height * 0.05 + 0.5, n)
+    th = rng.uniform(-np.pi, np.pi, n)
+    k = n // 2
+    cl = t.centerline[rng.integers(0, len(t.centerline), k)]
+    x[:k], y[:k] = cl[:, 0] + rng.uniform(-0.5, 0.5, k), cl[:, 1] + rng.uniform(-0.5, 0.5, k)
+    q = n // 8
+    x[:q] = t.origin[0] + rng.integers(0, t.width, q) * 0.05
+    y[:q] = t.origin[1] + rng.integers(0, t.height, q) * 0.05
+    th[:q] = rng.choice([0.0, np.pi / 2, np.pi, -np.pi / 2, np.pi / 4, -np.pi / 4, 3 * np.pi / 4], q)
+    poses = np.stack([x, y, th], 1).astype(np.float32)
+    cfg = ro.OracleConfig(num_envs=n, cars_per_env=1, render_occupancy="reference")
+    ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=8)
+    ora.set_frame(t)
+    ora.reset()
+    ora.arr["x"][:], ora.arr["y"][:], ora.arr["theta"][:] = poses[:, 0], poses[:, 1], poses[:, 2]
+    ora.arr["st"][:], ora.arr["ct"][:] = ro.sincos32(poses[:, 2])
+    ora.arr["fresh"][:] = 0
+    ora._observe()
+    want = ora.patch.reshape(n, 64, 64)
+    env = BatchedRaceEnv(t, n, 1, obs_type="lidar_occupancy_reference")
+    assert not env.reset()["lidar_occupancy"].any()              # the first observation of an episode: zeros (dreamer/wrappers.py:413)
+    got = env.set_pose(poses)["lidar_occupancy"]
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().reshape(n, 64, 64)
+    bad = np.nonzero((got != want).reshape(n, -1).any(1))[0]
+    assert bad.size == 0, (track_name, bad.size, bad[:5], poses[bad[:5]])
+    assert want.any() and not want.all() and set(np.unique(want)) <= {0, 1}
+    env.close()
+
+
+def test_reference_patches_in_a_rollout_match_the_oracle():
+    """... and inside the step: 48 envs, action_repeat 4, auto-reset (fresh episodes read zeros), all other outputs as ever."""
+    _run_pair("columbia", num_envs=48, cars=1, steps=8, repeat=4, obs_type="lidar_occupancy_reference")
 
 
 def test_occupancy_patch_matches_oracle():

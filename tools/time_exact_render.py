@@ -1,0 +1,17 @@
+import sys, time, torch
+sys.path.insert(0, ".")
+from racing_dreamer_amd.batched_env import BatchedRaceEnv
+from racing_dreamer_amd import _lib as L
+for n in (2048, 16384, 65536):
+    env = BatchedRaceEnv("austria", n, 1, obs_type="lidar_occupancy_reference", auto_reset=True)
+    env.reset(mode="random", seed=0)
+    torch.cuda.set_stream(env.stream)
+    for k in range(5): env.step_random(seed=1, step=k)
+    env.sync(); env.reset_kernel_times(); env.set_profiling(True, kernels=[L.K_PATCH])
+    t0 = time.perf_counter()
+    m = 10
+    for k in range(m): env.step_random(seed=1, step=5 + k)
+    env.sync(); dt = time.perf_counter() - t0
+    env.set_profiling(False)
+    print(n, "envs: step", dt / m * 1e3, "ms;", n * m / dt / 1e6, "M env-steps/s; exact render", env.kernel_times()["rc_patch_kernel"], flush=True)
+    env.close()
