@@ -93,6 +93,10 @@ class BatchedRaceEnv:
         self.num_envs, self.cars_per_env = int(num_envs), int(cars_per_env)
         self.n_cars = self.num_envs * self.cars_per_env
         self.obs_type, self.action_repeat, self.seed = obs_type, int(action_repeat), int(seed)
+        if self.track.open and task != "max_speed":
+            import warnings
+            warnings.warn(f"track {self.track.name!r} is not a loop (tracks/index.json: open): progress never comes round, so no lap is ever "
+                          f"completed and `lap > laps` never ends an episode there", stacklevel=2)
         self.device = torch.device("cuda", device)
         self.first_env = int(first_env)
 

@@ -49,6 +49,26 @@ def source_hash(csrc: str = CSRC, flags=None, sources=None) -> str:
     return h.hexdigest()[:32]
 
 
+def headers_hash(csrc: str = CSRC) -> str:
+    """sha256 over the CONTENT of the headers alone: what the shipped library and the lab library must have in common (RcParams
+    and RcLaunchInfo cross between them by pointer).  Compiled into both as -DRC_HEADERS_ID; the loader compares."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in HEADERS:
+        with open(os.path.join(csrc, name), "rb") as f:
+            h.update(b"\0" + os.path.basename(name).encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def _tmp_beside(path: str) -> str:
+    """A temporary name next to `path` that no other process uses: N ranks may build the same library at once (the lab on first
+    use of a variant), and a shared `.new` let one replace or remove the file another was still writing."""
+    import tempfile
+    fd, tmp = tempfile.mkstemp(prefix=os.path.basename(path) + ".", suffix=".new", dir=os.path.dirname(path))
+    os.close(fd)
+    return tmp
+
+
 def library_build_id(path: str = LIB_PATH):
     """The build id a library file carries (the string behind `rc_build_id()`), read from the file's bytes - no dlopen, so
     asking does not load a stale library into the process.  None if the file is missing or carries none."""
@@ -194,8 +214,8 @@ def build(force: bool = False, verbose: bool = True, csrc: str = CSRC, lib_path:
             print(f"[racing_dreamer_amd.build] reused {lib_path}: its build id {want} is the hash of the sources and flags", flush=True)
         return lib_path
     os.makedirs(os.path.dirname(lib_path), exist_ok=True)
-    tmp = lib_path + ".new"
-    cmd = [find_hipcc(), *FLAGS, f'-DRC_BUILD_ID="{want}"', "-Rpass-analysis=kernel-resource-usage",
+    tmp = _tmp_beside(lib_path)
+    cmd = [find_hipcc(), *FLAGS, f'-DRC_BUILD_ID="{want}"', f'-DRC_HEADERS_ID="{headers_hash(csrc)}"', "-Rpass-analysis=kernel-resource-usage",
            *[os.path.join(csrc, s) for s in SOURCES], "-o", tmp]
     if verbose:
         print("[racing_dreamer_amd.build]", " ".join(cmd), flush=True)
@@ -203,6 +223,8 @@ def build(force: bool = False, verbose: bool = True, csrc: str = CSRC, lib_path:
     other = [l for l in r.stderr.splitlines() if "kernel-resource-usage" not in l and not l.startswith(("      |", " ")) and "hip-link" not in l]
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-8000:])
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise subprocess.CalledProcessError(r.returncode, cmd)
     if other and verbose:
         print("\n".join(other), file=sys.stderr)
@@ -212,6 +234,7 @@ def build(force: bool = False, verbose: bool = True, csrc: str = CSRC, lib_path:
     except RuntimeError:
         os.remove(tmp)
         raise
+    os.chmod(tmp, 0o755)
     os.replace(tmp, lib_path)
     LAST_BUILD.update(action="compiled")
     if library_build_id(lib_path) != want:
@@ -231,8 +254,8 @@ def build_lab(force: bool = False, verbose: bool = True, csrc: str = CSRC, lab_p
             print(f"[racing_dreamer_amd.build] reused {lab_path}: its build id {want} is the hash of the lab's sources and flags", flush=True)
         return lab_path
     os.makedirs(os.path.dirname(lab_path), exist_ok=True)
-    tmp = lab_path + ".new"
-    cmd = [find_hipcc(), *FLAGS, f'-DRC_BUILD_ID="{want}"', "-Rpass-analysis=kernel-resource-usage",
+    tmp = _tmp_beside(lab_path)
+    cmd = [find_hipcc(), *FLAGS, f'-DRC_BUILD_ID="{want}"', f'-DRC_HEADERS_ID="{headers_hash(csrc)}"', "-Rpass-analysis=kernel-resource-usage",
            *[os.path.join(csrc, s) for s in LAB_SOURCES], "-o", tmp]
     if verbose:
         print("[racing_dreamer_amd.build]", " ".join(cmd), flush=True)
@@ -240,6 +263,8 @@ def build_lab(force: bool = False, verbose: bool = True, csrc: str = CSRC, lab_p
     r = subprocess.run(cmd, cwd=csrc, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stderr[-8000:])
+        if os.path.exists(tmp):
+            os.remove(tmp)
         raise subprocess.CalledProcessError(r.returncode, cmd)
     try:
         check_resource_usage(r.stderr, required=("rc_raycast_car_stamps_kernel", "rc_raycast_kernel"), min_waves={})
@@ -247,6 +272,7 @@ def build_lab(force: bool = False, verbose: bool = True, csrc: str = CSRC, lab_p
     except RuntimeError:
         os.remove(tmp)
         raise
+    os.chmod(tmp, 0o755)
     os.replace(tmp, lab_path)
     if verbose:
         print(f"[racing_dreamer_amd.build] compiled {lab_path} in {time.time() - t0:.1f} s (build id {want})", flush=True)

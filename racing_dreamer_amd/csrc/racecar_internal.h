@@ -169,6 +169,7 @@ hipError_t rck_p2p_wait(const uint32_t *flags, int n, int skip, uint32_t value, 
 // kernel launchers (racecar_kernels.hip); all asynchronous on `s`
 void rck_set_launch_events(hipEvent_t start, hipEvent_t stop);   // attach start / stop timestamps to the NEXT launch of this thread
 hipError_t rck_set_lds_limits(size_t lds_bytes);
+const char *rck_lab_abi_string();   // sizes of RcParams / RcLaunchInfo + the hash of the headers: what a lab library must have been built against
 const char *rck_lab_unavailable();   // nullptr if the lab library (scan variants 0-6, stamps build: racecar_lab.hip) can be used, else why not
 hipError_t rck_build_quad_planes(const RcTrackDev &t, uint16_t *quad_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch, quad_plane_bytes
 hipError_t rck_build_first_table(const RcTrackDev &t, uint16_t *first_rect_dev, hipStream_t s);   // needs ray_words, h, w, pitch, cell_pitch

@@ -1816,6 +1816,17 @@ hipError_t rck_p2p_wait(const uint32_t *flags, int n, int skip, uint32_t value, 
 // ---- The lab library (racecar_lab.hip: scan variants 0-6, the stamps build): not part of this library.  It is looked for next
 // to this one (libracecar_lab.so in the directory libracecar_hip.so was loaded from) the first time a handle asks for one of
 // its kernels, and every such request fails with the reason when it is not there.
+// What both sides of the lab boundary must agree on: the sizes of the structs that cross it by pointer and the hash of the
+// headers that define them (-DRC_HEADERS_ID, build.py) - in ONE string, compared as a whole.
+#ifndef RC_HEADERS_ID
+#define RC_HEADERS_ID "unhashed"
+#endif
+const char *rck_lab_abi_string() {
+    static const std::string s = "RcParams " + std::to_string(sizeof(RcParams)) + " RcLaunchInfo " + std::to_string(sizeof(RcLaunchInfo)) +
+                                 " headers " RC_HEADERS_ID;
+    return s.c_str();
+}
+
 namespace {
 struct Lab {
     void *handle = nullptr;
@@ -1827,10 +1838,14 @@ std::mutex g_lab_mutex;
 Lab g_lab;
 size_t g_lds_limit = 0;              // what rck_set_lds_limits was last called with (the lab's kernels get the same)
 
-const Lab &lab() {
+// A snapshot BY VALUE, taken under the lock (a reference to g_lab read after the lock was dropped raced with another
+// thread inside lab() clearing `why` and assigning the function pointers).
+Lab lab() {
     std::lock_guard<std::mutex> lock(g_lab_mutex);
     if (g_lab.handle != nullptr) return g_lab;
     g_lab.why.clear();               // (not loaded yet: look again - it may have been built since the last request)
+    g_lab.launch_raycast = nullptr;
+    g_lab.set_lds_limits = nullptr;
     Dl_info info;
     std::string dir = ".";
     if (dladdr(reinterpret_cast<const void *>(&rck_set_launch_events), &info) != 0 && info.dli_fname != nullptr) {
@@ -1847,18 +1862,25 @@ const Lab &lab() {
                     "); build it with `python -m racing_dreamer_amd.build --lab`";
         return g_lab;
     }
+    auto refuse = [&](const std::string &why) {
+        g_lab.why = why;
+        g_lab.launch_raycast = nullptr;
+        g_lab.set_lds_limits = nullptr;
+        dlclose(h);
+        return g_lab;
+    };
+    // RcParams and RcLaunchInfo cross this boundary by pointer: a lab built against other headers reads them wrongly - wrong scans
+    // or a GPU fault, no error.  The lab says what it was built against; anything else is refused.
+    auto abi = reinterpret_cast<const char *(*)(void)>(dlsym(h, "rclab_abi"));
+    const std::string want = rck_lab_abi_string();
+    if (abi == nullptr || want != abi())
+        return refuse(path + " was built against other headers (it says \"" + std::string(abi != nullptr ? abi() : "nothing: no rclab_abi") +
+                      "\", this library needs \"" + want + "\"); rebuild it with `python -m racing_dreamer_amd.build --lab`");
     g_lab.launch_raycast = reinterpret_cast<decltype(g_lab.launch_raycast)>(dlsym(h, "rclab_launch_raycast"));
     g_lab.set_lds_limits = reinterpret_cast<decltype(g_lab.set_lds_limits)>(dlsym(h, "rclab_set_lds_limits"));
-    if (g_lab.launch_raycast == nullptr || g_lab.set_lds_limits == nullptr) {
-        g_lab.why = path + " does not export rclab_launch_raycast / rclab_set_lds_limits";
-        dlclose(h);
-        return g_lab;
-    }
-    if (g_lds_limit != 0 && g_lab.set_lds_limits(g_lds_limit) != (int)hipSuccess) {
-        g_lab.why = path + ": rclab_set_lds_limits failed";
-        dlclose(h);
-        return g_lab;
-    }
+    if (g_lab.launch_raycast == nullptr || g_lab.set_lds_limits == nullptr)
+        return refuse(path + " does not export rclab_launch_raycast / rclab_set_lds_limits");
+    if (g_lds_limit != 0 && g_lab.set_lds_limits(g_lds_limit) != (int)hipSuccess) return refuse(path + ": rclab_set_lds_limits failed");
     g_lab.handle = h;
     return g_lab;
 }
@@ -1867,12 +1889,9 @@ const Lab &lab() {
 // nullptr if the lab's kernels can be launched, else the reason (the calling thread's copy: valid until its next call)
 const char *rck_lab_unavailable() {
     thread_local std::string reason;
-    const Lab &l = lab();
+    const Lab l = lab();
     if (l.handle != nullptr) return nullptr;
-    {
-        std::lock_guard<std::mutex> lock(g_lab_mutex);
-        reason = l.why;
-    }
+    reason = l.why;
     return reason.c_str();
 }
 
@@ -1945,7 +1964,7 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
     const bool stamps = li.scan_stamps != nullptr && p.cars_per_env == 1;
     if (li.raycast_variant != 7 || stamps) {
         // a lab kernel (superseded variant or the instrumented build): racecar_lab.hip, loaded on first use
-        const Lab &l = lab();
+        const Lab l = lab();
         if (l.handle == nullptr) return hipErrorSharedObjectInitFailed;      // (rc_set_raycast_variant / rc_debug_scan_stamps refuse before it comes to this)
         const hipEvent_t a = g_ev_start, b = g_ev_stop;
         g_ev_start = g_ev_stop = nullptr;

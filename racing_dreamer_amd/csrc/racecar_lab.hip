@@ -10,6 +10,8 @@
 //   rclab_cohabit_kernel            a co-tenant of chosen size for the scan (tools/cohabit_sweep.py: what a collective beside it costs)
 //
 // Numerics as in racecar_kernels.hip: one IEEE operation per written operator (-ffp-contract=off).
+#include <string>
+
 #include "racecar_scan.h"
 
 namespace {
@@ -448,6 +450,16 @@ extern "C" {
 
 // (the marker build.py looks for in the file's bytes: RC_BUILD_ID=<hash of the lab's sources and flags>)
 const char *rclab_build_id(void) { return "RC_BUILD_ID=" RC_BUILD_ID; }
+
+// what this library was built against (racecar_kernels.hip, rck_lab_abi_string: the loader compares the whole string)
+#ifndef RC_HEADERS_ID
+#define RC_HEADERS_ID "unhashed"
+#endif
+const char *rclab_abi(void) {
+    static const std::string s = "RcParams " + std::to_string(sizeof(RcParams)) + " RcLaunchInfo " + std::to_string(sizeof(RcLaunchInfo)) +
+                                 " headers " RC_HEADERS_ID;
+    return s.c_str();
+}
 
 // Dynamic LDS of the variants that stage tables there, and the check that the stamps kernel - which addresses its dynamic
 // LDS from 0 like the shipped scan - has no static LDS.

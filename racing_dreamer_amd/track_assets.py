@@ -54,6 +54,13 @@ class Track:
     def bitmap_bytes(self) -> int:
         return self.height * self.pitch * 4
 
+    @property
+    def open(self) -> bool:
+        """True for a compiled map that is NOT a loop (tracks/index.json "open": a building lobby compiled from a start of its
+        own): scans, steps and collisions are as on any map, but the progress grid does not come round - a lap is never completed,
+        `lap > laps` never ends an episode, and the centre-line table's two ends are not neighbours."""
+        return self.name in open_tracks()
+
 
 def pack_words(mask: np.ndarray, pitch: int) -> np.ndarray:
     h, w = mask.shape
@@ -101,6 +108,16 @@ def load_track(name: str) -> Track:
             f"track asset {path!r} not found; compile it with "
             f"`python -m racing_dreamer_amd.track_compiler {name}` (needs the map images)")
     return track_from_npz(path)
+
+
+@lru_cache(maxsize=None)
+def open_tracks() -> frozenset:
+    import json
+    path = os.path.join(TRACK_DIR, "index.json")
+    if not os.path.exists(path):
+        return frozenset()
+    with open(path) as f:
+        return frozenset(k for k, v in json.load(f).items() if v.get("open"))
 
 
 def available_tracks():

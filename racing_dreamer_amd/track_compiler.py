@@ -343,10 +343,12 @@ def compile_all(maps_dir: str, out_dir: str) -> dict:
     import json
     by_map = {v: k for k, v in TRACK_TO_MAP.items()}
     starts = start_positions()
-    refused = {}
+    refused, open_maps = {}, set()
     if os.path.exists(START_POSITIONS):
         with open(START_POSITIONS) as f:
-            refused = {k: v["refused"] for k, v in json.load(f).items() if "refused" in v}
+            table = json.load(f)
+            refused = {k: v["refused"] for k, v in table.items() if "refused" in v}
+            open_maps = {k for k, v in table.items() if v.get("open")}
     index = {}
     for path in sorted(glob.glob(os.path.join(maps_dir, "*.yaml"))):
         map_name = os.path.basename(path)[:-5]
@@ -369,6 +371,8 @@ def compile_all(maps_dir: str, out_dir: str) -> dict:
                        "track_length_m": round(t.max_steps * t.resolution, 2)}
         if name in starts:
             index[name]["start_position"] = [float(v) for v in starts[name]]
+        if name in open_maps:
+            index[name]["open"] = True          # not a loop: the BFS wave does not come round, a lap is never completed
     with open(os.path.join(out_dir, "index.json"), "w") as f:
         json.dump(index, f, indent=1, sort_keys=True)
     return index

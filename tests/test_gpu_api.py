@@ -358,3 +358,37 @@ def test_sqrt_selftest_is_exact_on_this_device():
     n, bad = C.c_uint64(0), C.c_uint64(0)
     L.check(lib.rc_selftest_sqrt(0, C.byref(n), C.byref(bad)))
     assert n.value == 70 * (1 << 23) + 1 and bad.value == 0
+
+def test_a_lab_library_built_against_other_headers_is_refused(tmp_path):
+    """RcParams and RcLaunchInfo cross the lab boundary by pointer, so a lab library built against other headers would
+    read them wrongly - wrong scans or a GPU fault, no error.  The lab says what it was built against (`rclab_abi`: struct sizes
+    + the hash of the headers), the loader compares the whole string and refuses anything else, naming the build command.  Here:
+    the lab's own source compiled with another headers id (a few seconds; no kernel of it ever runs)."""
+    import os
+    import subprocess
+    import sys
+    from racing_dreamer_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stale = str(tmp_path / "libracecar_lab.so")
+    cmd = [B.find_hipcc(), *B.FLAGS, '-DRC_BUILD_ID="0"', '-DRC_HEADERS_ID="some-other-tree"', os.path.join(B.CSRC, B.LAB_SOURCES[0]), "-o", stale]
+    subprocess.run(cmd, cwd=B.CSRC, check=True, capture_output=True)
+    code = r'''
+import os, sys
+os.environ["RC_LAB_LIBRARY"] = %r
+sys.path.insert(0, %r)
+import torch
+from racing_dreamer_amd.batched_env import BatchedRaceEnv
+env = BatchedRaceEnv("columbia", 64, 1, auto_reset=True)
+env.reset(mode="random", seed=1)
+rc = env._lib.rc_set_raycast_variant(env._h, 3)
+print("variant", rc, env._lib.rc_last_error().decode())
+out = env.step_random(1, 0)
+torch.cuda.synchronize()
+print("scan", env.scan_kernel_name(), float(out["lidar"].max()))
+''' % (stale, root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = {l.split(" ", 1)[0]: l for l in r.stdout.splitlines() if l.split(" ", 1)[0] in ("variant", "scan")}
+    assert int(lines["variant"].split()[1]) != 0 and "built against other headers" in lines["variant"], lines["variant"]
+    assert "some-other-tree" in lines["variant"] and "racing_dreamer_amd.build --lab" in lines["variant"]
+    assert "rc_raycast_car_kernel<1" in lines["scan"] and float(lines["scan"].split()[-1]) > 1.0

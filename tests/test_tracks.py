@@ -187,3 +187,17 @@ def test_scene_export_is_what_the_plotting_code_loads(tmp_path):
         rr, cc = occ.to_pixel((x, y))
         assert occ.map[rr, cc] and maps["progress"].map[rr, cc] >= 0.0 and maps["obstacle"].map[rr, cc] > 0.0, (x, y)
     assert os.path.isabs(config.sdf) and config.name == track and config.map.no_such_key is None
+
+
+def test_the_one_open_map_is_flagged_open():
+    """levinelobby - a building lobby compiled from a start of its own - is not a loop (tracks/start_positions.json
+    says so; the BFS wave does not come round).  index.json and Track carry the flag, every other compiled map is a loop, and
+    the track compiler writes the flag from the start-position table."""
+    import json
+    from racing_dreamer_amd.track_assets import TRACK_DIR, load_track, open_tracks
+    with open(os.path.join(TRACK_DIR, "index.json")) as f:
+        index = json.load(f)
+    assert open_tracks() == {"levinelobby"} == {k for k, v in index.items() if v.get("open")}
+    assert load_track("levinelobby").open and not load_track("austria").open and not load_track("columbia").open
+    with open(os.path.join(TRACK_DIR, "start_positions.json")) as f:
+        assert {k for k, v in json.load(f).items() if v.get("open")} == {"levinelobby"}

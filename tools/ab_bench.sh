@@ -6,6 +6,8 @@
 reps=${1:-3}; shift
 lib=racing_dreamer_amd/lib/libracecar_hip.so
 cp $lib /tmp/ab_original.so
+# whatever ends this script - Ctrl-C, a time-out, a failing step - the shipped library is put back
+trap 'cp /tmp/ab_original.so $lib' EXIT INT TERM
 for r in $(seq $reps); do
   for v in racing_dreamer_amd/lib/ab/*.so; do
     cp $v $lib

@@ -3,6 +3,8 @@
 R=$(pwd); export TMPDIR=/tmp
 lib=racing_dreamer_amd/lib/libracecar_hip.so
 cp $lib /tmp/ab_pmc_original.so
+# whatever ends this script - Ctrl-C, a time-out, a failing step - the shipped library is put back
+trap 'cp /tmp/ab_pmc_original.so $lib' EXIT INT TERM
 for v in racing_dreamer_amd/lib/ab/*.so; do
   cp $v $lib
   echo "== $(basename $v .so)"

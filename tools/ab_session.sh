@@ -3,6 +3,8 @@
 #   bash tools/ab_session.sh [reps] [bench args...] > gpurun_out/ab.log
 lib=racing_dreamer_amd/lib/libracecar_hip.so
 cp $lib /tmp/ab_session_original.so
+# whatever ends this script - Ctrl-C, a time-out, a failing step - the shipped library is put back
+trap 'cp /tmp/ab_session_original.so $lib' EXIT INT TERM
 for v in racing_dreamer_amd/lib/ab/*.so; do
   cp $v $lib
   timeout -k 10 300 python tools/ab_check.py $(basename $v .so) 2>&1 | grep ab_check || echo "ab_check $(basename $v .so): FAILED"
