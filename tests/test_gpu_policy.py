@@ -51,6 +51,7 @@ def test_reference_agent_on_the_device_is_the_oracle_run_step_for_step():
     dev.env.close()
 
 
+@pytest.mark.gpu_slow          # (22 s, most of it the NumPy policy: `pytest -m gpu_slow`; the closed loop above stays in `-m gpu`)
 def test_reference_agent_drives_a_thousand_cars_on_the_device():
     n = 1024
     dev = DeviceEnv("austria", n)

@@ -99,6 +99,7 @@ def test_longitudinal_model_limits():
     """dv/dt = |m| * 4 - 0.8 v (throttle) resp. -|m| * 4 - 0.8 v (brake): throttle m settles at 5 m m/s."""
     env = _box_env(size=2000)
     env.centerline[0, :2] = (5.0, 50.0)
+    env.raycast = lambda *a, **k: np.zeros((env.NC, ro.N_BEAMS), np.float32)      # (1 350 steps: the scans are not what is tested)
     env.reset()
     out = None
     for k in range(200):
@@ -340,7 +341,7 @@ def test_random_starts_follow_the_law_of_survey_h6(track_name, cars):
     t = load_track(track_name)
     n = 20000
     cfg = ro.OracleConfig(num_envs=n, cars_per_env=cars, auto_reset=True)
-    env = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg)
+    env = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=8)
     ref = ro.OracleRaceEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, ro.OracleConfig(num_envs=4, cars_per_env=cars))
     width = ref.spawn_width()
     assert np.array_equal(width, env._keep["spawn_w"]) and width.max() > 0.3 and width.min() >= 0.0

@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round 5: the plain `--gpus N` line's new legs (whole-record gathers at action_repeat 4, configs[4]'s track mix) with ONE rank over
-# the real RCCL backend (GPU box): bash tools/bench_one_rank_rccl_r5.sh
+# The plain `--gpus N` line's new legs (whole-record gathers at action_repeat 4, configs[4]'s track mix) with ONE rank over
+# the real RCCL backend (GPU box): bash tools/bench_one_rank_rccl.sh
 mkdir -p gpurun_out
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29513 bench.py \
     --gpus 1 --force-gather --steps 20 --warmup 5 2>gpurun_out/one_rank_r5.err > gpurun_out/one_rank_r5.json || { tail -5 gpurun_out/one_rank_r5.err; exit 1; }
