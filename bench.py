@@ -644,20 +644,24 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
     track_name = ["columbia", "austria", "barcelona"][rank % 3] if args.mixed_tracks else args.track
     track = load_track(track_name)
     shard = shard_envs(args.envs * world, rank, world)
-    env = None
-    if not fake_local:
-        env = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
-                             device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
+    def make_env():
+        e = BatchedRaceEnv(track, shard.num_envs, args.cars, obs_type=args.obs_type, action_repeat=args.repeat,
+                           device=dev, first_env=shard.first_env, auto_reset=True, profiling=False)
         if args.raycast_variant is not None:
-            env.set_raycast_variant(args.raycast_variant)      # (variants 0-6: lab kernels, built on this request)
+            e.set_raycast_variant(args.raycast_variant)      # (variants 0-6: lab kernels, built on this request)
         for kv in args.debug_knob:
             name, _, val = kv.partition("=")
-            env.debug_set(name, int(val))
-        env.reset(mode="random", seed=0)
+            e.debug_set(name, int(val))
+        e.reset(mode="random", seed=0)
         # every loop below works on the env's own stream: with torch's current stream another one, each step pays two cross-stream
         # event waits (BatchedRaceEnv._enter / _exit) - what the 25 us per step of "non-scan time" in round 4's fresh_reset leg were
         # (that leg ran before this call; `profiles/r05_e_fresh_window*.log` has the kernel timeline of the window)
-        torch.cuda.set_stream(env.stream)
+        torch.cuda.set_stream(e.stream)
+        return e
+
+    env = None
+    if not fake_local:
+        env = make_env()
     # the first steps after a reset, timed on their own (N = 1): what `--settle 0` would put into the timed window
     fresh = None
     if not distributed and not args.no_configs:
@@ -783,6 +787,16 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
                     dist.broadcast_object_list(ids, src=0)
                     env.comm_init(ids[0], rank, world)
                     abi_ranks = env.comm_count()
+        # The env of stage 1 has done its work.  The headline runs on an env - and so on a stream - created AFTER the communicator:
+        # with the env's stream older than the communicator's, the sharded loop ran 0.237 ms per step where it takes 0.207 the other
+        # way round (one rank over RCCL, alternating on one box: profiles/r06_i_ab_stream_order_one_rank.txt; the scan itself is
+        # the same - it is the exchange beside it that lands differently on the hardware queues).  The track's tables are shared
+        # between the two handles (the new one is created before the old one goes), so this costs an arena and a reset.
+        if not fake_local and not os.environ.get("RC_EXP_KEEP_ENV"):
+            with guard.leg("second_env", budget_s=min(args.leg_timeout, 60.0)):
+                old_env, env = env, make_env()
+                old_env.close()
+                step_no = 0
         if rank == 0:
             print(f"bench.py: {world} ranks joined ({args.backend}), {guard.time_left():.0f} s of the time budget left; rank 0 alone: "
                   f"{local['env_steps_per_s_this_rank'] / 1e6:.1f} M env-steps/s", file=sys.stderr, flush=True)
@@ -1281,6 +1295,32 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
             with guard.leg("configs"):
                 out["configs"] = [time_config(*c, settle=args.settle) for c in cfgs]
                 out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10, settle=args.settle))
+        # obs_type lidar_occupancy_reference: the patch computed exactly as the reference's OccupancyMapObs.step does (binary64 spline
+        # rotation + Pillow's integer resize, racecar_patch_exact.h) - opt-in, ~100 x the fast sampler's cost: a few steps suffice
+        if guard.go("exact_render", 15):
+            with guard.leg("exact_render"):
+                n_x = min(args.envs, 16384)
+                ex = BatchedRaceEnv(track, n_x, 1, obs_type="lidar_occupancy_reference", device=dev, auto_reset=True)
+                ex.reset(mode="random", seed=0)
+                torch.cuda.set_stream(ex.stream)
+                for k in range(3):
+                    ex.step_random(seed=2, step=k)
+                ex.sync()
+                ex.reset_kernel_times()
+                ex.set_profiling(True, kernels=[L.K_PATCH])
+                t0 = time.perf_counter()
+                for k in range(4):
+                    ex.step_random(seed=1, step=3 + k)
+                ex.sync()
+                dtx = time.perf_counter() - t0
+                ex.set_profiling(False)
+                kx = ex.kernel_times()["rc_patch_kernel"]["avg_ms"]
+                ex.close()
+                out["exact_render"] = {
+                    "workload": f"{n_x} envs, {track_name}, obs_type=lidar_occupancy_reference (dreamer/wrappers.py:396-406 restated to the binary64 operation)",
+                    "steps": 4, "ms_per_step": dtx / 4 * 1e3, "env_steps_per_s": n_x * 4 / dtx, "render_ms": round(kx, 3),
+                    "render_us_per_car": round(kx * 1e3 / n_x, 3),
+                    "note": "identical to the reference's own patches (G6); the reference's wrapper takes 5.6 ms per call on one core (SURVEY.md 6)"}
         # the scan across tracks at the headline's batch size: small tables (columbia) to the largest (gbr: 506 MB of
         # first-trip table) - the range the headline's one track sits in
         if guard.go("tracks", 40):

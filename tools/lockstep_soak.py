@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Long lockstep run of the HIP env against the C oracle (GPU box): python tools/lockstep_soak.py [steps] [envs]
 
-The parity tests compare every output of every step, but over tens of steps (the NumPy oracle is slow); tools/soak.py runs for
-thousands of steps but checks the last scan only.  This compares EVERY output of EVERY step over thousands of steps with the C
+The parity tests compare every output of every step, but over tens of steps (the NumPy oracle is slow); a soak that
+checks only the last scan says little.  This compares EVERY output of EVERY step over thousands of steps with the C
 port of the oracle (oracle/racecar_oracle.c, itself held bit-identical to the NumPy oracle by tests/test_c_oracle.py) on the
 configurations where rare events live: finish-line crossings and `lap > laps` (a follow-the-gap driver that laps), resets of all
 three modes behind every kind of episode end, 2-4 cars with inter-car rays / collisions / clash fallbacks of the start law,
@@ -35,20 +35,30 @@ CONFIGS = [
     ("time limit + remapped actions", "barcelona", 1, "random", dict(time_limit_steps=50, remap=True), "grid", 4),
     ("three cars, max_speed task", "gbr", 3, "forward", dict(task="max_speed"), "random", 1),
     ("no termination on contact", "Treitlstrasse_3-U_v3", 2, "forward", dict(terminate_on_collision=False, time_limit=6.0), "random_ball", 3),
+    # round 6: the start law where bins are skipped and headings held (boxes on the track, one-cell corridors), three cars
+    ("narrow map: skipped bins, held headings", "torino", 3, "forward", dict(), "random_ball", 2),
+    ("a lobby, not a loop: 26 unusable bins, grid start of four", "levinelobby", 4, "forward", dict(time_limit=3.0), "grid", 2),
+    # round 6: the reference's own lidar_occupancy arithmetic in the step (binary64 on both sides; a twentieth of the envs and a tenth
+    # of the steps: the C port renders 9 ms per car and thread)
+    ("random actions + the reference render", "columbia", 1, "random", dict(obs="lidar_occupancy_reference", scale=(0.1, 0.05)), "random", 2),
 ]
 
 
 def run(name, track_name, cars, policy, kw, mode, repeat, steps, n):
     t = load_track(track_name)
-    occ = kw.get("obs") == "lidar_occupancy"
+    occ = {None: False, "lidar_occupancy": True, "lidar_occupancy_reference": "reference"}[kw.get("obs")]
+    if "scale" in kw:
+        steps, n = max(int(steps * kw["scale"][0]), 20), max(int(n * kw["scale"][1]), 16)
     common = dict(laps=kw.get("laps", 10), time_limit=kw.get("time_limit", 180.0), terminate_on_collision=kw.get("terminate_on_collision", True),
                   time_limit_steps=kw.get("time_limit_steps", 0), n_steps=kw.get("n_steps", 10))
-    env = BatchedRaceEnv(t, n, cars, obs_type="lidar_occupancy" if occ else "lidar", auto_reset=True, task=kw.get("task", "maximize_progress"),
+    env = BatchedRaceEnv(t, n, cars, obs_type=kw.get("obs") or "lidar", auto_reset=True, task=kw.get("task", "maximize_progress"),
                          remap_actions=kw.get("remap", False), car_tasks=kw.get("car_tasks"), **common)
     cfg = ro.OracleConfig(num_envs=n, cars_per_env=cars, auto_reset=True, render_occupancy=occ,
                           task=spec.TASK_MAX_SPEED if kw.get("task") == "max_speed" else 0, remap_actions=kw.get("remap", False),
                           car_tasks=None if kw.get("car_tasks") is None else [TASK_IDS[x] for x in kw["car_tasks"]], **common)
     ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=min(16, os.cpu_count() or 1))
+    if occ == "reference":
+        ora.set_frame(t)
     dv = env.reset(mode=mode, seed=5)
     ov = ora.reset(mode=spec.RESET_MODES[mode], seed=5)
     names = EXACT_INT + EXACT_FLOAT + (["lidar_occupancy"] if occ else [])
