@@ -1,8 +1,11 @@
+"""obs_type lidar_occupancy_reference: ms per step and the exact render's own time at some batch sizes (GPU box):
+    python tools/time_exact_render.py [n_envs ...]"""
 import sys, time, torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from racing_dreamer_amd.batched_env import BatchedRaceEnv
 from racing_dreamer_amd import _lib as L
-for n in (2048, 16384, 65536):
+sizes = [int(a) for a in sys.argv[1:]] or [2048, 16384, 65536]
+for n in sizes:
     env = BatchedRaceEnv("austria", n, 1, obs_type="lidar_occupancy_reference", auto_reset=True)
     env.reset(mode="random", seed=0)
     torch.cuda.set_stream(env.stream)
