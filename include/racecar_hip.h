@@ -391,7 +391,9 @@ enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, R
        RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiment: bit 1 = plain instead of non-temporal stores */
        RC_DBG_SCAN_BOUNDED = 5,     /* != 0: the scan runs the build whose trip loop carries a trip budget (see below) */
        RC_DBG_SCAN_ORDER = 6,   /* 0 = production (the scan takes the cars in track order, sorted every 64 observations), 1 = car index order, k > 1 = sorted every k - 1 observations */
-    RC_DBG_COUNT = 7 };
+       RC_DBG_EXACT_CHUNK = 7,  /* k > 0: the exact render (RC_OBS_LIDAR_OCCUPANCY_REFERENCE) works on k cars at a time instead of 2 048
+                                 * (at most the size its scratch was allocated for) */
+    RC_DBG_COUNT = 8 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);
 
 /* The default scan's trip loop is unbounded in the production build (its termination is a property of the tables and
@@ -422,6 +424,11 @@ int rc_selftest_reciprocal(int32_t device, uint64_t *n_checked, uint64_t *n_mism
  * correctly rounded root the spec's np.sqrt is.  Checks every positive binary32 from 2^-60 to 2^10 (587 M values) and zero
  * against the double-precision root rounded once; *n_mismatch must come back 0. */
 int rc_selftest_sqrt(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
+
+/* The exact render (RC_OBS_LIDAR_OCCUPANCY_REFERENCE) divides the spline weights by 6 without a division instruction (a quotient
+ * estimate, its exact remainder by one fused multiply-add, one correction: correctly rounded by Markstein's theorem).  This
+ * compares that with the device's own binary64 division over 2^32 operands from 2^-160 to 8, either sign; n_mismatch must be 0. */
+int rc_selftest_div6(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
 
 const char *rc_last_error(void);
 int rc_abi_version(void);

@@ -26,10 +26,10 @@ GATHER_FULL, GATHER_FULL_U16, GATHER_SUMMARY = range(3)
 GATHER_MODES = {"full": GATHER_FULL, "full-u16": GATHER_FULL_U16, "summary": GATHER_SUMMARY}
 
 # rc_debug_set knobs (experiments / validation only; all 0 in production)
-DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2, DBG_PATCH_VARIANT, DBG_SCAN_BOUNDED, DBG_SCAN_ORDER = range(7)
+DBG_RAY_THREADS, DBG_RAY_SPLIT, DBG_RAY_WG_PER_CU, DBG_BAND_LOG2, DBG_PATCH_VARIANT, DBG_SCAN_BOUNDED, DBG_SCAN_ORDER, DBG_EXACT_CHUNK = range(8)
 DEBUG_KNOBS = {"ray_threads": DBG_RAY_THREADS, "ray_split": DBG_RAY_SPLIT, "ray_wg_per_cu": DBG_RAY_WG_PER_CU,
                "band_log2": DBG_BAND_LOG2, "patch_variant": DBG_PATCH_VARIANT, "scan_bounded": DBG_SCAN_BOUNDED,
-               "scan_order": DBG_SCAN_ORDER}
+               "scan_order": DBG_SCAN_ORDER, "exact_chunk": DBG_EXACT_CHUNK}
 P2P_EXPORT_BYTES = 256
 
 K_DYNAMICS, K_RAYCAST, K_PATCH, K_RESET, K_ACTIONS, K_FTG, K_COUNT = range(7)
@@ -116,6 +116,7 @@ SYMBOLS = {
     "rc_set_arena": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rc_selftest_sqrt": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "rc_selftest_div6": (C.c_int, [C.c_int32, _P(C.c_uint64), _P(C.c_uint64)]),
     "rc_last_error": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),
     "rc_build_id": (C.c_char_p, []),

@@ -439,7 +439,9 @@ int render_reference_patches(rc_env *env) {
     x.drv_words = p.trk.drv_words; x.pitch = p.trk.pitch; x.h = p.trk.h; x.w = p.trk.w;
     x.x = p.st.x; x.y = p.st.y; x.theta = p.st.theta; x.fresh = p.st.fresh;
     x.patch = p.out.patch;                                   // (rc_set_arena may have moved the outputs)
-    TIMED(env, RC_K_PATCH, rck_launch_patch_exact(x, env->exact_chunk, env->stream));
+    int chunk = env->exact_chunk;
+    if (env->dbg[RC_DBG_EXACT_CHUNK] > 0 && env->dbg[RC_DBG_EXACT_CHUNK] < chunk) chunk = env->dbg[RC_DBG_EXACT_CHUNK];
+    TIMED(env, RC_K_PATCH, rck_launch_patch_exact(x, chunk, env->stream));
     return RC_OK;
 }
 
@@ -613,6 +615,22 @@ int rc_selftest_sqrt(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch) 
     (void)hipFree(dev);
     if (e != hipSuccess) return fail(RC_ERR_HIP, "rc_selftest_sqrt: %s", hipGetErrorString(e));
     *n_checked = (uint64_t)(hi_bits - lo_bits + 1u) + 1u;
+    *n_mismatch = host;
+    return RC_OK;
+}
+
+int rc_selftest_div6(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch) {
+    if (!n_checked || !n_mismatch) return fail(RC_ERR_INVALID, "NULL output pointer");
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long *dev = nullptr, host = 0;
+    HIP_TRY(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemset(dev, 0, sizeof(host));
+    const int blocks = 4096, threads = 256, per_lane = 4096;          // 2^32 operands
+    if (e == hipSuccess) e = rck_launch_selftest_div6(blocks, threads, per_lane, dev, nullptr);
+    if (e == hipSuccess) e = hipMemcpy(&host, dev, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(RC_ERR_HIP, "rc_selftest_div6: %s", hipGetErrorString(e));
+    *n_checked = (uint64_t)blocks * threads * per_lane;
     *n_mismatch = host;
     return RC_OK;
 }

@@ -200,5 +200,6 @@ hipError_t rck_launch_ftg(const RcParams &p, float *actions, float motor_straigh
 hipError_t rck_launch_ftg_reference(const RcParams &p, float *actions, float *prev_heading, float dt, float *detail, hipStream_t s);
 hipError_t rck_launch_selftest_rcp(uint32_t exp_lo, uint32_t exp_hi, unsigned long long *mismatches_dev, hipStream_t s);
 hipError_t rck_launch_selftest_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches_dev, hipStream_t s);
+hipError_t rck_launch_selftest_div6(int blocks, int threads, int per_lane, unsigned long long *mismatches_dev, hipStream_t s);
 hipError_t rck_launch_random_actions(float *actions, int n_cars, uint32_t first_car, uint32_t seed_lo,
                                      uint32_t seed_hi, uint32_t step, hipStream_t s);

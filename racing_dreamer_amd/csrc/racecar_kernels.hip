@@ -2027,6 +2027,11 @@ hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStr
     return hipGetLastError();
 }
 
+hipError_t rck_launch_selftest_div6(int blocks, int threads, int per_lane, unsigned long long *mismatches_dev, hipStream_t s) {
+    hipLaunchKernelGGL(rc_selftest_div6_kernel, dim3(blocks), dim3(threads), 0, s, 0x243f6a8885a308d3ull, per_lane, mismatches_dev);
+    return hipGetLastError();
+}
+
 hipError_t rck_launch_selftest_sqrt(uint32_t lo_bits, uint32_t hi_bits, unsigned long long *mismatches_dev, hipStream_t s) {
     hipLaunchKernelGGL(rc_selftest_sqrt_kernel, dim3(4096), dim3(256), 0, s, lo_bits, hi_bits, mismatches_dev);
     return hipGetLastError();

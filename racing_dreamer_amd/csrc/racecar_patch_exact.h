@@ -25,6 +25,10 @@
 #define PX_OUT 64
 #define PX_KSIZE 15
 #define PX_BITS 22
+#define PX_T 25                               // the sample kernel renders the 200 x 200 window in 8 x 8 tiles of 25 x 25 pixels (40: 11 % slower,
+                                              // 20: 2 %, 10: 40 % - tools/exact_tile_sweep.sh)
+#define PX_TILE_N 41                          // a tile's taps lie within 24 sqrt(2) + 7 = 40.9 coefficients per axis
+#define PX_TILE_PITCH 41                      // doubles per staged column (odd: consecutive columns start in different LDS banks)
 #define PX_Z (-0.2679491924311227)            // scipy ni_splines.c: the cubic spline's pole, sqrt(3) - 2 correctly rounded
 #define PX_ZN (-5.539710763905135e-126)       // pow(PX_Z, 219)
 #define PX_PI180 1.74532925199432957692e-2
@@ -58,11 +62,23 @@ __device__ __forceinline__ void sincos_deg(double x, double &cosv, double &sinv)
     sinv = j == 0 ? sp : (j == 2 ? cp : (j == 4 ? -sp : -cp));
 }
 
+// x / 6.0, correctly rounded, without the division: q = RN(x r) with r = RN(1 / 6) is a faithful quotient, the remainder
+// x - 6 q is exact in one fused multiply-add, and RN(q + rem r) is the correctly rounded quotient (Markstein's theorem; 6 has no
+// all-ones significand, and the operands here - spline weights' numerators, 2^-159 .. 8 - are far from underflow).  The compiler's
+// own expansion of a binary64 division is ~12 instructions around a quarter-rate v_rcp_f64; a pixel needs six such quotients.
+// `rc_selftest_div6` compares the two on the device over 2^32 operands (tests/test_gpu_api.py).
+__device__ __forceinline__ double div6(double x) {
+    const double r = 1.0 / 6.0;
+    const double q = x * r;
+    const double rem = __builtin_fma(-6.0, q, x);
+    return __builtin_fma(rem, r, q);
+}
+
 __device__ __forceinline__ void weights(double cc, double (&w)[4]) {
     const double y = cc - floor(cc), z = 1.0 - y;
-    w[1] = ((y * y) * (y - 2.0) * 3.0 + 4.0) / 6.0;
-    w[2] = ((z - 2.0) * (z * z) * 3.0 + 4.0) / 6.0;
-    w[0] = ((z * z) * z) / 6.0;
+    w[1] = div6((y * y) * (y - 2.0) * 3.0 + 4.0);
+    w[2] = div6((z - 2.0) * (z * z) * 3.0 + 4.0);
+    w[0] = div6((z * z) * z);
     w[3] = ((1.0 - w[0]) - w[1]) - w[2];
 }
 
@@ -157,7 +173,14 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
         for (int q = t; q < PX_OUT * PX_OUT / 16; q += 256) reinterpret_cast<uint4 *>(out)[q] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    __shared__ uint8_t win[PX_WIN * PX_WIN];
+    // The 200 x 200 window is rendered in 8 x 8 tiles of PX_T x PX_T pixels.  A tile's taps lie in a rectangle of the coefficient
+    // array at most 41 x 41 large (the tile rotated, + the 4 x 4 footprint): it is staged in LDS first - coalesced column segments -
+    // and the 16 taps per pixel are LDS reads.  Read straight from memory (the first form) a wave's 64 taps of one load instruction
+    // lay in up to 64 different cache lines, and the texture-address unit, not the arithmetic, set the pace: 1.51 ms per 2 048
+    // cars; more workgroups per CU made it worse (their 387 KB arrays push each other out of the XCD's L2:
+    // tools/exact_strip_sweep.sh).  A row of tiles is resized horizontally as soon as it is complete.
+    __shared__ double tile[PX_TILE_N * PX_TILE_PITCH];
+    __shared__ uint8_t win[PX_T * PX_WIN];
     __shared__ uint8_t tmp[PX_WIN * PX_OUT];
     __shared__ int32_t kk[PX_OUT * PX_KSIZE];
     __shared__ int32_t bounds[PX_OUT * 2];
@@ -179,40 +202,76 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
     const double h0 = (double)(S0 - 1) / 2, h1 = (double)(S1 - 1) / 2;
     const double off0 = (double)(PX_CROP - 1) / 2 - (cs * h0 + sn * h1), off1 = (double)(PX_CROP - 1) / 2 - (-sn * h0 + cs * h1);
     const int i0 = S0 / 2 - PX_WIN / 2, j0 = S1 / 2 - PX_WIN / 2;
-    for (int q = t; q < PX_WIN * PX_WIN; q += 256) {
-        const int i = q / PX_WIN, j = q - i * PX_WIN;
-        const double o0 = (double)(i0 + i), o1 = (double)(j0 + j);
-        const double cc0 = ((0.0 + o0 * cs) + o1 * sn) + off0, cc1 = ((0.0 + o0 * (-sn)) + o1 * cs) + off1;
-        double tv = 0.0;
-        if (!(cc0 < 0 || cc0 > PX_CROP - 1 || cc1 < 0 || cc1 > PX_CROP - 1)) {
-            double w0[4], w1[4];
-            px::weights(cc0, w0);
-            px::weights(cc1, w1);
-            const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
-            int col[4];
+    auto src0 = [&](int i, int j) { return ((0.0 + (double)(i0 + i) * cs) + (double)(j0 + j) * sn) + off0; };        // the library's expression
+    auto src1 = [&](int i, int j) { return ((0.0 + (double)(i0 + i) * (-sn)) + (double)(j0 + j) * cs) + off1; };
+    for (int ti = 0; ti < PX_WIN / PX_T; ++ti) {
+        for (int tj = 0; tj < PX_WIN / PX_T; ++tj) {
+            // the rectangle of coefficients this tile's taps can touch: the map is linear, so its extremes are at the tile's corners;
+            // two cells of margin beyond the 4 x 4 footprint (rounding of the corner values, mirrored taps at the array's edges)
+            const int ia = ti * PX_T, ib = ia + PX_T - 1, ja = tj * PX_T, jb = ja + PX_T - 1;
+            const double r00 = src0(ia, ja), r01 = src0(ia, jb), r10 = src0(ib, ja), r11 = src0(ib, jb);
+            const double c00 = src1(ia, ja), c01 = src1(ia, jb), c10 = src1(ib, ja), c11 = src1(ib, jb);
+            const double rmin = fmin(fmin(r00, r01), fmin(r10, r11)), rmax = fmax(fmax(r00, r01), fmax(r10, r11));
+            const double cmin = fmin(fmin(c00, c01), fmin(c10, c11)), cmax = fmax(fmax(c00, c01), fmax(c10, c11));
+            const bool none = rmax < -0.5 || rmin > PX_CROP - 0.5 || cmax < -0.5 || cmin > PX_CROP - 0.5;      // every pixel of the tile reads the constant 0
+            int r_lo = (int)floor(rmin) - 3, r_hi = (int)floor(rmax) + 4, c_lo = (int)floor(cmin) - 3, c_hi = (int)floor(cmax) + 4;
+            r_lo = r_lo < 0 ? 0 : r_lo; c_lo = c_lo < 0 ? 0 : c_lo;
+            r_hi = r_hi > PX_CROP - 1 ? PX_CROP - 1 : r_hi; c_hi = c_hi > PX_CROP - 1 ? PX_CROP - 1 : c_hi;
+            const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
+            const bool staged = !none && nr > 0 && nc > 0 && nr <= PX_TILE_N && nc <= PX_TILE_N;      // (always, by the bound above; else: straight from memory)
+            if (staged)
+                for (int q = t; q < nr * nc; q += 256) {
+                    const int c = q / nr, r = q - c * nr;
+                    tile[c * PX_TILE_PITCH + r] = coef[(c_lo + c) * PX_CROP + r_lo + r];
+                }
+            __syncthreads();
+            for (int q = t; q < PX_T * PX_T; q += 256) {
+                const int il = q / PX_T, jl = q - il * PX_T, i = ia + il, j = ja + jl;
+                const double cc0 = src0(i, j), cc1 = src1(i, j);
+                double tv = 0.0;
+                if (!(cc0 < 0 || cc0 > PX_CROP - 1 || cc1 < 0 || cc1 > PX_CROP - 1)) {
+                    double w0[4], w1[4];
+                    px::weights(cc0, w0);
+                    px::weights(cc1, w1);
+                    const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
+                    if (staged) {
+                        int col[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) col[b] = px::mirror(st1 + b) * PX_CROP;
+                        for (int b = 0; b < 4; ++b) col[b] = (px::mirror(st1 + b) - c_lo) * PX_TILE_PITCH - r_lo;
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int row = px::mirror(st0 + a);
+                        for (int a = 0; a < 4; ++a) {
+                            const int row = px::mirror(st0 + a);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) tv = tv + (coef[col[b] + row] * w0[a]) * w1[b];
+                            for (int b = 0; b < 4; ++b) tv = tv + (tile[col[b] + row] * w0[a]) * w1[b];
+                        }
+                    } else {
+                        int col[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) col[b] = px::mirror(st1 + b) * PX_CROP;
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const int row = px::mirror(st0 + a);
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) tv = tv + (coef[col[b] + row] * w0[a]) * w1[b];
+                        }
+                    }
+                }
+                tv = tv > 0 ? tv + 0.5 : 0.0;
+                win[il * PX_WIN + j] = (uint8_t)(tv > 255.0 ? 255.0 : tv);
             }
+            __syncthreads();          // (the next tile's staging overwrites `tile`)
         }
-        tv = tv > 0 ? tv + 0.5 : 0.0;
-        win[q] = (uint8_t)(tv > 255.0 ? 255.0 : tv);
+        // Pillow's 8-bit resize, horizontal pass, this row of tiles: PX_T rows x 64 columns
+        for (int q = t; q < PX_T * PX_OUT; q += 256) {
+            const int r = q / PX_OUT, xx = q - r * PX_OUT;
+            const int x0 = bounds[2 * xx], xm = bounds[2 * xx + 1];
+            int32_t acc = 1 << (PX_BITS - 1);
+            for (int k = 0; k < xm; ++k) acc += (int32_t)win[r * PX_WIN + x0 + k] * kk[xx * PX_KSIZE + k];
+            acc >>= PX_BITS;
+            tmp[ti * PX_T * PX_OUT + q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // Pillow's 8-bit resize, horizontal pass: 200 rows x 64 columns
-    for (int q = t; q < PX_WIN * PX_OUT; q += 256) {
-        const int r = q / PX_OUT, xx = q - r * PX_OUT;
-        const int x0 = bounds[2 * xx], xm = bounds[2 * xx + 1];
-        int32_t acc = 1 << (PX_BITS - 1);
-        for (int k = 0; k < xm; ++k) acc += (int32_t)win[r * PX_WIN + x0 + k] * kk[xx * PX_KSIZE + k];
-        acc >>= PX_BITS;
-        tmp[q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
-    }
-    __syncthreads();
     // ... vertical pass: 64 x 64, written once
     for (int q = t; q < PX_OUT * PX_OUT; q += 256) {
         const int yy = q / PX_OUT, xx = q - yy * PX_OUT;
@@ -222,4 +281,21 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
         acc >>= PX_BITS;
         out[q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
     }
+}
+
+// x / 6.0 by the hardware's division against px::div6, bit for bit, over `n` operands per lane drawn by a 64-bit LCG from
+// [2^-160, 8) with either sign (exponent uniform, significand uniform): the count of disagreements (rc_selftest_div6)
+__global__ __launch_bounds__(256) void rc_selftest_div6_kernel(unsigned long long seed, int n, unsigned long long *mismatches) {
+    unsigned long long s = seed + 0x9e3779b97f4a7c15ull * (unsigned long long)(blockIdx.x * blockDim.x + threadIdx.x + 1u);
+    unsigned long long bad = 0;
+    for (int k = 0; k < n; ++k) {
+        s = s * 6364136223846793005ull + 1442695040888963407ull;
+        const unsigned long long mant = s >> 12;
+        const unsigned long long e = 1023ull - 160ull + ((s >> 3) & 0xffull) % 163ull;          // 2^-160 .. 2^2
+        const unsigned long long bits = ((s & 1ull) << 63) | (e << 52) | mant;
+        const double x = __longlong_as_double((long long)bits);
+        const double a = x / 6.0, b = px::div6(x);
+        bad += __double_as_longlong(a) != __double_as_longlong(b) ? 1ull : 0ull;
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }

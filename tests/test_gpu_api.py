@@ -359,6 +359,20 @@ def test_sqrt_selftest_is_exact_on_this_device():
     L.check(lib.rc_selftest_sqrt(0, C.byref(n), C.byref(bad)))
     assert n.value == 70 * (1 << 23) + 1 and bad.value == 0
 
+def test_division_by_six_without_a_division_is_exact_on_this_device():
+    """The exact render's spline weights are divided by 6 through a quotient estimate, its exact remainder (one fused
+    multiply-add) and one correction - correctly rounded by Markstein's theorem - instead of the ~12-instruction expansion of a
+    binary64 division: bit-equal to the device's own division over 2^32 operands from 2^-160 to 8 of either sign."""
+    import ctypes as C
+    import torch
+    from racing_dreamer_amd import _lib as L
+    torch.cuda.init()
+    lib = L.load_library()
+    n, bad = C.c_uint64(0), C.c_uint64(0)
+    L.check(lib.rc_selftest_div6(0, C.byref(n), C.byref(bad)))
+    assert n.value == 1 << 32 and bad.value == 0
+
+
 def test_a_lab_library_built_against_other_headers_is_refused(tmp_path):
     """RcParams and RcLaunchInfo cross the lab boundary by pointer, so a lab library built against other headers would
     read them wrongly - wrong scans or a GPU fault, no error.  The lab says what it was built against (`rclab_abi`: struct sizes
