@@ -75,7 +75,7 @@ enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1,                  /* dream.p
        RC_OBS_LIDAR_OCCUPANCY_REFERENCE = 2 };   /* lidar_occupancy computed EXACTLY as the reference's OccupancyMapObs.step does
                                                   * (dreamer/wrappers.py:396-406: to_pixel, 220 x 220 crop, cubic-spline rotation,
                                                   * centre crop, antialiased bicubic resize) instead of by the one-tap sampler of
-                                                  * RC_OBS_LIDAR_OCCUPANCY: bit-identical to the reference's patches, ~100 x the cost;
+                                                  * RC_OBS_LIDAR_OCCUPANCY: bit-identical to the reference's patches, ~1 000 x the render's cost;
                                                   * needs rc_set_source_frame */
 /* what RC_F_LIDAR holds: metres, or the caller-side scaling fused into the scan's store */
 enum { RC_LIDAR_METRES = 0,
