@@ -779,14 +779,6 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
             except Exception:                                      # noqa: BLE001 - without it a failed leg is still caught by the deadline
                 store = None
             guard.set_store(store)
-            if via == "abi":
-                if args.backend != "nccl":
-                    via = "torch"                       # RCCL wants one GPU per rank; the gloo functional tests share one
-                else:
-                    ids = [BatchedRaceEnv.comm_unique_id() if rank == 0 else None]
-                    dist.broadcast_object_list(ids, src=0)
-                    env.comm_init(ids[0], rank, world)
-                    abi_ranks = env.comm_count()
         # The env of stage 1 has done its work.  The headline runs on an env - and so on a stream - created AFTER the communicator:
         # with the env's stream older than the communicator's, the sharded loop ran 0.237 ms per step where it takes 0.207 the other
         # way round (one rank over RCCL, alternating on one box: profiles/r06_i_ab_stream_order_one_rank.txt; the scan itself is
@@ -797,6 +789,15 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
                 old_env, env = env, make_env()
                 old_env.close()
                 step_no = 0
+        if via == "abi":                                # the C-ABI's own communicator belongs to the env the headline runs on
+            with guard.leg("abi_communicator", budget_s=min(args.leg_timeout, 60.0)):
+                if args.backend != "nccl":
+                    via = "torch"                       # RCCL wants one GPU per rank; the gloo functional tests share one
+                else:
+                    ids = [BatchedRaceEnv.comm_unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    env.comm_init(ids[0], rank, world)
+                    abi_ranks = env.comm_count()
         if rank == 0:
             print(f"bench.py: {world} ranks joined ({args.backend}), {guard.time_left():.0f} s of the time budget left; rank 0 alone: "
                   f"{local['env_steps_per_s_this_rank'] / 1e6:.1f} M env-steps/s", file=sys.stderr, flush=True)
