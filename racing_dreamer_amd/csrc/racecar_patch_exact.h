@@ -149,21 +149,25 @@ __device__ __forceinline__ void px_filter_line_lds(double *line) {
 // lanes write the lines out - so a pass costs one read and one write of the array (axis 0: the write alone) where the first form
 // of this kernel (forward values through memory) moved 3.5 MB per car at 4.6 TB/s of HBM traffic.  64 lines are in flight per CU
 // (160 KB of LDS hold 92); the waves run out of step with one another, so loads, recursions and stores of different waves overlap.
-#define PX_NBW 8
+#define PX_NBW 10
+#define PX_PF_WAVES 4                           // waves per workgroup of the prefilter kernel (PX_PF_WAVES x PX_NBW lines in LDS at a time)
 #define PX_LPITCH 221
-__global__ __launch_bounds__(256) void rc_patch_exact_prefilter_kernel(RcExactParams p) {
+#define PX_RPW ((PX_CROP + 63) / 64)             // passes of the wave over a line (axis 0)
+#define PX_IPW (64 / PX_NBW)                    // columns of a batch one pass of the wave covers (axis 1)
+#define PX_NIT ((PX_CROP + PX_IPW - 1) / PX_IPW) // passes per batch
+__global__ __launch_bounds__(64 * PX_PF_WAVES, 2) void rc_patch_exact_prefilter_kernel(RcExactParams p) {
     const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
     if (px::skip_car(p, car)) return;                                  // (uniform over the workgroup)
     double *colmaj = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [c][r]
-    __shared__ double lines[4][PX_NBW][PX_LPITCH];
-    __shared__ uint32_t cropw[PX_CROP][8];                             // the crop's rows as bits: bit k of the row = cell column gxw * 32 + k
+    __shared__ double lines[PX_PF_WAVES][PX_NBW][PX_LPITCH];
+    __shared__ uint32_t cropw[PX_CROP][9];                             // the crop's rows as bits: bit k of the row = cell column gxw * 32 + k
     const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
     (void)z;
     int pr, pc;
     px::pixel_of(p, car, pr, pc);
     const int gx0 = (pc - PX_CROP / 2) - p.c0;                        // grid column of crop column 0 (may be negative)
     const int gxw = gx0 >> 5;                                          // its word (floor)
-    for (int q = t; q < PX_CROP * 8; q += 256) {
+    for (int q = t; q < PX_CROP * 8; q += 64 * PX_PF_WAVES) {
         const int r = q >> 3, k = q & 7, gy = p.r_top - (pr - PX_CROP / 2 + r), gw = gxw + k;
         uint32_t word = 0;
         if ((unsigned)gy < (unsigned)p.h && (unsigned)gw < (unsigned)p.pitch) {
@@ -177,36 +181,59 @@ __global__ __launch_bounds__(256) void rc_patch_exact_prefilter_kernel(RcExactPa
     const int wave = t >> 6, lane = t & 63;
     double (*mine)[PX_LPITCH] = lines[wave];
     // ---- axis 0: a line = a column of the crop (north-up: crop row r is grid row r_top - (pr - 110 + r))
-    for (int b = wave; b * PX_NBW < PX_CROP; b += 4) {
+    for (int b = wave; b * PX_NBW < PX_CROP; b += PX_PF_WAVES) {
         const int c0 = b * PX_NBW;
-        for (int q = lane; q < PX_NBW * PX_CROP; q += 64) {
-            const int l = q / PX_CROP, r = q - l * PX_CROP, bitpos = (gx0 + c0 + l) - gxw * 32;
-            const uint32_t bit = (c0 + l < PX_CROP) ? (cropw[r][bitpos >> 5] >> (bitpos & 31)) & 1u : 0u;
-            mine[l][r] = bit ? 1.0 * gain : 0.0 * gain;
+#pragma unroll
+        for (int l = 0; l < PX_NBW; ++l) {
+            const int bitpos = (gx0 + c0 + l) - gxw * 32;              // (uniform over the wave)
+#pragma unroll
+            for (int k = 0; k < PX_RPW; ++k) {
+                const int r = lane + 64 * k;
+                if (r < PX_CROP) {
+                    const uint32_t bit = (c0 + l < PX_CROP) ? (cropw[r][bitpos >> 5] >> (bitpos & 31)) & 1u : 0u;
+                    mine[l][r] = bit ? gain : 0.0;                     // (1.0 * gain, 0.0 * gain)
+                }
+            }
         }
         __builtin_amdgcn_wave_barrier();                               // (one wave: its own LDS writes, in order)
         if (lane < PX_NBW && c0 + lane < PX_CROP) px_filter_line_lds(mine[lane]);
         __builtin_amdgcn_wave_barrier();
-        for (int q = lane; q < PX_NBW * PX_CROP; q += 64) {
-            const int l = q / PX_CROP, r = q - l * PX_CROP;
-            if (c0 + l < PX_CROP) colmaj[(size_t)(c0 + l) * PX_CROP + r] = mine[l][r];
-        }
+#pragma unroll
+        for (int l = 0; l < PX_NBW; ++l)
+#pragma unroll
+            for (int k = 0; k < PX_RPW; ++k) {
+                const int r = lane + 64 * k;
+                if (r < PX_CROP && c0 + l < PX_CROP) colmaj[(size_t)(c0 + l) * PX_CROP + r] = mine[l][r];
+            }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();          // every column's result is visible to the whole workgroup (global memory, same CU)
-    // ---- axis 1: a line = a row; element (row r, column i) lies at colmaj[i * 220 + r]
-    for (int b = wave; b * PX_NBW < PX_CROP; b += 4) {
+    // ---- axis 1: a line = a row; element (row r, column i) lies at colmaj[i * 220 + r].  The next batch's rows are fetched into
+    // registers BEFORE this batch's recursions start (they are other rows than the ones this batch writes), so the memory latency
+    // of a fill hides behind the dependent chains instead of standing in front of them.
+    double pre[PX_NIT];
+    const int li = lane / PX_NBW, ll = lane - li * PX_NBW;            // lane = (column within a pass of PX_IPW columns, line)
+    auto fetch = [&](int r0) {
+        const double *src = colmaj + (size_t)li * PX_CROP + r0 + ll;
+#pragma unroll
+        for (int k = 0; k < PX_NIT; ++k)
+            pre[k] = (li < PX_IPW && li + PX_IPW * k < PX_CROP && r0 + ll < PX_CROP) ? src[(size_t)k * (PX_IPW * PX_CROP)] : 0.0;
+    };
+    if (wave * PX_NBW < PX_CROP) fetch(wave * PX_NBW);
+    for (int b = wave; b * PX_NBW < PX_CROP; b += PX_PF_WAVES) {
         const int r0 = b * PX_NBW;
-        for (int q = lane; q < PX_NBW * PX_CROP; q += 64) {
-            const int i = q >> 3, l = q & 7;
-            mine[l][i] = (r0 + l < PX_CROP) ? colmaj[(size_t)i * PX_CROP + r0 + l] * gain : 0.0;      // the second pass scales its input too
-        }
+#pragma unroll
+        for (int k = 0; k < PX_NIT; ++k)
+            if (li < PX_IPW && li + PX_IPW * k < PX_CROP) mine[ll][li + PX_IPW * k] = pre[k] * gain;      // the second pass scales its input too
         __builtin_amdgcn_wave_barrier();
+        if ((b + PX_PF_WAVES) * PX_NBW < PX_CROP) fetch((b + PX_PF_WAVES) * PX_NBW);
         if (lane < PX_NBW && r0 + lane < PX_CROP) px_filter_line_lds(mine[lane]);
         __builtin_amdgcn_wave_barrier();
-        for (int q = lane; q < PX_NBW * PX_CROP; q += 64) {
-            const int i = q >> 3, l = q & 7;
-            if (r0 + l < PX_CROP) colmaj[(size_t)i * PX_CROP + r0 + l] = mine[l][i];
+        {
+            double *dst = colmaj + (size_t)li * PX_CROP + r0 + ll;
+#pragma unroll
+            for (int k = 0; k < PX_NIT; ++k)
+                if (li < PX_IPW && li + PX_IPW * k < PX_CROP && r0 + ll < PX_CROP) dst[(size_t)k * (PX_IPW * PX_CROP)] = mine[ll][li + PX_IPW * k];
         }
         __builtin_amdgcn_wave_barrier();
     }
