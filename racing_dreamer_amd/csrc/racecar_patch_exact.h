@@ -27,8 +27,9 @@
 #define PX_BITS 22
 #define PX_T 25                               // the sample kernel renders the 200 x 200 window in 8 x 8 tiles of 25 x 25 pixels (40: 11 % slower,
                                               // 20: 2 %, 10: 40 % - tools/exact_tile_sweep.sh)
-#define PX_TILE_N 41                          // a tile's taps lie within 24 sqrt(2) + 7 = 40.9 coefficients per axis
-#define PX_TILE_PITCH 41                      // doubles per staged column (odd: consecutive columns start in different LDS banks)
+#define PX_TW 20                              // ... of PX_T rows x PX_TW columns: 500 pixels = two passes of 256 threads at 98 % (25 x 25: three at 81 %)
+#define PX_TILE_N 39                          // a tile's taps lie within sqrt(24^2 + 19^2) + 9 = 39.6 coefficients per axis
+#define PX_TILE_PITCH 39                      // doubles per staged column (odd: consecutive columns start in different LDS banks)
 #define PX_Z (-0.2679491924311227)            // scipy ni_splines.c: the cubic spline's pole, sqrt(3) - 2 correctly rounded
 #define PX_ZN (-5.539710763905135e-126)       // pow(PX_Z, 219)
 #define PX_PI180 1.74532925199432957692e-2
@@ -196,7 +197,9 @@ __global__ __launch_bounds__(64 * PX_PF_WAVES, 2) void rc_patch_exact_prefilter_
             }
         }
         __builtin_amdgcn_wave_barrier();                               // (one wave: its own LDS writes, in order)
+#ifndef PX_EXP_NO_CHAIN
         if (lane < PX_NBW && c0 + lane < PX_CROP) px_filter_line_lds(mine[lane]);
+#endif
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int l = 0; l < PX_NBW; ++l)
@@ -227,7 +230,9 @@ __global__ __launch_bounds__(64 * PX_PF_WAVES, 2) void rc_patch_exact_prefilter_
             if (li < PX_IPW && li + PX_IPW * k < PX_CROP) mine[ll][li + PX_IPW * k] = pre[k] * gain;      // the second pass scales its input too
         __builtin_amdgcn_wave_barrier();
         if ((b + PX_PF_WAVES) * PX_NBW < PX_CROP) fetch((b + PX_PF_WAVES) * PX_NBW);
+#ifndef PX_EXP_NO_CHAIN
         if (lane < PX_NBW && r0 + lane < PX_CROP) px_filter_line_lds(mine[lane]);
+#endif
         __builtin_amdgcn_wave_barrier();
         {
             double *dst = colmaj + (size_t)li * PX_CROP + r0 + ll;
@@ -239,12 +244,153 @@ __global__ __launch_bounds__(64 * PX_PF_WAVES, 2) void rc_patch_exact_prefilter_
     }
 }
 
+// ------------------------------------------------------------------------------------------ prefilter, lines in registers
+// The same arithmetic with a line per LANE: 4 waves x 55 lanes = the 220 lines of an axis at once, a line's 220 values in the lane's
+// registers (PXR_REG of them) and LDS (the rest) - what bounds the LDS form is lines in flight per CU (80) over the 45 cycles a
+// step of a recursion takes (tools/ubench/f64_chain.hip), and a CU's registers hold three times what its LDS holds.  Every loop over
+// a line is fully unrolled, so every register index is a constant.  Axis 0 (lane = column): the column's bits from the staged crop,
+// results of the backward pass through a 55 x 16 LDS tile per wave so that they reach memory [column][row] in 128-byte runs.
+// Axis 1 (lane = row): [column][row] is contiguous across lanes, so the 220 loads of the fill go out back to back and the backward
+// pass stores from registers.
+#define PX_PREFILTER_REG 1
+#define PXR_REG 161
+#define PXR_LDS (PX_CROP - PXR_REG)
+#define PXR_LANES 55
+#define PXR_TB 16
+#define PXR_TPITCH 17
+#define PXR_SB 8                                // the scheduler may move code within blocks of this many steps only (else it
+                                                // hoists hundreds of loads and spills)
+#define PXR_LINES (PX_CROP + 4)                 // + one dummy line per wave for the idle lanes 55 .. 63
+
+template <class Emit, class Block>
+__device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl, Emit emit, Block block) {
+    const double z = PX_Z, zn = PX_ZN;
+#define PXR_GET(i) ((i) < PXR_REG ? +S[(i) < PXR_REG ? (i) : 0] : +sl[(i) < PXR_REG ? 0 : (i) - PXR_REG])      // (rvalues: no pointer select)
+#define PXR_PUT(i, v) do { if ((i) < PXR_REG) S[(i) < PXR_REG ? (i) : 0] = (v); else sl[(i) < PXR_REG ? 0 : (i) - PXR_REG] = (v); } while (0)
+    double c0 = PXR_GET(0) + zn * PXR_GET(PX_CROP - 1), zi = z;
+#pragma unroll
+    for (int i = 1; i < PX_CROP - 1; ++i) {
+        c0 = c0 + zi * (PXR_GET(i) + zn * PXR_GET(PX_CROP - 1 - i));
+        zi *= z;
+        if (i % PXR_SB == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    double v = c0 / (1.0 - zn * zn), prev = 0.0;
+    PXR_PUT(0, v);
+#pragma unroll
+    for (int i = 1; i < PX_CROP; ++i) {
+        prev = v;
+        v = PXR_GET(i) + z * v;
+        PXR_PUT(i, v);
+        if (i % PXR_SB == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    v = (z * prev + v) * z / (z * z - 1.0);
+    emit(PX_CROP - 1, v);
+    // (blocks of PXR_TB steps: a loop whose body held the block's work at every step would exceed the unroller's size limit, be
+    // unrolled in part only, and leave the register array in scratch memory)
+#pragma unroll
+    for (int m = (PX_CROP - 1) / PXR_TB; m >= 0; --m) {
+#pragma unroll
+        for (int k = PXR_TB - 1; k >= 0; --k) {
+            const int i = PXR_TB * m + k;
+            if (i <= PX_CROP - 2) {
+                v = z * (v - PXR_GET(i));
+                emit(i, v);
+            }
+            if (k == PXR_SB) __builtin_amdgcn_sched_barrier(0);
+        }
+        block(PXR_TB * m);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_reg_kernel(RcExactParams p) {
+    const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
+    if (px::skip_car(p, car)) return;                                  // (uniform over the workgroup)
+    double *colmaj = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [c][r]
+    __shared__ double slds[PXR_LINES][PXR_LDS | 1];                    // (odd pitch: the lanes of a step fall into different banks)
+    __shared__ double tile[4][64][PXR_TPITCH];
+    __shared__ uint32_t cropw[PX_CROP][9];
+    const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
+    int pr, pc;
+    px::pixel_of(p, car, pr, pc);
+    const int gx0 = (pc - PX_CROP / 2) - p.c0, gxw = gx0 >> 5;
+    for (int q = t; q < PX_CROP * 8; q += 256) {
+        const int r = q >> 3, k = q & 7, gy = p.r_top - (pr - PX_CROP / 2 + r), gw = gxw + k;
+        uint32_t word = 0;
+        if ((unsigned)gy < (unsigned)p.h && (unsigned)gw < (unsigned)p.pitch) {
+            word = p.drv_words[(size_t)gy * p.pitch + gw];
+            const int first = gw * 32;
+            if (first + 32 > p.w) word &= first >= p.w ? 0u : (0xffffffffu >> (32 - (p.w - first)));
+        }
+        cropw[r][k] = word;
+    }
+    __syncthreads();
+    const int wave = t >> 6, lane = t & 63;
+    const bool act = lane < PXR_LANES;
+    const int n = act ? wave * PXR_LANES + lane : PX_CROP + wave;      // the lane's line (idle lanes share a dummy line)
+    double *sl = slds[n];
+    double (*tl)[PXR_TPITCH] = tile[wave];
+    double S[PXR_REG];
+    // ---- axis 0: the line = column n of the crop
+    {
+        const int bitpos = (gx0 + (act ? n : 0)) - gxw * 32, wq = bitpos >> 5, sh = bitpos & 31;
+        uint32_t colbits[(PX_CROP + 31) / 32];                         // the column's 220 cells, 32 LDS reads in flight at a time
+#pragma unroll
+        for (int wi = 0; wi < (PX_CROP + 31) / 32; ++wi) {
+            uint32_t w32[32];
+#pragma unroll
+            for (int b = 0; b < 32; ++b) w32[b] = (32 * wi + b < PX_CROP) ? cropw[32 * wi + b < PX_CROP ? 32 * wi + b : 0][wq] : 0u;
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < 32; ++b) acc |= ((w32[b] >> sh) & 1u) << b;
+            colbits[wi] = acc;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < PX_CROP; ++i) {
+            const double f = ((colbits[i >> 5] >> (i & 31)) & 1u) ? gain : 0.0;        // (1.0 * gain, 0.0 * gain)
+            PXR_PUT(i, f);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int cq = lane >> 4, k = lane & 15;
+        pxr_filter_line(S, sl, [&](int i, double v) { tl[lane][i & (PXR_TB - 1)] = v; },
+            [&](int i) {                                               // rows i .. i + 15 of the wave's 55 columns are complete
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int pass = 0; pass < (PXR_LANES + 3) / 4; ++pass) {
+                    const int cl = 4 * pass + cq;
+                    if (cl < PXR_LANES && i + k < PX_CROP) colmaj[(size_t)(wave * PXR_LANES + cl) * PX_CROP + i + k] = tl[cl][k];
+                }
+                __builtin_amdgcn_wave_barrier();
+            });
+    }
+    __syncthreads();          // every column's result is visible to the whole workgroup (global memory, same CU)
+    // ---- axis 1: the line = row n; element (row n, column i) lies at colmaj[i * 220 + n]
+    {
+        double *mine = colmaj + (act ? n : wave * PXR_LANES);          // (idle lanes read a neighbour's row - no branch around the loads,
+                                                                       //  or every one of them gets a wait of its own - and store nothing)
+#pragma unroll
+        for (int i = PXR_REG; i < PX_CROP; ++i) PXR_PUT(i, mine[(size_t)i * PX_CROP] * gain);      // the second pass scales its input too
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < PXR_REG; ++i) S[i] = mine[(size_t)i * PX_CROP];                        // 161 loads in flight, then
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < PXR_REG; ++i) S[i] = S[i] * gain;
+        __builtin_amdgcn_sched_barrier(0);
+        pxr_filter_line(S, sl, [&](int i, double v) { if (act) mine[(size_t)i * PX_CROP] = v; }, [](int) {});
+    }
+}
+
 // ------------------------------------------------------------------------------------------------- rotate, crop, resize
-__global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParams p) {
+#define PX_ST 256                              // threads of the sample kernel (320 = a 25 x 25 tile in two passes instead of three: one car alone 7 % faster,
+                                               // 2 048 cars 36 % slower - five waves per workgroup do not spread evenly over four SIMDs)
+#define PX_NPRE ((PX_TILE_N * PX_TILE_PITCH + PX_ST - 1) / PX_ST)      // coefficients of a tile per thread
+__global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactParams p) {
     const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
     uint8_t *out = p.patch + (size_t)car * (PX_OUT * PX_OUT);
     if (px::skip_car(p, car)) {
-        for (int q = t; q < PX_OUT * PX_OUT / 16; q += 256) reinterpret_cast<uint4 *>(out)[q] = make_uint4(0u, 0u, 0u, 0u);
+        for (int q = t; q < PX_OUT * PX_OUT / 16; q += PX_ST) reinterpret_cast<uint4 *>(out)[q] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
     // The 200 x 200 window is rendered in 8 x 8 tiles of PX_T x PX_T pixels.  A tile's taps lie in a rectangle of the coefficient
@@ -258,8 +404,8 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
     __shared__ uint8_t tmp[PX_WIN * PX_OUT];
     __shared__ int32_t kk[PX_OUT * PX_KSIZE];
     __shared__ int32_t bounds[PX_OUT * 2];
-    for (int q = t; q < PX_OUT * PX_KSIZE; q += 256) kk[q] = p.kk[q];
-    for (int q = t; q < PX_OUT * 2; q += 256) bounds[q] = p.kk[PX_OUT * PX_KSIZE + q];
+    for (int q = t; q < PX_OUT * PX_KSIZE; q += PX_ST) kk[q] = p.kk[q];
+    for (int q = t; q < PX_OUT * 2; q += PX_ST) bounds[q] = p.kk[PX_OUT * PX_KSIZE + q];
     const double *coef = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [column][row]
     // the rotation of scipy.ndimage.rotate(reshape=True) on a 220 x 220 input (patch_reference.py, rotation)
     double cs, sn;
@@ -278,29 +424,55 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
     const int i0 = S0 / 2 - PX_WIN / 2, j0 = S1 / 2 - PX_WIN / 2;
     auto src0 = [&](int i, int j) { return ((0.0 + (double)(i0 + i) * cs) + (double)(j0 + j) * sn) + off0; };        // the library's expression
     auto src1 = [&](int i, int j) { return ((0.0 + (double)(i0 + i) * (-sn)) + (double)(j0 + j) * cs) + off1; };
+    // the rectangle of coefficients a tile's taps can touch: the map is linear, so its extremes are at the tile's corners; two cells
+    // of margin beyond the 4 x 4 footprint (rounding of the corner values, mirrored taps at the array's edges)
+    auto rect = [&](int ti, int tj, int &r_lo, int &c_lo, int &nr, int &nc) -> bool {
+        const int ia = ti * PX_T, ib = ia + PX_T - 1, ja = tj * PX_TW, jb = ja + PX_TW - 1;
+        const double r00 = src0(ia, ja), r01 = src0(ia, jb), r10 = src0(ib, ja), r11 = src0(ib, jb);
+        const double c00 = src1(ia, ja), c01 = src1(ia, jb), c10 = src1(ib, ja), c11 = src1(ib, jb);
+        const double rmin = fmin(fmin(r00, r01), fmin(r10, r11)), rmax = fmax(fmax(r00, r01), fmax(r10, r11));
+        const double cmin = fmin(fmin(c00, c01), fmin(c10, c11)), cmax = fmax(fmax(c00, c01), fmax(c10, c11));
+        const bool none = rmax < -0.5 || rmin > PX_CROP - 0.5 || cmax < -0.5 || cmin > PX_CROP - 0.5;      // every pixel of the tile reads the constant 0
+        int r_hi = (int)floor(rmax) + 4, c_hi = (int)floor(cmax) + 4;
+        r_lo = (int)floor(rmin) - 3; c_lo = (int)floor(cmin) - 3;
+        r_lo = r_lo < 0 ? 0 : r_lo; c_lo = c_lo < 0 ? 0 : c_lo;
+        r_hi = r_hi > PX_CROP - 1 ? PX_CROP - 1 : r_hi; c_hi = c_hi > PX_CROP - 1 ? PX_CROP - 1 : c_hi;
+        nr = r_hi - r_lo + 1; nc = c_hi - c_lo + 1;
+        return !none && nr > 0 && nc > 0 && nr <= PX_TILE_N && nc <= PX_TILE_N;      // (always, by the bound above; else: straight from memory)
+    };
+    // A tile's coefficients travel memory -> registers -> LDS, and the registers are filled for tile k + 1 BEFORE the pixels of tile
+    // k are computed: the memory latency (half of a tile's time when a car has the CU alone) hides behind the arithmetic.
+    double pre[PX_NPRE];
+    auto fetch = [&](bool staged, int r_lo, int c_lo, int nr, int nc) {
+#pragma unroll
+        for (int k = 0; k < PX_NPRE; ++k) {
+            const int q = t + PX_ST * k, c = q / PX_TILE_PITCH, r = q - c * PX_TILE_PITCH;
+            pre[k] = (staged && c < nc && r < nr) ? coef[(c_lo + c) * PX_CROP + r_lo + r] : 0.0;
+        }
+    };
+    int r_lo, c_lo, nr, nc;
+    bool staged = rect(0, 0, r_lo, c_lo, nr, nc);
+    fetch(staged, r_lo, c_lo, nr, nc);
     for (int ti = 0; ti < PX_WIN / PX_T; ++ti) {
-        for (int tj = 0; tj < PX_WIN / PX_T; ++tj) {
-            // the rectangle of coefficients this tile's taps can touch: the map is linear, so its extremes are at the tile's corners;
-            // two cells of margin beyond the 4 x 4 footprint (rounding of the corner values, mirrored taps at the array's edges)
-            const int ia = ti * PX_T, ib = ia + PX_T - 1, ja = tj * PX_T, jb = ja + PX_T - 1;
-            const double r00 = src0(ia, ja), r01 = src0(ia, jb), r10 = src0(ib, ja), r11 = src0(ib, jb);
-            const double c00 = src1(ia, ja), c01 = src1(ia, jb), c10 = src1(ib, ja), c11 = src1(ib, jb);
-            const double rmin = fmin(fmin(r00, r01), fmin(r10, r11)), rmax = fmax(fmax(r00, r01), fmax(r10, r11));
-            const double cmin = fmin(fmin(c00, c01), fmin(c10, c11)), cmax = fmax(fmax(c00, c01), fmax(c10, c11));
-            const bool none = rmax < -0.5 || rmin > PX_CROP - 0.5 || cmax < -0.5 || cmin > PX_CROP - 0.5;      // every pixel of the tile reads the constant 0
-            int r_lo = (int)floor(rmin) - 3, r_hi = (int)floor(rmax) + 4, c_lo = (int)floor(cmin) - 3, c_hi = (int)floor(cmax) + 4;
-            r_lo = r_lo < 0 ? 0 : r_lo; c_lo = c_lo < 0 ? 0 : c_lo;
-            r_hi = r_hi > PX_CROP - 1 ? PX_CROP - 1 : r_hi; c_hi = c_hi > PX_CROP - 1 ? PX_CROP - 1 : c_hi;
-            const int nr = r_hi - r_lo + 1, nc = c_hi - c_lo + 1;
-            const bool staged = !none && nr > 0 && nc > 0 && nr <= PX_TILE_N && nc <= PX_TILE_N;      // (always, by the bound above; else: straight from memory)
-            if (staged)
-                for (int q = t; q < nr * nc; q += 256) {
-                    const int c = q / nr, r = q - c * nr;
-                    tile[c * PX_TILE_PITCH + r] = coef[(c_lo + c) * PX_CROP + r_lo + r];
-                }
+        for (int tj = 0; tj < PX_WIN / PX_TW; ++tj) {
+            const int ia = ti * PX_T, ja = tj * PX_TW;
+            const int r_lo_t = r_lo, c_lo_t = c_lo;
+            const bool staged_t = staged;
+            if (staged_t) {
+#pragma unroll
+                for (int k = 0; k < PX_NPRE; ++k)
+                    if (t + PX_ST * k < PX_TILE_N * PX_TILE_PITCH) tile[t + PX_ST * k] = pre[k];      // [column][row], pitch = PX_TILE_PITCH
+            }
             __syncthreads();
-            for (int q = t; q < PX_T * PX_T; q += 256) {
-                const int il = q / PX_T, jl = q - il * PX_T, i = ia + il, j = ja + jl;
+            {
+                const int tn = ti * (PX_WIN / PX_TW) + tj + 1;
+                if (tn < (PX_WIN / PX_T) * (PX_WIN / PX_TW)) {
+                    staged = rect(tn / (PX_WIN / PX_TW), tn % (PX_WIN / PX_TW), r_lo, c_lo, nr, nc);
+                    fetch(staged, r_lo, c_lo, nr, nc);
+                }
+            }
+            for (int q = t; q < PX_T * PX_TW; q += PX_ST) {
+                const int il = q / PX_TW, jl = q - il * PX_TW, i = ia + il, j = ja + jl;
                 const double cc0 = src0(i, j), cc1 = src1(i, j);
                 double tv = 0.0;
                 if (!(cc0 < 0 || cc0 > PX_CROP - 1 || cc1 < 0 || cc1 > PX_CROP - 1)) {
@@ -308,10 +480,10 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
                     px::weights(cc0, w0);
                     px::weights(cc1, w1);
                     const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
-                    if (staged) {
+                    if (staged_t) {
                         int col[4];
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) col[b] = (px::mirror(st1 + b) - c_lo) * PX_TILE_PITCH - r_lo;
+                        for (int b = 0; b < 4; ++b) col[b] = (px::mirror(st1 + b) - c_lo_t) * PX_TILE_PITCH - r_lo_t;
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const int row = px::mirror(st0 + a);
@@ -336,7 +508,7 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
             __syncthreads();          // (the next tile's staging overwrites `tile`)
         }
         // Pillow's 8-bit resize, horizontal pass, this row of tiles: PX_T rows x 64 columns
-        for (int q = t; q < PX_T * PX_OUT; q += 256) {
+        for (int q = t; q < PX_T * PX_OUT; q += PX_ST) {
             const int r = q / PX_OUT, xx = q - r * PX_OUT;
             const int x0 = bounds[2 * xx], xm = bounds[2 * xx + 1];
             int32_t acc = 1 << (PX_BITS - 1);
@@ -347,7 +519,7 @@ __global__ __launch_bounds__(256) void rc_patch_exact_sample_kernel(RcExactParam
         __syncthreads();
     }
     // ... vertical pass: 64 x 64, written once
-    for (int q = t; q < PX_OUT * PX_OUT; q += 256) {
+    for (int q = t; q < PX_OUT * PX_OUT; q += PX_ST) {
         const int yy = q / PX_OUT, xx = q - yy * PX_OUT;
         const int y0 = bounds[2 * yy], ym = bounds[2 * yy + 1];
         int32_t acc = 1 << (PX_BITS - 1);
