@@ -181,7 +181,7 @@ hipError_t rck_launch_reset(const RcParams &p, const uint8_t *mask_dev, hipStrea
 hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStream_t s);
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
-#define RC_EXACT_CAR_DOUBLES (2 * 220 * 220)     // scratch per car of a chunk: two 220 x 220 binary64 arrays (774 400 B)
+#define RC_EXACT_CAR_DOUBLES (220 * 220)         // scratch per car of a chunk: the 220 x 220 binary64 spline coefficients (387 200 B)
 #define RC_EXACT_TABLE_INTS (64 * 15 + 64 * 2)   // Pillow's integer coefficients [64][15] and bounds [64][2]
 struct RcExactParams {
     const uint32_t *drv_words;   // drivable bitmap [h][pitch], ring cleared
@@ -190,7 +190,7 @@ struct RcExactParams {
     const uint8_t *fresh;
     int32_t fh, r_top, c0;       // source image height; north-up pixel (R, C) = cell (C - c0, r_top - R)   (rc_set_source_frame)
     double ox, oy, res;
-    double *scratch;             // [chunk][2][220 * 220]
+    double *scratch;             // [chunk][220 * 220]
     uint8_t *patch;              // [n_cars][64][64]
     const int32_t *kk;           // [64][15] Pillow's integer coefficients, [64][2] bounds behind them
     int32_t car0, n_cars;

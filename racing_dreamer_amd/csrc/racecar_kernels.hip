@@ -1995,7 +1995,7 @@ hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream
 }
 
 hipError_t rck_launch_patch_exact(const RcExactParams &p0, int chunk_cars, hipStream_t s) {
-    // a chunk of cars at a time: 774 KB of spline coefficients per car in flight (two kernels per chunk: the prefilter, then the
+    // a chunk of cars at a time: 387 KB of spline coefficients per car in flight (two kernels per chunk: the prefilter, then the
     // rotation + resize); the launch timer spans the first launch's start to the last one's end
     const hipEvent_t a = g_ev_start, b = g_ev_stop;
     g_ev_start = g_ev_stop = nullptr;
@@ -2003,11 +2003,7 @@ hipError_t rck_launch_patch_exact(const RcExactParams &p0, int chunk_cars, hipSt
     for (int c0 = 0; c0 < p0.n_cars; c0 += chunk_cars) {
         const int n = p0.n_cars - c0 < chunk_cars ? p0.n_cars - c0 : chunk_cars;
         p.car0 = c0;
-#if PX_PREFILTER_REG
-        hipExtLaunchKernelGGL(rc_patch_exact_prefilter_reg_kernel, dim3(n), dim3(256), 0u, s, c0 == 0 ? a : nullptr, nullptr, 0u, p);
-#else
-        hipExtLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(n), dim3(64 * PX_PF_WAVES), 0u, s, c0 == 0 ? a : nullptr, nullptr, 0u, p);
-#endif
+        hipExtLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(n), dim3(256), 0u, s, c0 == 0 ? a : nullptr, nullptr, 0u, p);
         hipExtLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(n), dim3(PX_ST), 0u, s, nullptr, c0 + n >= p0.n_cars ? b : nullptr, 0u, p);
     }
     return hipGetLastError();

@@ -5,15 +5,12 @@
 // multiply-add: the library is built with -ffp-contract=off; integer arithmetic for Pillow's resize).
 //
 //   rc_patch_exact_prefilter_kernel   one 256-thread workgroup per car: the crop's cubic-spline coefficients, 220 x 220 binary64
-//       (387 KB per car: global scratch, two buffers per car of the chunk - no LDS holds it).  Axis 0 with one lane per COLUMN
-//       (the column's 220 bits in LDS words; the causal start value summed from the bits in registers; forward values stored row-major
-//       = coalesced across lanes; the backward pass writes its results TRANSPOSED, four rows per lane at a time), then axis 1 with
-//       one lane per ROW reading the transposed array = coalesced again; the result stays in [column][row] order.
-//   rc_patch_exact_sample_kernel      one 256-thread workgroup per car: the 200 x 200 centre window of the rotated image (16 taps
-//       per pixel from the coefficient array through L1 / L2, weights and sums in binary64, rounded to uint8 as the library does)
-//       into LDS, then Pillow's two integer passes (200 x 200 -> 200 x 64 -> 64 x 64) from LDS, the patch written once.
-// A recurrence of 220 dependent steps per line cannot be sped up by a scan without changing the order of the additions; what
-// hides its latency is other cars: two workgroups (eight waves) per SIMD, every load of the backward passes issued ahead.
+//       (387 KB per car - no LDS holds it: the registers and the LDS of a CU together do), both axes and the transposition between
+//       them on the chip, the result written once to the car's scratch in [column][row] order.
+//   rc_patch_exact_sample_kernel      one 256-thread workgroup per car: the 200 x 200 centre window of the rotated image in tiles
+//       of 25 x 20 pixels (a tile's coefficients staged in LDS, the next tile's already on their way in registers; weights and the
+//       16 taps in binary64, rounded to uint8 as the library does), then Pillow's two integer passes (200 x 200 -> 200 x 64 -> 64 x
+//       64) from LDS, the patch written once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,9 +22,9 @@
 #define PX_OUT 64
 #define PX_KSIZE 15
 #define PX_BITS 22
-#define PX_T 25                               // the sample kernel renders the 200 x 200 window in 8 x 8 tiles of 25 x 25 pixels (40: 11 % slower,
-                                              // 20: 2 %, 10: 40 % - tools/exact_tile_sweep.sh)
-#define PX_TW 20                              // ... of PX_T rows x PX_TW columns: 500 pixels = two passes of 256 threads at 98 % (25 x 25: three at 81 %)
+#define PX_T 25                               // the sample kernel renders the 200 x 200 window in 8 x 10 tiles of PX_T rows x PX_TW columns:
+#define PX_TW 20                              // 500 pixels = two passes of 256 threads at 98 % (square tiles of 40 / 25 / 20 / 10: EXPERIMENTS.md 000.4;
+                                              // 25 x 25 is three passes at 81 %)
 #define PX_TILE_N 39                          // a tile's taps lie within sqrt(24^2 + 19^2) + 9 = 39.6 coefficients per axis
 #define PX_TILE_PITCH 39                      // doubles per staged column (odd: consecutive columns start in different LDS banks)
 #define PX_Z (-0.2679491924311227)            // scipy ni_splines.c: the cubic spline's pole, sqrt(3) - 2 correctly rounded
@@ -91,173 +88,22 @@ __device__ __forceinline__ int mirror(int i) {
 }  // namespace px
 
 // ---------------------------------------------------------------------------------------------------------------- prefilter
-// One line of the cubic-spline prefilter, IN PLACE in LDS, by one lane (patch_reference.py, _filter_lines; the line already
-// carries the gain): the mirror-summed causal start, the causal recursion, the anticausal start and recursion.  The LDS reads of a
-// block of PX_BLK steps are issued together ahead of the block's dependent chain (their addresses do not depend on it).
-#define PX_BLK 11                              // 220 = 20 x 11
-__device__ __forceinline__ void px_filter_line_lds(double *line) {
-    const double z = PX_Z, zn = PX_ZN;
-    double c0 = line[0] + zn * line[PX_CROP - 1], zi = z;
-    // i = 1 .. 218: two steps alone, then 18 blocks of 12
-    for (int i = 1; i < 3; ++i) {
-        c0 = c0 + zi * (line[i] + zn * line[PX_CROP - 1 - i]);
-        zi *= z;
-    }
-    for (int i0 = 3; i0 < PX_CROP - 1; i0 += 12) {
-        double f[12], g[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) { f[k] = line[i0 + k]; g[k] = line[PX_CROP - 1 - i0 - k]; }
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            c0 = c0 + zi * (f[k] + zn * g[k]);
-            zi *= z;
-        }
-    }
-    double v = c0 / (1.0 - zn * zn), prev = 0.0;
-    line[0] = v;
-    // forward, i = 1 .. 219: 19 blocks of 11, then 10 steps
-    for (int i0 = 1; i0 < PX_CROP; i0 += PX_BLK) {
-        double f[PX_BLK];
-#pragma unroll
-        for (int k = 0; k < PX_BLK; ++k) f[k] = (i0 + k < PX_CROP) ? line[i0 + k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < PX_BLK; ++k)
-            if (i0 + k < PX_CROP) {
-                prev = v;
-                v = f[k] + z * v;
-                line[i0 + k] = v;
-            }
-    }
-    v = (z * prev + v) * z / (z * z - 1.0);
-    line[PX_CROP - 1] = v;
-    // backward, i = 218 .. 0: 19 blocks of 11, then 10 steps
-    for (int i0 = PX_CROP - 2; i0 >= 0; i0 -= PX_BLK) {
-        double f[PX_BLK];
-#pragma unroll
-        for (int k = 0; k < PX_BLK; ++k) f[k] = (i0 - k >= 0) ? line[i0 - k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < PX_BLK; ++k)
-            if (i0 - k >= 0) {
-                v = z * (v - f[k]);
-                line[i0 - k] = v;
-            }
-    }
-}
-
-// The crop's spline coefficients, 220 x 220 binary64, into the car's scratch in [column][row] order.  Every recursion runs in LDS:
-// each of the workgroup's four waves takes eight lines at a time - all 64 lanes fill them (axis 0: from the crop's bits, staged
-// once per car; axis 1: from the axis-0 result in memory, scaled by the gain), lanes 0 - 7 filter a line each in place, all 64
-// lanes write the lines out - so a pass costs one read and one write of the array (axis 0: the write alone) where the first form
-// of this kernel (forward values through memory) moved 3.5 MB per car at 4.6 TB/s of HBM traffic.  64 lines are in flight per CU
-// (160 KB of LDS hold 92); the waves run out of step with one another, so loads, recursions and stores of different waves overlap.
-#define PX_NBW 10
-#define PX_PF_WAVES 4                           // waves per workgroup of the prefilter kernel (PX_PF_WAVES x PX_NBW lines in LDS at a time)
-#define PX_LPITCH 221
-#define PX_RPW ((PX_CROP + 63) / 64)             // passes of the wave over a line (axis 0)
-#define PX_IPW (64 / PX_NBW)                    // columns of a batch one pass of the wave covers (axis 1)
-#define PX_NIT ((PX_CROP + PX_IPW - 1) / PX_IPW) // passes per batch
-__global__ __launch_bounds__(64 * PX_PF_WAVES, 2) void rc_patch_exact_prefilter_kernel(RcExactParams p) {
-    const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
-    if (px::skip_car(p, car)) return;                                  // (uniform over the workgroup)
-    double *colmaj = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [c][r]
-    __shared__ double lines[PX_PF_WAVES][PX_NBW][PX_LPITCH];
-    __shared__ uint32_t cropw[PX_CROP][9];                             // the crop's rows as bits: bit k of the row = cell column gxw * 32 + k
-    const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
-    (void)z;
-    int pr, pc;
-    px::pixel_of(p, car, pr, pc);
-    const int gx0 = (pc - PX_CROP / 2) - p.c0;                        // grid column of crop column 0 (may be negative)
-    const int gxw = gx0 >> 5;                                          // its word (floor)
-    for (int q = t; q < PX_CROP * 8; q += 64 * PX_PF_WAVES) {
-        const int r = q >> 3, k = q & 7, gy = p.r_top - (pr - PX_CROP / 2 + r), gw = gxw + k;
-        uint32_t word = 0;
-        if ((unsigned)gy < (unsigned)p.h && (unsigned)gw < (unsigned)p.pitch) {
-            word = p.drv_words[(size_t)gy * p.pitch + gw];
-            const int first = gw * 32;                                 // cells at or beyond the grid's width read 0
-            if (first + 32 > p.w) word &= first >= p.w ? 0u : (0xffffffffu >> (32 - (p.w - first)));
-        }
-        cropw[r][k] = word;
-    }
-    __syncthreads();
-    const int wave = t >> 6, lane = t & 63;
-    double (*mine)[PX_LPITCH] = lines[wave];
-    // ---- axis 0: a line = a column of the crop (north-up: crop row r is grid row r_top - (pr - 110 + r))
-    for (int b = wave; b * PX_NBW < PX_CROP; b += PX_PF_WAVES) {
-        const int c0 = b * PX_NBW;
-#pragma unroll
-        for (int l = 0; l < PX_NBW; ++l) {
-            const int bitpos = (gx0 + c0 + l) - gxw * 32;              // (uniform over the wave)
-#pragma unroll
-            for (int k = 0; k < PX_RPW; ++k) {
-                const int r = lane + 64 * k;
-                if (r < PX_CROP) {
-                    const uint32_t bit = (c0 + l < PX_CROP) ? (cropw[r][bitpos >> 5] >> (bitpos & 31)) & 1u : 0u;
-                    mine[l][r] = bit ? gain : 0.0;                     // (1.0 * gain, 0.0 * gain)
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                               // (one wave: its own LDS writes, in order)
-#ifndef PX_EXP_NO_CHAIN
-        if (lane < PX_NBW && c0 + lane < PX_CROP) px_filter_line_lds(mine[lane]);
-#endif
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int l = 0; l < PX_NBW; ++l)
-#pragma unroll
-            for (int k = 0; k < PX_RPW; ++k) {
-                const int r = lane + 64 * k;
-                if (r < PX_CROP && c0 + l < PX_CROP) colmaj[(size_t)(c0 + l) * PX_CROP + r] = mine[l][r];
-            }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();          // every column's result is visible to the whole workgroup (global memory, same CU)
-    // ---- axis 1: a line = a row; element (row r, column i) lies at colmaj[i * 220 + r].  The next batch's rows are fetched into
-    // registers BEFORE this batch's recursions start (they are other rows than the ones this batch writes), so the memory latency
-    // of a fill hides behind the dependent chains instead of standing in front of them.
-    double pre[PX_NIT];
-    const int li = lane / PX_NBW, ll = lane - li * PX_NBW;            // lane = (column within a pass of PX_IPW columns, line)
-    auto fetch = [&](int r0) {
-        const double *src = colmaj + (size_t)li * PX_CROP + r0 + ll;
-#pragma unroll
-        for (int k = 0; k < PX_NIT; ++k)
-            pre[k] = (li < PX_IPW && li + PX_IPW * k < PX_CROP && r0 + ll < PX_CROP) ? src[(size_t)k * (PX_IPW * PX_CROP)] : 0.0;
-    };
-    if (wave * PX_NBW < PX_CROP) fetch(wave * PX_NBW);
-    for (int b = wave; b * PX_NBW < PX_CROP; b += PX_PF_WAVES) {
-        const int r0 = b * PX_NBW;
-#pragma unroll
-        for (int k = 0; k < PX_NIT; ++k)
-            if (li < PX_IPW && li + PX_IPW * k < PX_CROP) mine[ll][li + PX_IPW * k] = pre[k] * gain;      // the second pass scales its input too
-        __builtin_amdgcn_wave_barrier();
-        if ((b + PX_PF_WAVES) * PX_NBW < PX_CROP) fetch((b + PX_PF_WAVES) * PX_NBW);
-#ifndef PX_EXP_NO_CHAIN
-        if (lane < PX_NBW && r0 + lane < PX_CROP) px_filter_line_lds(mine[lane]);
-#endif
-        __builtin_amdgcn_wave_barrier();
-        {
-            double *dst = colmaj + (size_t)li * PX_CROP + r0 + ll;
-#pragma unroll
-            for (int k = 0; k < PX_NIT; ++k)
-                if (li < PX_IPW && li + PX_IPW * k < PX_CROP && r0 + ll < PX_CROP) dst[(size_t)k * (PX_IPW * PX_CROP)] = mine[ll][li + PX_IPW * k];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------------------------------ prefilter, lines in registers
-// The same arithmetic with a line per LANE: 4 waves x 55 lanes = the 220 lines of an axis at once, a line's 220 values in the lane's
-// registers (PXR_REG of them) and LDS (the rest) - what bounds the LDS form is lines in flight per CU (80) over the 45 cycles a
-// step of a recursion takes (tools/ubench/f64_chain.hip), and a CU's registers hold three times what its LDS holds.  Every loop over
-// a line is fully unrolled, so every register index is a constant.  Axis 0 (lane = column): the column's bits from the staged crop,
-// results of the backward pass through a 55 x 16 LDS tile per wave so that they reach memory [column][row] in 128-byte runs.
-// Axis 1 (lane = row): [column][row] is contiguous across lanes, so the 220 loads of the fill go out back to back and the backward
-// pass stores from registers.
-#define PX_PREFILTER_REG 1
+// The crop's cubic-spline coefficients (patch_reference.py, spline_coefficients): along every column, then along every row, the
+// mirror-summed causal start, the causal recursion, the anticausal start and recursion - 880 dependent steps per line, each a
+// binary64 multiply and a dependent add (45 cycles on a SIMD whatever the number of active lanes: tools/ubench/f64_chain.hip), in
+// the library's order: nothing to reassociate.  What sets the pace is the number of lines a CU has in flight.  One workgroup per
+// car, a line per LANE: 4 waves x 55 lanes = the 220 lines of an axis at once, a line's 220 values in the lane's registers
+// (PXR_REG of them; the kernel runs at one wave per SIMD with all 512 registers) and LDS (the rest).  Every loop over a line is
+// fully unrolled, so every register index is a constant.  Axis 0 (lane = column): the column's bits from the staged crop, filtered
+// in place.  Then the array is transposed ON THE CHIP (pxr_transpose) and axis 1 (lane = row) filters in place again, its backward
+// pass storing [column][row] - contiguous across lanes - straight from registers: the only memory traffic is the 387 KB result.
+// Forms measured before this one (EXPERIMENTS.md 000.4): forward values through memory (HBM-bound at 4.6 TB/s, 1.56 ms per 2 048
+// cars), lines in LDS ten per wave (80 lines in flight per CU: 0.97 ms), this form with the intermediate array through memory
+// (HBM-bound again: 0.54 ms); now 0.47 ms.
 #define PXR_REG 161
 #define PXR_LDS (PX_CROP - PXR_REG)
 #define PXR_LANES 55
-#define PXR_TB 16
-#define PXR_TPITCH 17
+#define PXR_TB 16                               // the backward pass is unrolled in blocks of this many steps
 #define PXR_SB 8                                // the scheduler may move code within blocks of this many steps only (else it
                                                 // hoists hundreds of loads and spills)
 #define PXR_LINES (PX_CROP + 4)                 // + one dummy line per wave for the idle lanes 55 .. 63
@@ -303,35 +149,56 @@ __device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl
     }
 }
 
-__global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_reg_kernel(RcExactParams p) {
-    const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
-    if (px::skip_car(p, car)) return;                                  // (uniform over the workgroup)
-    double *colmaj = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [c][r]
-    __shared__ double slds[PXR_LINES][PXR_LDS | 1];                    // (odd pitch: the lanes of a step fall into different banks)
-    __shared__ double tile[4][64][PXR_TPITCH];
-    __shared__ uint32_t cropw[PX_CROP][9];
-    const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
-    int pr, pc;
-    px::pixel_of(p, car, pr, pc);
-    const int gx0 = (pc - PX_CROP / 2) - p.c0, gxw = gx0 >> 5;
-    for (int q = t; q < PX_CROP * 8; q += 256) {
-        const int r = q >> 3, k = q & 7, gy = p.r_top - (pr - PX_CROP / 2 + r), gw = gxw + k;
-        uint32_t word = 0;
-        if ((unsigned)gy < (unsigned)p.h && (unsigned)gw < (unsigned)p.pitch) {
-            word = p.drv_words[(size_t)gy * p.pitch + gw];
-            const int first = gw * 32;
-            if (first + 32 > p.w) word &= first >= p.w ? 0u : (0xffffffffu >> (32 - (p.w - first)));
+// The array's transposition between the two axes, on the chip.  After axis 0 lane l of wave W holds column 55 W + l (row i in slot
+// i); axis 1 wants row 55 W + l there (column j in slot j).  Seen as 4 x 4 blocks of 55 lanes x 55 slots, block (W, P) of wave W
+// and block (P, W) of wave P swap, each transposed: both waves publish their block in LDS (xb[.][lane][slot], odd pitch), a
+// barrier, each reads the other's with lane and slot exchanged.  Two 55 x 55 buffers fit beside the lines' LDS part, so one pair of
+// waves (or two diagonal blocks) moves at a time: 8 steps.  W is a template parameter: every slot index is a constant.
+#define PXR_XPITCH 57
+#define PXR_XROWS 56                            // 55 lanes + a row the idle lanes write to
+template <int W>
+__device__ __forceinline__ void pxr_transpose(double (&S)[PXR_REG], double *sl, double *xb, int lrow, int lcol) {
+    constexpr int sched[8][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}, {0, 1}, {2, 3}};     // the last two: diagonal blocks of waves a, b
+#pragma unroll
+    for (int step = 0; step < 8; ++step) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int a = sched[step][0], b = sched[step][1];
+        const bool in = W == a || W == b, diag = step >= 6;
+        const int P = diag ? W : (W == a ? b : a);                    // the wave whose block range of slots moves
+        double *mine = xb + (W == a ? 0 : 1) * (PXR_XROWS * PXR_XPITCH);
+        double *other = diag ? mine : xb + (W == a ? 1 : 0) * (PXR_XROWS * PXR_XPITCH);
+        if (in) {
+#pragma unroll
+            for (int q = 0; q < PXR_LANES; ++q) mine[lrow * PXR_XPITCH + q] = PXR_GET(PXR_LANES * P + q);
         }
-        cropw[r][k] = word;
+        __syncthreads();
+        if (in) {
+#pragma unroll
+            for (int q = 0; q < PXR_LANES; ++q) PXR_PUT(PXR_LANES * P + q, other[q * PXR_XPITCH + lcol]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    const int wave = t >> 6, lane = t & 63;
+}
+
+// What a wave does once the crop's bits are staged, compiled once per wave index (pxr_transpose: its slot indices depend on the
+// wave).  The four instances never meet again - behind a common continuation the register allocator has to reconcile four
+// assignments of the 161 register-resident values and does it through scratch memory (measured: + 24 us per car).
+#ifdef PXR_STAMPS      // (tools/ubench/exact_latency.hip: the clock at the phase boundaries of each wave, lane 0, into `stamps`)
+#define PXR_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); if (lane == 0) stamps[8 * W + (k)] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PXR_STAMP(k) do { } while (0)
+#endif
+template <int W>
+__device__ __forceinline__ void pxr_wave(const uint32_t (*cropw)[9], double (*slds)[PXR_LDS | 1], double *xb, double *colmaj, long long *stamps, int gx0, int gxw, int lane) {
+    (void)stamps;
+    const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
     const bool act = lane < PXR_LANES;
-    const int n = act ? wave * PXR_LANES + lane : PX_CROP + wave;      // the lane's line (idle lanes share a dummy line)
+    const int n = act ? W * PXR_LANES + lane : PX_CROP + W;      // the lane's line (idle lanes share a dummy line)
     double *sl = slds[n];
-    double (*tl)[PXR_TPITCH] = tile[wave];
     double S[PXR_REG];
-    // ---- axis 0: the line = column n of the crop
+    PXR_STAMP(0);
+    // ---- axis 0: the line = column n of the crop, filtered in place
     {
         const int bitpos = (gx0 + (act ? n : 0)) - gxw * 32, wq = bitpos >> 5, sh = bitpos & 31;
         uint32_t colbits[(PX_CROP + 31) / 32];                         // the column's 220 cells, 32 LDS reads in flight at a time
@@ -352,39 +219,77 @@ __global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_reg_kernel(Rc
             PXR_PUT(i, f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        const int cq = lane >> 4, k = lane & 15;
-        pxr_filter_line(S, sl, [&](int i, double v) { tl[lane][i & (PXR_TB - 1)] = v; },
-            [&](int i) {                                               // rows i .. i + 15 of the wave's 55 columns are complete
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int pass = 0; pass < (PXR_LANES + 3) / 4; ++pass) {
-                    const int cl = 4 * pass + cq;
-                    if (cl < PXR_LANES && i + k < PX_CROP) colmaj[(size_t)(wave * PXR_LANES + cl) * PX_CROP + i + k] = tl[cl][k];
-                }
-                __builtin_amdgcn_wave_barrier();
-            });
+        PXR_STAMP(1);
+        pxr_filter_line(S, sl, [&](int i, double v) { PXR_PUT(i, v); }, [](int) {});
+        PXR_STAMP(2);
     }
-    __syncthreads();          // every column's result is visible to the whole workgroup (global memory, same CU)
-    // ---- axis 1: the line = row n; element (row n, column i) lies at colmaj[i * 220 + n]
+    __syncthreads();          // (every wave is done with the crop bits: the exchange buffers may be written)
+    // ---- columns -> rows, then axis 1: the line = row n, scaled by the gain first (the second pass scales its input too)
     {
-        double *mine = colmaj + (act ? n : wave * PXR_LANES);          // (idle lanes read a neighbour's row - no branch around the loads,
-                                                                       //  or every one of them gets a wait of its own - and store nothing)
-#pragma unroll
-        for (int i = PXR_REG; i < PX_CROP; ++i) PXR_PUT(i, mine[(size_t)i * PX_CROP] * gain);      // the second pass scales its input too
+        const int lrow = act ? lane : PXR_LANES, lcol = act ? lane : 0;
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < PXR_REG; ++i) S[i] = mine[(size_t)i * PX_CROP];                        // 161 loads in flight, then
+        PXR_STAMP(3);
+        pxr_transpose<W>(S, sl, xb, lrow, lcol);
+        PXR_STAMP(4);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    {
 #pragma unroll
-        for (int i = 0; i < PXR_REG; ++i) S[i] = S[i] * gain;
-        __builtin_amdgcn_sched_barrier(0);
-        pxr_filter_line(S, sl, [&](int i, double v) { if (act) mine[(size_t)i * PX_CROP] = v; }, [](int) {});
+        for (int i = 0; i < PX_CROP; ++i) {
+            const double f = PXR_GET(i) * gain;
+            PXR_PUT(i, f);
+            if (i % (4 * PXR_SB) == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        // element (row n, column i) goes to colmaj[i * 220 + n]: contiguous across lanes.  The whole pass runs under the lane mask
+        // of the 55 active lanes (one branch) - a store masked on its own costs a mask save / branch / restore at every step of the
+        // chain, and idle lanes storing to a dummy place cost a cache line of write traffic per step
+        double *mine = colmaj + n;
+        PXR_STAMP(5);
+        if (act) pxr_filter_line(S, sl, [&](int i, double v) { mine[(size_t)i * PX_CROP] = v; }, [](int) {});
+        PXR_STAMP(6);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_kernel(RcExactParams p) {
+    const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
+    if (px::skip_car(p, car)) return;                                  // (uniform over the workgroup)
+    double *colmaj = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES;      // [column][row]
+    // LDS: the lines' LDS part [224][59] (odd pitch: the lanes of a step fall into different banks), then the two exchange
+    // buffers of the transposition - which the staged crop bits share: they are dead once every lane has gathered its column
+    __shared__ double lds[PXR_LINES * (PXR_LDS | 1) + 2 * PXR_XROWS * PXR_XPITCH];
+    double (*slds)[PXR_LDS | 1] = reinterpret_cast<double (*)[PXR_LDS | 1]>(lds);
+    double *xb = lds + PXR_LINES * (PXR_LDS | 1);
+    uint32_t (*cropw)[9] = reinterpret_cast<uint32_t (*)[9]>(xb);
+    static_assert(PX_CROP * 9 * 4 <= 2 * PXR_XROWS * PXR_XPITCH * 8, "the crop bits share the exchange buffers");
+    const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
+    int pr, pc;
+    px::pixel_of(p, car, pr, pc);
+    const int gx0 = (pc - PX_CROP / 2) - p.c0, gxw = gx0 >> 5;
+    for (int q = t; q < PX_CROP * 8; q += 256) {
+        const int r = q >> 3, k = q & 7, gy = p.r_top - (pr - PX_CROP / 2 + r), gw = gxw + k;
+        uint32_t word = 0;
+        if ((unsigned)gy < (unsigned)p.h && (unsigned)gw < (unsigned)p.pitch) {
+            word = p.drv_words[(size_t)gy * p.pitch + gw];
+            const int first = gw * 32;
+            if (first + 32 > p.w) word &= first >= p.w ? 0u : (0xffffffffu >> (32 - (p.w - first)));
+        }
+        cropw[r][k] = word;
+    }
+    __syncthreads();
+    const int lane = t & 63;
+    long long *stamps = reinterpret_cast<long long *>(p.patch + (size_t)car * (PX_OUT * PX_OUT));      // (PXR_STAMPS builds only)
+    switch (t >> 6) {
+        case 0: pxr_wave<0>(cropw, slds, xb, colmaj, stamps, gx0, gxw, lane); break;
+        case 1: pxr_wave<1>(cropw, slds, xb, colmaj, stamps, gx0, gxw, lane); break;
+        case 2: pxr_wave<2>(cropw, slds, xb, colmaj, stamps, gx0, gxw, lane); break;
+        default: pxr_wave<3>(cropw, slds, xb, colmaj, stamps, gx0, gxw, lane); break;
     }
 }
 
 // ------------------------------------------------------------------------------------------------- rotate, crop, resize
 #define PX_ST 256                              // threads of the sample kernel (320 = a 25 x 25 tile in two passes instead of three: one car alone 7 % faster,
                                                // 2 048 cars 36 % slower - five waves per workgroup do not spread evenly over four SIMDs)
+#define PX_NTILES ((PX_WIN / PX_T) * (PX_WIN / PX_TW))
 #define PX_NPRE ((PX_TILE_N * PX_TILE_PITCH + PX_ST - 1) / PX_ST)      // coefficients of a tile per thread
 __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactParams p) {
     const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
@@ -393,20 +298,21 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
         for (int q = t; q < PX_OUT * PX_OUT / 16; q += PX_ST) reinterpret_cast<uint4 *>(out)[q] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
-    // The 200 x 200 window is rendered in 8 x 8 tiles of PX_T x PX_T pixels.  A tile's taps lie in a rectangle of the coefficient
-    // array at most 41 x 41 large (the tile rotated, + the 4 x 4 footprint): it is staged in LDS first - coalesced column segments -
-    // and the 16 taps per pixel are LDS reads.  Read straight from memory (the first form) a wave's 64 taps of one load instruction
-    // lay in up to 64 different cache lines, and the texture-address unit, not the arithmetic, set the pace: 1.51 ms per 2 048
-    // cars; more workgroups per CU made it worse (their 387 KB arrays push each other out of the XCD's L2:
-    // tools/exact_strip_sweep.sh).  A row of tiles is resized horizontally as soon as it is complete.
+    // The 200 x 200 window is rendered in tiles of PX_T x PX_TW pixels.  A tile's taps lie in a rectangle of the coefficient array
+    // at most 39 x 39 large (the tile rotated, + the 4 x 4 footprint): it is staged in LDS first - coalesced column segments - and
+    // the 16 taps per pixel are LDS reads.  Read straight from memory (the first form) a wave's 64 taps of one load instruction lay
+    // in up to 64 different cache lines, and the texture-address unit, not the arithmetic, set the pace: 1.51 ms per 2 048 cars;
+    // more workgroups per CU made it worse (their 387 KB arrays push each other out of the XCD's L2: EXPERIMENTS.md 000.4).
+    // A row of tiles is resized horizontally as soon as it is complete.
     __shared__ double tile[PX_TILE_N * PX_TILE_PITCH];
     __shared__ uint8_t win[PX_T * PX_WIN];
     __shared__ uint8_t tmp[PX_WIN * PX_OUT];
     __shared__ int32_t kk[PX_OUT * PX_KSIZE];
     __shared__ int32_t bounds[PX_OUT * 2];
+    __shared__ int32_t rects[PX_NTILES][4];
     for (int q = t; q < PX_OUT * PX_KSIZE; q += PX_ST) kk[q] = p.kk[q];
     for (int q = t; q < PX_OUT * 2; q += PX_ST) bounds[q] = p.kk[PX_OUT * PX_KSIZE + q];
-    const double *coef = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES + PX_CROP * PX_CROP;      // [column][row]
+    const double *coef = p.scratch + (size_t)blockIdx.x * PX_CAR_DOUBLES;      // [column][row]
     // the rotation of scipy.ndimage.rotate(reshape=True) on a 220 x 220 input (patch_reference.py, rotation)
     double cs, sn;
     px::sincos_deg((2.0 * 3.141592653589793 - (double)p.theta[car]) * (180.0 / 3.141592653589793), cs, sn);
@@ -426,7 +332,7 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
     auto src1 = [&](int i, int j) { return ((0.0 + (double)(i0 + i) * (-sn)) + (double)(j0 + j) * cs) + off1; };
     // the rectangle of coefficients a tile's taps can touch: the map is linear, so its extremes are at the tile's corners; two cells
     // of margin beyond the 4 x 4 footprint (rounding of the corner values, mirrored taps at the array's edges)
-    auto rect = [&](int ti, int tj, int &r_lo, int &c_lo, int &nr, int &nc) -> bool {
+    auto rect = [&](int ti, int tj, int &r_lo, int &c_lo, int &nr, int &nc, bool &edge) -> bool {
         const int ia = ti * PX_T, ib = ia + PX_T - 1, ja = tj * PX_TW, jb = ja + PX_TW - 1;
         const double r00 = src0(ia, ja), r01 = src0(ia, jb), r10 = src0(ib, ja), r11 = src0(ib, jb);
         const double c00 = src1(ia, ja), c01 = src1(ia, jb), c10 = src1(ib, ja), c11 = src1(ib, jb);
@@ -435,6 +341,7 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
         const bool none = rmax < -0.5 || rmin > PX_CROP - 0.5 || cmax < -0.5 || cmin > PX_CROP - 0.5;      // every pixel of the tile reads the constant 0
         int r_hi = (int)floor(rmax) + 4, c_hi = (int)floor(cmax) + 4;
         r_lo = (int)floor(rmin) - 3; c_lo = (int)floor(cmin) - 3;
+        edge = r_lo < 0 || c_lo < 0 || r_hi > PX_CROP - 1 || c_hi > PX_CROP - 1;      // a tap of this tile may be a mirrored one
         r_lo = r_lo < 0 ? 0 : r_lo; c_lo = c_lo < 0 ? 0 : c_lo;
         r_hi = r_hi > PX_CROP - 1 ? PX_CROP - 1 : r_hi; c_hi = c_hi > PX_CROP - 1 ? PX_CROP - 1 : c_hi;
         nr = r_hi - r_lo + 1; nc = c_hi - c_lo + 1;
@@ -450,14 +357,23 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
             pre[k] = (staged && c < nc && r < nr) ? coef[(c_lo + c) * PX_CROP + r_lo + r] : 0.0;
         }
     };
-    int r_lo, c_lo, nr, nc;
-    bool staged = rect(0, 0, r_lo, c_lo, nr, nc);
+    // every tile's rectangle once per car, a tile per thread (computed where it is used - by all 256 threads, the same values - the
+    // eight corner evaluations were a sixth of a tile's arithmetic)
+    for (int q = t; q < PX_NTILES; q += PX_ST) {
+        int a, b, c, d;
+        bool edge;
+        const bool ok = rect(q / (PX_WIN / PX_TW), q % (PX_WIN / PX_TW), a, b, c, d, edge);
+        rects[q][0] = a; rects[q][1] = b; rects[q][2] = ok ? c : 0; rects[q][3] = d | (edge ? 1 << 16 : 0);      // (rows 0: not staged)
+    }
+    __syncthreads();
+    int r_lo = rects[0][0], c_lo = rects[0][1], nr = rects[0][2], nc = rects[0][3] & 0xffff;
+    bool staged = nr > 0, edge = (rects[0][3] >> 16) != 0;
     fetch(staged, r_lo, c_lo, nr, nc);
     for (int ti = 0; ti < PX_WIN / PX_T; ++ti) {
         for (int tj = 0; tj < PX_WIN / PX_TW; ++tj) {
             const int ia = ti * PX_T, ja = tj * PX_TW;
             const int r_lo_t = r_lo, c_lo_t = c_lo;
-            const bool staged_t = staged;
+            const bool staged_t = staged, edge_t = edge;
             if (staged_t) {
 #pragma unroll
                 for (int k = 0; k < PX_NPRE; ++k)
@@ -466,8 +382,9 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
             __syncthreads();
             {
                 const int tn = ti * (PX_WIN / PX_TW) + tj + 1;
-                if (tn < (PX_WIN / PX_T) * (PX_WIN / PX_TW)) {
-                    staged = rect(tn / (PX_WIN / PX_TW), tn % (PX_WIN / PX_TW), r_lo, c_lo, nr, nc);
+                if (tn < PX_NTILES) {
+                    r_lo = rects[tn][0]; c_lo = rects[tn][1]; nr = rects[tn][2]; nc = rects[tn][3] & 0xffff;
+                    staged = nr > 0; edge = (rects[tn][3] >> 16) != 0;
                     fetch(staged, r_lo, c_lo, nr, nc);
                 }
             }
@@ -480,7 +397,13 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
                     px::weights(cc0, w0);
                     px::weights(cc1, w1);
                     const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
-                    if (staged_t) {
+                    if (staged_t && !edge_t) {                          // (most tiles: no tap beyond the array, nothing to mirror)
+                        const double *t0 = tile + (st1 - c_lo_t) * PX_TILE_PITCH + (st0 - r_lo_t);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) tv = tv + (t0[b * PX_TILE_PITCH + a] * w0[a]) * w1[b];
+                    } else if (staged_t) {
                         int col[4];
 #pragma unroll
                         for (int b = 0; b < 4; ++b) col[b] = (px::mirror(st1 + b) - c_lo_t) * PX_TILE_PITCH - r_lo_t;

@@ -26,8 +26,8 @@ int main() {
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     std::vector<double> s(RC_EXACT_CAR_DOUBLES);
     CK(hipMemcpy(s.data(), d_s, s.size() * 8, hipMemcpyDeviceToHost));
-    double mx0 = 0, mx1 = 0; for (int i = 0; i < 220 * 220; ++i) { mx0 = fmax(mx0, fabs(s[i])); mx1 = fmax(mx1, fabs(s[220 * 220 + i])); }
-    printf("prefilter: max |rowmaj| %g max |colmaj| %g colmaj[110*220+110] %.17g\n", mx0, mx1, s[220 * 220 + 110 * 220 + 110]);
+    double mx = 0; for (int i = 0; i < 220 * 220; ++i) mx = fmax(mx, fabs(s[i]));
+    printf("prefilter: max |coefficient| %g  coefficient[110][110] %.17g\n", mx, s[110 * 220 + 110]);
     hipLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(1), dim3(PX_ST), 0, 0, p);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     std::vector<uint8_t> patch(4096);

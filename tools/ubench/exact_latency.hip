@@ -1,9 +1,11 @@
-// The exact render's two kernels on 1, 256 and 2 048 identical synthetic cars: what a car costs alone on a CU (latency of the whole
-// dependent work) against what it costs with every CU busy (the memory system shared).  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+// The exact render's two kernels on 1 .. 2 048 identical synthetic cars: what a car costs alone on a CU (latency of the whole
+// dependent work) against what it costs with every CU busy (the memory system shared); then the prefilter's phases on one car
+// (the header's PXR_STAMP, compiled in here only).  hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#define PXR_STAMPS 1
 #include "../../racing_dreamer_amd/csrc/racecar_patch_exact.h"
 #define CK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(_e), __LINE__); return 1; } } while (0)
 int main() {
@@ -26,17 +28,25 @@ int main() {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     const int grids[] = {1, 64, 256, 512, 2048};
     for (int g : grids) {
-        float best[3] = {1e9f, 1e9f, 1e9f};
+        float best[2] = {1e9f, 1e9f};
         for (int rep = 0; rep < 5; ++rep) {
             float ms;
-            CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_prefilter_reg_kernel, dim3(g), dim3(256), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(g), dim3(256), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
             CK(hipEventElapsedTime(&ms, a, b)); best[0] = ms < best[0] ? ms : best[0];
-            CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(g), dim3(64 * PX_PF_WAVES), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-            CK(hipEventElapsedTime(&ms, a, b)); best[1] = ms < best[1] ? ms : best[1];
             CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(g), dim3(PX_ST), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-            CK(hipEventElapsedTime(&ms, a, b)); best[2] = ms < best[2] ? ms : best[2];
+            CK(hipEventElapsedTime(&ms, a, b)); best[1] = ms < best[1] ? ms : best[1];
         }
-        printf("%5d cars: prefilter (registers) %8.1f us   prefilter (LDS) %8.1f us   sample %8.1f us\n", g, best[0] * 1e3, best[1] * 1e3, best[2] * 1e3);
+        printf("%5d cars: prefilter %8.1f us   sample %8.1f us\n", g, best[0] * 1e3, best[1] * 1e3);
+    }
+    // phases of the prefilter, one car alone: clock stamps of lane 0 of each wave (in the car's patch bytes)
+    hipLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(1), dim3(256), 0, 0, p); CK(hipDeviceSynchronize());
+    std::vector<long long> st(32);
+    CK(hipMemcpy(st.data(), d_patch, 32 * 8, hipMemcpyDeviceToHost));
+    const char *names[] = {"gather bits, fill", "axis 0", "barrier", "transposition", "gain", "axis 1"};
+    for (int w = 0; w < 4; ++w) {
+        printf("wave %d:", w);
+        for (int k = 0; k < 6; ++k) printf("  %s %lld", names[k], st[8 * w + k + 1] - st[8 * w + k]);
+        printf("  (clock64 ticks)\n");
     }
     CK(hipGetLastError());
     return 0;
