@@ -94,8 +94,10 @@ def needs_build(lib_path: str = LIB_PATH, csrc: str = CSRC) -> bool:
 # register without need - but a spill of that register to scratch would store it BEFORE the load has landed.  So the build
 # refuses a library in which one of these kernels spills or uses scratch at all, and one that has fallen below the
 # occupancy the launch geometry assumes.
-NO_SPILL_KERNELS = ("rc_raycast_car_kernel", "rc_raycast_car_stamps_kernel", "rc_raycast_kernel", "rc_patch_car_kernel")
-MIN_WAVES_PER_SIMD = {"rc_raycast_car_kernel": 8, "rc_patch_car_kernel": 8}
+NO_SPILL_KERNELS = ("rc_raycast_car_kernel", "rc_raycast_car_stamps_kernel", "rc_raycast_kernel", "rc_patch_car_kernel",
+                    "rc_patch_exact_prefilter_kernel", "rc_patch_exact_sample_kernel")
+# (the exact prefilter holds a line per lane in 161 + registers: one wave per SIMD by design - what it must not do is spill)
+MIN_WAVES_PER_SIMD = {"rc_raycast_car_kernel": 8, "rc_patch_car_kernel": 8, "rc_patch_exact_sample_kernel": 4}
 
 
 def check_resource_usage(remarks: str, required=("rc_raycast_car_kernel", "rc_patch_car_kernel"), min_waves=None) -> None:
@@ -111,7 +113,7 @@ def check_resource_usage(remarks: str, required=("rc_raycast_car_kernel", "rc_pa
         m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]): (\d+)", line)
         if not m or name is None:
             continue
-        kernel = next((k for k in NO_SPILL_KERNELS if k + "I" in name or name.endswith(k) or k + "E" in name), None)
+        kernel = next((k for k in NO_SPILL_KERNELS if k + "I" in name or name.endswith(k) or k + "E" in name or re.search(k + r"\d", name)), None)
         if kernel is None:
             continue
         seen.add(kernel)
@@ -229,7 +231,8 @@ def build(force: bool = False, verbose: bool = True, csrc: str = CSRC, lib_path:
     if other and verbose:
         print("\n".join(other), file=sys.stderr)
     try:
-        check_resource_usage(r.stderr)
+        check_resource_usage(r.stderr, required=("rc_raycast_car_kernel", "rc_patch_car_kernel", "rc_patch_exact_prefilter_kernel",
+                                                 "rc_patch_exact_sample_kernel"))
         verify_scan_assembly(verbose, csrc)
     except RuntimeError:
         os.remove(tmp)

@@ -126,6 +126,13 @@ def test_build_refuses_a_scan_kernel_that_spills():
     other = ok + ("k.hip:9:1: remark: Function Name: _ZN12_GLOBAL__N_118rc_dynamics_kernelILi4EEEv8RcParamsPfijjj [-Rpass-analysis=kernel-resource-usage]\n"
                   "k.hip:9:1: remark:     VGPRs Spill: 12 [-Rpass-analysis=kernel-resource-usage]\n")
     build.check_resource_usage(other)           # kernels without such loads may spill
+    # the exact render's prefilter keeps a line per lane in registers: one wave per SIMD is its design, a spill is refused
+    exact = ok + ("k.h:9:1: remark: Function Name: _Z31rc_patch_exact_prefilter_kernel13RcExactParams [-Rpass-analysis=kernel-resource-usage]\n"
+                  "k.h:9:1: remark:     Occupancy [waves/SIMD]: 1 [-Rpass-analysis=kernel-resource-usage]\n"
+                  "k.h:9:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]\n")
+    build.check_resource_usage(exact, required=("rc_raycast_car_kernel", "rc_patch_car_kernel", "rc_patch_exact_prefilter_kernel"))
+    with pytest.raises(RuntimeError, match="rc_patch_exact_prefilter_kernel.*VGPRs Spill = 15"):
+        build.check_resource_usage(exact.replace("k.h:9:1: remark:     VGPRs Spill: 0", "k.h:9:1: remark:     VGPRs Spill: 15"))
 
 
 def test_build_refuses_a_copy_of_a_register_with_a_load_in_flight():
