@@ -182,6 +182,9 @@ hipError_t rck_launch_set_pose(const RcParams &p, const float *xyyaw_dev, hipStr
 hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
 #define RC_EXACT_CAR_DOUBLES (220 * 220)         // scratch per car of a chunk: the 220 x 220 binary64 spline coefficients (387 200 B)
+#ifndef RC_EXACT_CHUNK_CARS
+#define RC_EXACT_CHUNK_CARS 5120                 // cars per chunk of the exact render (2 GB of scratch)
+#endif
 #define RC_EXACT_TABLE_INTS (64 * 15 + 64 * 2)   // Pillow's integer coefficients [64][15] and bounds [64][2]
 struct RcExactParams {
     const uint32_t *drv_words;   // drivable bitmap [h][pitch], ring cleared

@@ -289,6 +289,7 @@ __global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_kernel(RcExac
 // ------------------------------------------------------------------------------------------------- rotate, crop, resize
 #define PX_ST 256                              // threads of the sample kernel (320 = a 25 x 25 tile in two passes instead of three: one car alone 7 % faster,
                                                // 2 048 cars 36 % slower - five waves per workgroup do not spread evenly over four SIMDs)
+#define PX_RING 64                             // rows of the horizontally resized window kept in LDS (a power of two >= 15 + PX_T)
 #define PX_NTILES ((PX_WIN / PX_T) * (PX_WIN / PX_TW))
 #define PX_NPRE ((PX_TILE_N * PX_TILE_PITCH + PX_ST - 1) / PX_ST)      // coefficients of a tile per thread
 __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactParams p) {
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
     // A row of tiles is resized horizontally as soon as it is complete.
     __shared__ double tile[PX_TILE_N * PX_TILE_PITCH];
     __shared__ uint8_t win[PX_T * PX_WIN];
-    __shared__ uint8_t tmp[PX_WIN * PX_OUT];
+    __shared__ uint8_t tmp[PX_RING * PX_OUT];                          // the horizontally resized rows, a ring of PX_RING rows
     __shared__ int32_t kk[PX_OUT * PX_KSIZE];
     __shared__ int32_t bounds[PX_OUT * 2];
     __shared__ int32_t rects[PX_NTILES][4];
@@ -369,6 +370,7 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
     int r_lo = rects[0][0], c_lo = rects[0][1], nr = rects[0][2], nc = rects[0][3] & 0xffff;
     bool staged = nr > 0, edge = (rects[0][3] >> 16) != 0;
     fetch(staged, r_lo, c_lo, nr, nc);
+    int next_out = 0;                                                  // the first output row not written yet
     for (int ti = 0; ti < PX_WIN / PX_T; ++ti) {
         for (int tj = 0; tj < PX_WIN / PX_TW; ++tj) {
             const int ia = ti * PX_T, ja = tj * PX_TW;
@@ -437,18 +439,23 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
             int32_t acc = 1 << (PX_BITS - 1);
             for (int k = 0; k < xm; ++k) acc += (int32_t)win[r * PX_WIN + x0 + k] * kk[xx * PX_KSIZE + k];
             acc >>= PX_BITS;
-            tmp[ti * PX_T * PX_OUT + q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+            tmp[((ti * PX_T + r) & (PX_RING - 1)) * PX_OUT + xx] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
         }
         __syncthreads();
-    }
-    // ... vertical pass: 64 x 64, written once
-    for (int q = t; q < PX_OUT * PX_OUT; q += PX_ST) {
-        const int yy = q / PX_OUT, xx = q - yy * PX_OUT;
-        const int y0 = bounds[2 * yy], ym = bounds[2 * yy + 1];
-        int32_t acc = 1 << (PX_BITS - 1);
-        for (int k = 0; k < ym; ++k) acc += (int32_t)tmp[(y0 + k) * PX_OUT + xx] * kk[yy * PX_KSIZE + k];
-        acc >>= PX_BITS;
-        out[q] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+        // ... vertical pass: the output rows whose taps are all there now (an output row reaches back <= 15 rows, a row of tiles
+        // adds 25: the ring's 64 rows hold what is still needed - 12.8 KB of LDS less, a fifth workgroup per CU); each byte of the
+        // patch is written once
+        int lim = next_out;
+        while (lim < PX_OUT && bounds[2 * lim] + bounds[2 * lim + 1] <= (ti + 1) * PX_T) ++lim;       // (uniform)
+        for (int q = t; q < (lim - next_out) * PX_OUT; q += PX_ST) {
+            const int yy = next_out + q / PX_OUT, xx = q % PX_OUT;
+            const int y0 = bounds[2 * yy], ym = bounds[2 * yy + 1];
+            int32_t acc = 1 << (PX_BITS - 1);
+            for (int k = 0; k < ym; ++k) acc += (int32_t)tmp[((y0 + k) & (PX_RING - 1)) * PX_OUT + xx] * kk[yy * PX_KSIZE + k];
+            acc >>= PX_BITS;
+            out[yy * PX_OUT + xx] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+        }
+        next_out = lim;
     }
 }
 
