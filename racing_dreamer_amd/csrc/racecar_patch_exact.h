@@ -108,11 +108,17 @@ __device__ __forceinline__ int mirror(int i) {
                                                 // hoists hundreds of loads and spills)
 #define PXR_LINES (PX_CROP + 4)                 // + one dummy line per wave for the idle lanes 55 .. 63
 
-template <class Emit, class Block>
-__device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl, Emit emit, Block block) {
-    const double z = PX_Z, zn = PX_ZN;
-#define PXR_GET(i) ((i) < PXR_REG ? +S[(i) < PXR_REG ? (i) : 0] : +sl[(i) < PXR_REG ? 0 : (i) - PXR_REG])      // (rvalues: no pointer select)
+// Slot i of the lane's line: register S[i] for i < PXR_REG, else the lane's LDS row sl[i - PXR_REG].  i is a constant wherever these
+// are used (fully unrolled loops), so each expands to one of its branches; the two sides of PXR_GET are rvalues on purpose - as
+// lvalues the conditional becomes a select between a private and an LDS pointer and the whole array stays in scratch memory.
+#define PXR_GET(i) ((i) < PXR_REG ? +S[(i) < PXR_REG ? (i) : 0] : +sl[(i) < PXR_REG ? 0 : (i) - PXR_REG])
 #define PXR_PUT(i, v) do { if ((i) < PXR_REG) S[(i) < PXR_REG ? (i) : 0] = (v); else sl[(i) < PXR_REG ? 0 : (i) - PXR_REG] = (v); } while (0)
+
+// One line, in place: patch_reference.py, _filter_lines (the line already carries the gain).  `emit(i, v)` takes the results of the
+// backward pass (i = 219 .. 0).
+template <class Emit>
+__device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl, Emit emit) {
+    const double z = PX_Z, zn = PX_ZN;
     double c0 = PXR_GET(0) + zn * PXR_GET(PX_CROP - 1), zi = z;
 #pragma unroll
     for (int i = 1; i < PX_CROP - 1; ++i) {
@@ -131,8 +137,8 @@ __device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl
     }
     v = (z * prev + v) * z / (z * z - 1.0);
     emit(PX_CROP - 1, v);
-    // (blocks of PXR_TB steps: a loop whose body held the block's work at every step would exceed the unroller's size limit, be
-    // unrolled in part only, and leave the register array in scratch memory)
+    // (in blocks of PXR_TB steps: the unroller has a size limit - a body of 219 large steps gets unrolled in part only, and then the
+    // register array stays in scratch memory)
 #pragma unroll
     for (int m = (PX_CROP - 1) / PXR_TB; m >= 0; --m) {
 #pragma unroll
@@ -144,7 +150,6 @@ __device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl
             }
             if (k == PXR_SB) __builtin_amdgcn_sched_barrier(0);
         }
-        block(PXR_TB * m);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -161,8 +166,6 @@ __device__ __forceinline__ void pxr_transpose(double (&S)[PXR_REG], double *sl, 
     constexpr int sched[8][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}, {0, 1}, {2, 3}};     // the last two: diagonal blocks of waves a, b
 #pragma unroll
     for (int step = 0; step < 8; ++step) {
-        constexpr int dummy = 0;
-        (void)dummy;
         const int a = sched[step][0], b = sched[step][1];
         const bool in = W == a || W == b, diag = step >= 6;
         const int P = diag ? W : (W == a ? b : a);                    // the wave whose block range of slots moves
@@ -220,7 +223,7 @@ __device__ __forceinline__ void pxr_wave(const uint32_t (*cropw)[9], double (*sl
         }
         __builtin_amdgcn_sched_barrier(0);
         PXR_STAMP(1);
-        pxr_filter_line(S, sl, [&](int i, double v) { PXR_PUT(i, v); }, [](int) {});
+        pxr_filter_line(S, sl, [&](int i, double v) { PXR_PUT(i, v); });
         PXR_STAMP(2);
     }
     __syncthreads();          // (every wave is done with the crop bits: the exchange buffers may be written)
@@ -245,7 +248,7 @@ __device__ __forceinline__ void pxr_wave(const uint32_t (*cropw)[9], double (*sl
         // chain, and idle lanes storing to a dummy place cost a cache line of write traffic per step
         double *mine = colmaj + n;
         PXR_STAMP(5);
-        if (act) pxr_filter_line(S, sl, [&](int i, double v) { mine[(size_t)i * PX_CROP] = v; }, [](int) {});
+        if (act) pxr_filter_line(S, sl, [&](int i, double v) { mine[(size_t)i * PX_CROP] = v; });
         PXR_STAMP(6);
     }
 }
