@@ -104,8 +104,9 @@ __device__ __forceinline__ int mirror(int i) {
 #define PXR_LDS (PX_CROP - PXR_REG)
 #define PXR_LANES 55
 #define PXR_TB 16                               // the backward pass is unrolled in blocks of this many steps
+#ifndef PXR_SB
 #define PXR_SB 8                                // the scheduler may move code within blocks of this many steps only (else it
-                                                // hoists hundreds of loads and spills)
+#endif                                          // hoists hundreds of loads and spills; 16: no spill either, same time; 4, 12: spills)
 #define PXR_LINES (PX_CROP + 4)                 // + one dummy line per wave for the idle lanes 55 .. 63
 
 // Slot i of the lane's line: register S[i] for i < PXR_REG, else the lane's LDS row sl[i - PXR_REG].  i is a constant wherever these
