@@ -139,6 +139,15 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
         raise RacecarHipError(
             f"{path} not found: the HIP extension is not built. Run `python -m racing_dreamer_amd.build` "
             "(needs hipcc; cross-compiles for gfx950 without a GPU). There is no CPU fallback.")
+    if path == LIB_PATH and not os.environ.get("RC_ALLOW_STALE_LIBRARY"):
+        # A library that does not belong to the sources beside it would let every test pass on yesterday's kernels: refuse it.
+        # (The identity is a hash of flags and file CONTENTS compiled into the library, racing_dreamer_amd/build.py; the A/B
+        # scripts under tools/, which put variant builds in the library's place, set RC_ALLOW_STALE_LIBRARY=1.)
+        from . import build as _build
+        if os.path.isdir(_build.CSRC) and _build.needs_build(path):
+            raise RacecarHipError(
+                f"{path} was built from other sources than the ones in {_build.CSRC} (its build id {_build.library_build_id(path)}, "
+                f"theirs {_build.source_hash()}): run `python -m racing_dreamer_amd.build` (or __graft_entry__.build()) first.")
     lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is not exported

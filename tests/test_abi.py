@@ -101,6 +101,25 @@ def test_missing_library_fails_loudly(tmp_path):
         _lib._lib = saved
 
 
+def test_a_library_that_does_not_belong_to_the_sources_is_refused(monkeypatch):
+    """Round 6: a stale libracecar_hip.so (built, then a header edited) would let the GPU suite pass on yesterday's kernels.  The
+    loader compares the build id compiled into the library with the hash of the sources beside it and refuses a mismatch -
+    unless the A/B scripts' RC_ALLOW_STALE_LIBRARY says a variant build stands in the library's place."""
+    import pytest
+    from racing_dreamer_amd import _lib, build
+    saved = _lib._lib
+    _lib._lib = None
+    try:
+        monkeypatch.delenv("RC_ALLOW_STALE_LIBRARY", raising=False)
+        monkeypatch.setattr(build, "needs_build", lambda *a, **k: True)
+        with pytest.raises(_lib.RacecarHipError, match="built from other sources"):
+            _lib.load_library()
+        monkeypatch.setenv("RC_ALLOW_STALE_LIBRARY", "1")
+        assert _lib.load_library() is not None
+    finally:
+        _lib._lib = saved
+
+
 def test_build_refuses_a_scan_kernel_that_spills():
     """The scan hands a register to an asynchronous load in inline assembly and waits for it in a later statement: a spill
     of that register would store it before the load has landed.  The build parses the compiler's resource

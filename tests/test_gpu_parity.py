@@ -141,6 +141,13 @@ def test_reference_patches_dense_poses_equal_the_c_oracle(track_name):
     bad = np.nonzero((got != want).reshape(n, -1).any(1))[0]
     assert bad.size == 0, (track_name, bad.size, bad[:5], poses[bad[:5]])
     assert want.any() and not want.all() and set(np.unique(want)) <= {0, 1}
+    # the render works on a chunk of cars at a time (5 120; its scratch holds one chunk): the same in 11 chunks of 100, the last
+    # one of 24 - a car's patch does not depend on where in a chunk it falls
+    env.debug_set("exact_chunk", 100)
+    env.views["lidar_occupancy"].zero_()
+    again = env.set_pose(poses)["lidar_occupancy"]
+    torch.cuda.synchronize()
+    assert np.array_equal(again.cpu().numpy().reshape(n, 64, 64), want), track_name
     env.close()
 
 

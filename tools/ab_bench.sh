@@ -4,6 +4,7 @@
 #   build each variant, copy its libracecar_hip.so to racing_dreamer_amd/lib/ab/<name>.so, then
 #   bash tools/ab_bench.sh [reps] [bench args...]      prints the scan time of every variant, `reps` times in turn
 reps=${1:-3}; shift
+export RC_ALLOW_STALE_LIBRARY=1      # (variant builds take the library's place: racing_dreamer_amd/_lib.py)
 lib=racing_dreamer_amd/lib/libracecar_hip.so
 cp $lib /tmp/ab_original.so
 # whatever ends this script - Ctrl-C, a time-out, a failing step - the shipped library is put back

@@ -1,6 +1,7 @@
 #!/bin/bash
 # SQ counters of the scan for every variant in racing_dreamer_amd/lib/ab/ (GPU box): bash tools/ab_pmc.sh > gpurun_out/ab_pmc.log
 R=$(pwd); export TMPDIR=/tmp
+export RC_ALLOW_STALE_LIBRARY=1      # (variant builds take the library's place: racing_dreamer_amd/_lib.py)
 lib=racing_dreamer_amd/lib/libracecar_hip.so
 cp $lib /tmp/ab_pmc_original.so
 # whatever ends this script - Ctrl-C, a time-out, a failing step - the shipped library is put back
