@@ -99,7 +99,8 @@ __device__ __forceinline__ int mirror(int i) {
 // pass storing [column][row] - contiguous across lanes - straight from registers: the only memory traffic is the 387 KB result.
 // Forms measured before this one (EXPERIMENTS.md 000.4): forward values through memory (HBM-bound at 4.6 TB/s, 1.56 ms per 2 048
 // cars), lines in LDS ten per wave (80 lines in flight per CU: 0.97 ms), this form with the intermediate array through memory
-// (HBM-bound again: 0.54 ms); now 0.47 ms.
+// (HBM-bound again: 0.54 ms); now 0.47 ms - one car alone on a CU: 45 us = axis 0 14 + transposition 12 + axis 1 16 + the rest 3
+// (tools/ubench/exact_latency.hip), the axes at the chains' own length (660 two-operation and 220 one-operation steps).
 #define PXR_REG 161
 #define PXR_LDS (PX_CROP - PXR_REG)
 #define PXR_LANES 55
@@ -265,7 +266,6 @@ __global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_kernel(RcExac
     double *xb = lds + PXR_LINES * (PXR_LDS | 1);
     uint32_t (*cropw)[9] = reinterpret_cast<uint32_t (*)[9]>(xb);
     static_assert(PX_CROP * 9 * 4 <= 2 * PXR_XROWS * PXR_XPITCH * 8, "the crop bits share the exchange buffers");
-    const double z = PX_Z, gain = (1.0 - 1.0 / z) * (1.0 - z);
     int pr, pc;
     px::pixel_of(p, car, pr, pc);
     const int gx0 = (pc - PX_CROP / 2) - p.c0, gxw = gx0 >> 5;
