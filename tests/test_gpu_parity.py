@@ -154,6 +154,8 @@ def test_reference_patches_dense_poses_equal_the_c_oracle(track_name):
 def test_reference_patches_in_a_rollout_match_the_oracle():
     """... and inside the step: 48 envs, action_repeat 4, auto-reset (fresh episodes read zeros), all other outputs as ever."""
     _run_pair("columbia", num_envs=48, cars=1, steps=8, repeat=4, obs_type="lidar_occupancy_reference")
+    # two cars per env: a patch per car (the reference's wrapper renders the map, not the opponents)
+    _run_pair("treitlstrasse_v2", num_envs=12, cars=2, steps=6, repeat=2, mode="random_ball", obs_type="lidar_occupancy_reference")
 
 
 def test_occupancy_patch_matches_oracle():
