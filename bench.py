@@ -1297,7 +1297,7 @@ def run(args, guard, rank, local_rank, world, distributed, t0_run):
                 out["configs"] = [time_config(*c, settle=args.settle) for c in cfgs]
                 out["configs"].append(time_mixed_tracks(("columbia", "austria", "barcelona"), 65536, 100, 10, settle=args.settle))
         # obs_type lidar_occupancy_reference: the patch computed exactly as the reference's OccupancyMapObs.step does (binary64 spline
-        # rotation + Pillow's integer resize, racecar_patch_exact.h) - opt-in, ~100 x the fast sampler's cost: a few steps suffice
+        # rotation + Pillow's integer resize, racecar_patch_exact.h) - opt-in, ~600 x the fast sampler's cost: a few steps suffice
         if guard.go("exact_render", 15):
             with guard.leg("exact_render"):
                 n_x = min(args.envs, 16384)
