@@ -160,11 +160,12 @@ __device__ __forceinline__ void pxr_filter_line(double (&S)[PXR_REG], double *sl
 // i); axis 1 wants row 55 W + l there (column j in slot j).  Seen as 4 x 4 blocks of 55 lanes x 55 slots, block (W, P) of wave W
 // and block (P, W) of wave P swap, each transposed: both waves publish their block in LDS (xb[.][lane][slot], odd pitch), a
 // barrier, each reads the other's with lane and slot exchanged.  Two 55 x 55 buffers fit beside the lines' LDS part, so one pair of
-// waves (or two diagonal blocks) moves at a time: 8 steps.  W is a template parameter: every slot index is a constant.
+// waves (or two diagonal blocks) moves at a time: 8 steps.  W is a template parameter: every slot index is a constant.  Every value
+// passes exactly once: it is scaled by the gain on the way (the second pass scales its input too).
 #define PXR_XPITCH 57
 #define PXR_XROWS 56                            // 55 lanes + a row the idle lanes write to
 template <int W>
-__device__ __forceinline__ void pxr_transpose(double (&S)[PXR_REG], double *sl, double *xb, int lrow, int lcol) {
+__device__ __forceinline__ void pxr_transpose(double (&S)[PXR_REG], double *sl, double *xb, int lrow, int lcol, double gain) {
     constexpr int sched[8][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {0, 3}, {1, 2}, {0, 1}, {2, 3}};     // the last two: diagonal blocks of waves a, b
 #pragma unroll
     for (int step = 0; step < 8; ++step) {
@@ -180,7 +181,7 @@ __device__ __forceinline__ void pxr_transpose(double (&S)[PXR_REG], double *sl, 
         __syncthreads();
         if (in) {
 #pragma unroll
-            for (int q = 0; q < PXR_LANES; ++q) PXR_PUT(PXR_LANES * P + q, other[q * PXR_XPITCH + lcol]);
+            for (int q = 0; q < PXR_LANES; ++q) PXR_PUT(PXR_LANES * P + q, other[q * PXR_XPITCH + lcol] * gain);
         }
         __syncthreads();
     }
@@ -229,22 +230,16 @@ __device__ __forceinline__ void pxr_wave(const uint32_t (*cropw)[9], double (*sl
         PXR_STAMP(2);
     }
     __syncthreads();          // (every wave is done with the crop bits: the exchange buffers may be written)
-    // ---- columns -> rows, then axis 1: the line = row n, scaled by the gain first (the second pass scales its input too)
+    // ---- columns -> rows (scaled by the gain on the way), then axis 1: the line = row n
     {
         const int lrow = act ? lane : PXR_LANES, lcol = act ? lane : 0;
         __builtin_amdgcn_sched_barrier(0);
         PXR_STAMP(3);
-        pxr_transpose<W>(S, sl, xb, lrow, lcol);
+        pxr_transpose<W>(S, sl, xb, lrow, lcol, gain);
         PXR_STAMP(4);
         __builtin_amdgcn_sched_barrier(0);
     }
     {
-#pragma unroll
-        for (int i = 0; i < PX_CROP; ++i) {
-            const double f = PXR_GET(i) * gain;
-            PXR_PUT(i, f);
-            if (i % (4 * PXR_SB) == 0) __builtin_amdgcn_sched_barrier(0);
-        }
         // element (row n, column i) goes to colmaj[i * 220 + n]: contiguous across lanes.  The whole pass runs under the lane mask
         // of the 55 active lanes (one branch) - a store masked on its own costs a mask save / branch / restore at every step of the
         // chain, and idle lanes storing to a dummy place cost a cache line of write traffic per step

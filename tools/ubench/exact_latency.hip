@@ -42,7 +42,7 @@ int main() {
     hipLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(1), dim3(256), 0, 0, p); CK(hipDeviceSynchronize());
     std::vector<long long> st(32);
     CK(hipMemcpy(st.data(), d_patch, 32 * 8, hipMemcpyDeviceToHost));
-    const char *names[] = {"gather bits, fill", "axis 0", "barrier", "transposition", "gain", "axis 1"};
+    const char *names[] = {"gather bits, fill", "axis 0", "barrier", "transposition + gain", "-", "axis 1"};
     for (int w = 0; w < 4; ++w) {
         printf("wave %d:", w);
         for (int k = 0; k < 6; ++k) printf("  %s %lld", names[k], st[8 * w + k + 1] - st[8 * w + k]);
