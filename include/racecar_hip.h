@@ -75,7 +75,7 @@ enum { RC_OBS_LIDAR = 0, RC_OBS_LIDAR_OCCUPANCY = 1,                  /* dream.p
        RC_OBS_LIDAR_OCCUPANCY_REFERENCE = 2 };   /* lidar_occupancy computed EXACTLY as the reference's OccupancyMapObs.step does
                                                   * (dreamer/wrappers.py:396-406: to_pixel, 220 x 220 crop, cubic-spline rotation,
                                                   * centre crop, antialiased bicubic resize) instead of by the one-tap sampler of
-                                                  * RC_OBS_LIDAR_OCCUPANCY: bit-identical to the reference's patches, ~600 x the render's cost (0.6 us per car);
+                                                  * RC_OBS_LIDAR_OCCUPANCY: bit-identical to the reference's patches, ~500 x the render's cost (0.5 us per car);
                                                   * needs rc_set_source_frame */
 /* what RC_F_LIDAR holds: metres, or the caller-side scaling fused into the scan's store */
 enum { RC_LIDAR_METRES = 0,
@@ -391,7 +391,7 @@ enum { RC_DBG_RAY_THREADS = 0, RC_DBG_RAY_SPLIT = 1, RC_DBG_RAY_WG_PER_CU = 2, R
        RC_DBG_PATCH_VARIANT = 4,    /* lidar_occupancy render experiment: bit 1 = plain instead of non-temporal stores */
        RC_DBG_SCAN_BOUNDED = 5,     /* != 0: the scan runs the build whose trip loop carries a trip budget (see below) */
        RC_DBG_SCAN_ORDER = 6,   /* 0 = production (the scan takes the cars in track order, sorted every 64 observations), 1 = car index order, k > 1 = sorted every k - 1 observations */
-       RC_DBG_EXACT_CHUNK = 7,  /* k > 0: the exact render (RC_OBS_LIDAR_OCCUPANCY_REFERENCE) works on k cars at a time instead of 5 120
+       RC_DBG_EXACT_CHUNK = 7,  /* k > 0: the exact render (RC_OBS_LIDAR_OCCUPANCY_REFERENCE) works on k cars at a time instead of 6 144
                                  * (at most the size its scratch was allocated for) */
     RC_DBG_COUNT = 8 };
 int rc_debug_set(rc_env *env, int32_t knob, int32_t value);

@@ -865,8 +865,8 @@ int rc_set_source_frame(rc_env *env, int32_t full_height, int32_t row_top, int32
     if (full_height < 1 || !(resolution > 0.0)) return fail(RC_ERR_INVALID, "bad source frame: height %d, resolution %g", full_height, resolution);
     HIP_TRY(hipSetDevice(env->cfg.device));
     if (!env->exact_mem) {
-        // a chunk of cars in flight: 387 200 B of spline coefficients each.  RC_EXACT_CHUNK_CARS = 20 per CU: the prefilter runs one
-        // workgroup per CU, the sampling five - whole rounds for both
+        // a chunk of cars in flight: 387 200 B of spline coefficients each.  RC_EXACT_CHUNK_CARS = 24 per CU: the prefilter runs one
+        // workgroup per CU, the sampling six - whole rounds for both
         env->exact_chunk = env->n_cars < RC_EXACT_CHUNK_CARS ? env->n_cars : RC_EXACT_CHUNK_CARS;
         const size_t tab_bytes = (size_t)RC_EXACT_TABLE_INTS * 4, scratch = (size_t)env->exact_chunk * RC_EXACT_CAR_DOUBLES * 8;
         HIP_TRY(hipMalloc(&env->exact_mem, scratch + align_up(tab_bytes, 64)));

@@ -183,7 +183,7 @@ hipError_t rck_launch_raycast(const RcParams &p, const RcLaunchInfo &li, hipStre
 hipError_t rck_launch_patch(const RcParams &p, const RcLaunchInfo &li, hipStream_t s);
 #define RC_EXACT_CAR_DOUBLES (220 * 220)         // scratch per car of a chunk: the 220 x 220 binary64 spline coefficients (387 200 B)
 #ifndef RC_EXACT_CHUNK_CARS
-#define RC_EXACT_CHUNK_CARS 5120                 // cars per chunk of the exact render (2 GB of scratch)
+#define RC_EXACT_CHUNK_CARS 6144                 // cars per chunk of the exact render (2.4 GB of scratch)
 #endif
 #define RC_EXACT_TABLE_INTS (64 * 15 + 64 * 2)   // Pillow's integer coefficients [64][15] and bounds [64][2]
 struct RcExactParams {

@@ -8,9 +8,10 @@
 //       (387 KB per car - no LDS holds it: the registers and the LDS of a CU together do), both axes and the transposition between
 //       them on the chip, the result written once to the car's scratch in [column][row] order.
 //   rc_patch_exact_sample_kernel      one 256-thread workgroup per car: the 200 x 200 centre window of the rotated image in tiles
-//       of 25 x 20 pixels (a tile's coefficients staged in LDS, the next tile's already on their way in registers; weights and the
-//       16 taps in binary64, rounded to uint8 as the library does), then Pillow's two integer passes (200 x 200 -> 200 x 64 -> 64 x
-//       64) from LDS, the patch written once.
+//       of 25 x 20 pixels (a tile's coefficients staged in LDS, the next tile's already on their way in registers; a pixel is
+//       decided by a binary32 estimate of its 16-tap sum wherever the estimate's error bound allows, by the library's binary64
+//       sum where it does not - PX_BAND), then Pillow's two integer passes (200 x 200 -> 200 x 64 -> 64 x 64) from LDS, the patch
+//       written once.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -78,6 +79,16 @@ __device__ __forceinline__ void weights(double cc, double (&w)[4]) {
     w[2] = div6((z - 2.0) * (z * z) * 3.0 + 4.0);
     w[0] = div6((z * z) * z);
     w[3] = ((1.0 - w[0]) - w[1]) - w[2];
+}
+
+// The same weights in binary32 from the fractional part - for the sampling pass's ESTIMATE only (see PX_BAND): absolute error
+// <= 1e-6 each, <= 2e-6 for the one got by subtraction.
+__device__ __forceinline__ void weights32(float y, float (&w)[4]) {
+    const float z = 1.0f - y, sixth = 1.0f / 6.0f;
+    w[1] = ((y * y) * (y - 2.0f) * 3.0f + 4.0f) * sixth;
+    w[2] = ((z - 2.0f) * (z * z) * 3.0f + 4.0f) * sixth;
+    w[0] = ((z * z) * z) * sixth;
+    w[3] = ((1.0f - w[0]) - w[1]) - w[2];
 }
 
 __device__ __forceinline__ int mirror(int i) {
@@ -288,6 +299,15 @@ __global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_kernel(RcExac
 // ------------------------------------------------------------------------------------------------- rotate, crop, resize
 #define PX_ST 256                              // threads of the sample kernel (320 = a 25 x 25 tile in two passes instead of three: one car alone 7 % faster,
                                                // 2 048 cars 36 % slower - five waves per workgroup do not spread evenly over four SIMDs)
+// The sampling pass decides a pixel by a binary32 ESTIMATE of the interpolated value and computes the library's binary64 sum only
+// where the estimate cannot decide.  The pixel is floor(tv + 0.5), clamped; the estimate's error is bounded: a spline coefficient
+// of an image with values in [0, 1] is at most 9 in magnitude (the prefilter's impulse response 1.732 x 0.268^|k| sums to 3 per
+// axis; measured: 1.87), its binary32 copy is off by <= 9 x 6e-8, a binary32 weight by <= 1e-6 (eight operations on values <= 6,
+// the fraction rounded to binary32) and the one got by subtraction by <= 2e-6, the exact weights of an axis sum to 1, and 20 fused
+// multiply-adds on partial sums <= 9 add <= 1.1e-5: |estimate - exact| <= 9 x (5e-6 + 5e-6) + 5.4e-7 + 1.1e-5 < 1.1e-4.  PX_BAND
+// leaves a factor of 9: outside the band estimate and exact sum lie between the same two integers.  (The patches of 131 072 poses
+// on all 32 maps, of the 379 goldens and of every parity test equal the oracle's, which computes every pixel in binary64.)
+#define PX_BAND 1.0e-3f
 #define PX_RING 64                             // rows of the horizontally resized window kept in LDS (a power of two >= 15 + PX_T)
 #define PX_NTILES ((PX_WIN / PX_T) * (PX_WIN / PX_TW))
 #define PX_NPRE ((PX_TILE_N * PX_TILE_PITCH + PX_ST - 1) / PX_ST)      // coefficients of a tile per thread
@@ -304,7 +324,7 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
     // in up to 64 different cache lines, and the texture-address unit, not the arithmetic, set the pace: 1.51 ms per 2 048 cars;
     // more workgroups per CU made it worse (their 387 KB arrays push each other out of the XCD's L2: EXPERIMENTS.md 000.4).
     // A row of tiles is resized horizontally as soon as it is complete.
-    __shared__ double tile[PX_TILE_N * PX_TILE_PITCH];
+    __shared__ float tile[PX_TILE_N * PX_TILE_PITCH];                  // the tile's coefficients, rounded to binary32 (the estimate's operands)
     __shared__ uint8_t win[PX_T * PX_WIN];
     __shared__ uint8_t tmp[PX_RING * PX_OUT];                          // the horizontally resized rows, a ring of PX_RING rows
     __shared__ int32_t kk[PX_OUT * PX_KSIZE];
@@ -378,7 +398,7 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
             if (staged_t) {
 #pragma unroll
                 for (int k = 0; k < PX_NPRE; ++k)
-                    if (t + PX_ST * k < PX_TILE_N * PX_TILE_PITCH) tile[t + PX_ST * k] = pre[k];      // [column][row], pitch = PX_TILE_PITCH
+                    if (t + PX_ST * k < PX_TILE_N * PX_TILE_PITCH) tile[t + PX_ST * k] = (float)pre[k];      // [column][row], pitch = PX_TILE_PITCH
             }
             __syncthreads();
             {
@@ -392,42 +412,64 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
             for (int q = t; q < PX_T * PX_TW; q += PX_ST) {
                 const int il = q / PX_TW, jl = q - il * PX_TW, i = ia + il, j = ja + jl;
                 const double cc0 = src0(i, j), cc1 = src1(i, j);
-                double tv = 0.0;
+                int pix = 0;
                 if (!(cc0 < 0 || cc0 > PX_CROP - 1 || cc1 < 0 || cc1 > PX_CROP - 1)) {
-                    double w0[4], w1[4];
-                    px::weights(cc0, w0);
-                    px::weights(cc1, w1);
-                    const int st0 = (int)floor(cc0) - 1, st1 = (int)floor(cc1) - 1;
-                    if (staged_t && !edge_t) {                          // (most tiles: no tap beyond the array, nothing to mirror)
-                        const double *t0 = tile + (st1 - c_lo_t) * PX_TILE_PITCH + (st0 - r_lo_t);
+                    const double f0 = floor(cc0), f1 = floor(cc1);
+                    const int st0 = (int)f0 - 1, st1 = (int)f1 - 1;
+                    bool exact = !staged_t;
+                    if (staged_t) {
+                        // the ESTIMATE: weights and taps in binary32 from the staged binary32 copy (a third of the exact sum's issue
+                        // cycles).  The pixel is floor(tv + 0.5) clamped to 0 .. 255, so the estimate decides it unless tv + 0.5 lies
+                        // within PX_BAND of an integer - then, and only then, the lane computes the exact sum below
+                        float w0[4], w1[4];
+                        px::weights32((float)(cc0 - f0), w0);
+                        px::weights32((float)(cc1 - f1), w1);
+                        float tvf = 0.0f;
+                        if (!edge_t) {                                 // (most tiles: no tap beyond the array, nothing to mirror)
+                            const float *t0 = tile + (st1 - c_lo_t) * PX_TILE_PITCH + (st0 - r_lo_t);
 #pragma unroll
-                        for (int a = 0; a < 4; ++a)
+                            for (int a = 0; a < 4; ++a) {
+                                float rs = 0.0f;
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) tv = tv + (t0[b * PX_TILE_PITCH + a] * w0[a]) * w1[b];
-                    } else if (staged_t) {
-                        int col[4];
+                                for (int b = 0; b < 4; ++b) rs = __builtin_fmaf(t0[b * PX_TILE_PITCH + a], w1[b], rs);
+                                tvf = __builtin_fmaf(rs, w0[a], tvf);
+                            }
+                        } else {
+                            int col[4];
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) col[b] = (px::mirror(st1 + b) - c_lo_t) * PX_TILE_PITCH - r_lo_t;
+                            for (int b = 0; b < 4; ++b) col[b] = (px::mirror(st1 + b) - c_lo_t) * PX_TILE_PITCH - r_lo_t;
 #pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            const int row = px::mirror(st0 + a);
+                            for (int a = 0; a < 4; ++a) {
+                                const int row = px::mirror(st0 + a);
+                                float rs = 0.0f;
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) tv = tv + (tile[col[b] + row] * w0[a]) * w1[b];
+                                for (int b = 0; b < 4; ++b) rs = __builtin_fmaf(tile[col[b] + row], w1[b], rs);
+                                tvf = __builtin_fmaf(rs, w0[a], tvf);
+                            }
                         }
-                    } else {
+                        const float u = tvf + 0.5f, fl = floorf(u);
+                        exact = u - fl < PX_BAND || (fl + 1.0f) - u < PX_BAND;
+                        pix = fl < 0.0f ? 0 : (fl > 255.0f ? 255 : (int)fl);
+                    }
+                    if (exact) {                                       // the library's sum, operation by operation, from the binary64 array
+                        double w0[4], w1[4];
+                        px::weights(cc0, w0);
+                        px::weights(cc1, w1);
                         int col[4];
 #pragma unroll
                         for (int b = 0; b < 4; ++b) col[b] = px::mirror(st1 + b) * PX_CROP;
+                        double tv = 0.0;
 #pragma unroll
                         for (int a = 0; a < 4; ++a) {
                             const int row = px::mirror(st0 + a);
 #pragma unroll
                             for (int b = 0; b < 4; ++b) tv = tv + (coef[col[b] + row] * w0[a]) * w1[b];
                         }
+                        tv = tv > 0 ? tv + 0.5 : 0.0;
+                        pix = (int)(uint8_t)(tv > 255.0 ? 255.0 : tv);
                     }
                 }
-                tv = tv > 0 ? tv + 0.5 : 0.0;
-                win[il * PX_WIN + j] = (uint8_t)(tv > 255.0 ? 255.0 : tv);
+                win[il * PX_WIN + j] = (uint8_t)pix;
             }
             __syncthreads();          // (the next tile's staging overwrites `tile`)
         }
