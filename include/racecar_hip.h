@@ -430,6 +430,14 @@ int rc_selftest_sqrt(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
  * compares that with the device's own binary64 division over 2^32 operands from 2^-160 to 8, either sign; n_mismatch must be 0. */
 int rc_selftest_div6(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch);
 
+/* The exact render decides a pixel of the rotated window by a binary32 estimate of its 16-tap sum wherever that estimate lies more
+ * than 1e-3 from a rounding boundary, and by the library's binary64 sum elsewhere (racecar_patch_exact.h, PX_BAND: the estimate's
+ * error is bounded by 1.1e-4).  This renders the env's cars once more with BOTH computed for every pixel: out[0] = pixels inside
+ * the array, out[1] = those the band sent to the binary64 sum, out[2] = those the estimate alone would have got wrong (0, or the
+ * bound does not hold), out[3] = the largest |estimate - binary64 sum| seen, as the bits of a binary32.  The patches are written
+ * as by an observation.  tests/test_gpu_api.py. */
+int rc_selftest_exact_estimate(rc_env *env, uint64_t out[4]);
+
 const char *rc_last_error(void);
 int rc_abi_version(void);
 /* Hash (32 hex digits) of the compiler flags and of the contents of every source and header this library was built

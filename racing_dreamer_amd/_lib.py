@@ -117,6 +117,7 @@ SYMBOLS = {
     "rc_selftest_reciprocal": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rc_selftest_sqrt": (C.c_int, [C.c_int32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "rc_selftest_div6": (C.c_int, [C.c_int32, _P(C.c_uint64), _P(C.c_uint64)]),
+    "rc_selftest_exact_estimate": (C.c_int, [C.c_void_p, _P(C.c_uint64)]),
     "rc_last_error": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),
     "rc_build_id": (C.c_char_p, []),

@@ -635,6 +635,29 @@ int rc_selftest_div6(int32_t device, uint64_t *n_checked, uint64_t *n_mismatch) 
     return RC_OK;
 }
 
+int rc_selftest_exact_estimate(rc_env *env, uint64_t out[4]) {
+    if (!env || !out) return fail(RC_ERR_INVALID, "NULL argument");
+    if (env->cfg.obs_type != RC_OBS_LIDAR_OCCUPANCY_REFERENCE)
+        return fail(RC_ERR_INVALID, "rc_selftest_exact_estimate is for obs_type lidar_occupancy_reference (this handle: %d)", env->cfg.obs_type);
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    unsigned long long *dev = nullptr, host[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMalloc((void **)&dev, sizeof(host)));
+    hipError_t e = hipMemsetAsync(dev, 0, sizeof(host), env->stream);
+    int rc = RC_OK;
+    if (e == hipSuccess) {
+        env->exact.check = dev;
+        rc = render_reference_patches(env);                    // the patches themselves come out as ever
+        env->exact.check = nullptr;
+        e = hipStreamSynchronize(env->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(host, dev, sizeof(host), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (rc != RC_OK) return rc;
+    if (e != hipSuccess) return fail(RC_ERR_HIP, "rc_selftest_exact_estimate: %s", hipGetErrorString(e));
+    for (int k = 0; k < 4; ++k) out[k] = host[k];
+    return RC_OK;
+}
+
 void rc_spec_tables(float *beams_1080x2, float *footprint_34x2) {
     if (beams_1080x2 && footprint_34x2) make_tables(beams_1080x2, footprint_34x2);
 }

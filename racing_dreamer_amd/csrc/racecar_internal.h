@@ -197,6 +197,7 @@ struct RcExactParams {
     uint8_t *patch;              // [n_cars][64][64]
     const int32_t *kk;           // [64][15] Pillow's integer coefficients, [64][2] bounds behind them
     int32_t car0, n_cars;
+    unsigned long long *check;   // rc_selftest_exact_estimate: 4 counters (racecar_patch_exact.h, CHECK); nullptr in production
 };
 hipError_t rck_launch_patch_exact(const RcExactParams &p, int chunk_cars, hipStream_t s);   // obs_type lidar_occupancy_reference (racecar_patch_exact.h)
 hipError_t rck_launch_ftg(const RcParams &p, float *actions, float motor_straight, float motor_corner, hipStream_t s);

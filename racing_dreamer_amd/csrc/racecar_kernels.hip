@@ -2004,7 +2004,8 @@ hipError_t rck_launch_patch_exact(const RcExactParams &p0, int chunk_cars, hipSt
         const int n = p0.n_cars - c0 < chunk_cars ? p0.n_cars - c0 : chunk_cars;
         p.car0 = c0;
         hipExtLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(n), dim3(256), 0u, s, c0 == 0 ? a : nullptr, nullptr, 0u, p);
-        hipExtLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(n), dim3(PX_ST), 0u, s, nullptr, c0 + n >= p0.n_cars ? b : nullptr, 0u, p);
+        if (p.check) hipExtLaunchKernelGGL(rc_patch_exact_sample_kernel<true>, dim3(n), dim3(PX_ST), 0u, s, nullptr, c0 + n >= p0.n_cars ? b : nullptr, 0u, p);
+        else hipExtLaunchKernelGGL(rc_patch_exact_sample_kernel<false>, dim3(n), dim3(PX_ST), 0u, s, nullptr, c0 + n >= p0.n_cars ? b : nullptr, 0u, p);
     }
     return hipGetLastError();
 }

@@ -311,6 +311,10 @@ __global__ __launch_bounds__(256, 1) void rc_patch_exact_prefilter_kernel(RcExac
 #define PX_RING 64                             // rows of the horizontally resized window kept in LDS (a power of two >= 15 + PX_T)
 #define PX_NTILES ((PX_WIN / PX_T) * (PX_WIN / PX_TW))
 #define PX_NPRE ((PX_TILE_N * PX_TILE_PITCH + PX_ST - 1) / PX_ST)      // coefficients of a tile per thread
+// CHECK (rc_selftest_exact_estimate): every pixel's exact sum is computed beside its estimate; p.check counts the pixels inside the
+// array, those the band sent to the exact sum, those the estimate alone would have decided differently (must be 0) and keeps the
+// largest |estimate - exact| seen (binary32 bits).
+template <bool CHECK>
 __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactParams p) {
     const int car = p.car0 + (int)blockIdx.x, t = (int)threadIdx.x;
     uint8_t *out = p.patch + (size_t)car * (PX_OUT * PX_OUT);
@@ -390,6 +394,8 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
     bool staged = nr > 0, edge = (rects[0][3] >> 16) != 0;
     fetch(staged, r_lo, c_lo, nr, nc);
     int next_out = 0;                                                  // the first output row not written yet
+    unsigned long long chk_inside = 0, chk_band = 0, chk_wrong = 0;
+    float chk_err = 0.0f;
     for (int ti = 0; ti < PX_WIN / PX_T; ++ti) {
         for (int tj = 0; tj < PX_WIN / PX_TW; ++tj) {
             const int ia = ti * PX_T, ja = tj * PX_TW;
@@ -417,6 +423,8 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
                     const double f0 = floor(cc0), f1 = floor(cc1);
                     const int st0 = (int)f0 - 1, st1 = (int)f1 - 1;
                     bool exact = !staged_t;
+                    float est = 0.0f;
+                    int est_pix = -1;
                     if (staged_t) {
                         // the ESTIMATE: weights and taps in binary32 from the staged binary32 copy (a third of the exact sum's issue
                         // cycles).  The pixel is floor(tv + 0.5) clamped to 0 .. 255, so the estimate decides it unless tv + 0.5 lies
@@ -450,8 +458,9 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
                         const float u = tvf + 0.5f, fl = floorf(u);
                         exact = u - fl < PX_BAND || (fl + 1.0f) - u < PX_BAND;
                         pix = fl < 0.0f ? 0 : (fl > 255.0f ? 255 : (int)fl);
+                        if (CHECK) { est = tvf; est_pix = pix; chk_inside += 1; chk_band += exact ? 1 : 0; }
                     }
-                    if (exact) {                                       // the library's sum, operation by operation, from the binary64 array
+                    if (exact || CHECK) {                                       // the library's sum, operation by operation, from the binary64 array
                         double w0[4], w1[4];
                         px::weights(cc0, w0);
                         px::weights(cc1, w1);
@@ -465,8 +474,10 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
 #pragma unroll
                             for (int b = 0; b < 4; ++b) tv = tv + (coef[col[b] + row] * w0[a]) * w1[b];
                         }
+                        if (CHECK && est_pix >= 0) chk_err = fmaxf(chk_err, fabsf(est - (float)tv));
                         tv = tv > 0 ? tv + 0.5 : 0.0;
                         pix = (int)(uint8_t)(tv > 255.0 ? 255.0 : tv);
+                        if (CHECK && est_pix >= 0 && !exact && est_pix != pix) chk_wrong += 1;
                     }
                 }
                 win[il * PX_WIN + j] = (uint8_t)pix;
@@ -497,6 +508,12 @@ __global__ __launch_bounds__(PX_ST) void rc_patch_exact_sample_kernel(RcExactPar
             out[yy * PX_OUT + xx] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
         }
         next_out = lim;
+    }
+    if (CHECK) {
+        if (chk_inside) atomicAdd(p.check + 0, chk_inside);
+        if (chk_band) atomicAdd(p.check + 1, chk_band);
+        if (chk_wrong) atomicAdd(p.check + 2, chk_wrong);
+        atomicMax(p.check + 3, (unsigned long long)__float_as_uint(chk_err));       // (non-negative floats order like their bits)
     }
 }
 

@@ -373,6 +373,42 @@ def test_division_by_six_without_a_division_is_exact_on_this_device():
     assert n.value == 1 << 32 and bad.value == 0
 
 
+def test_the_exact_renders_estimate_never_decides_a_pixel_wrongly():
+    """The exact render decides a pixel of the rotated window by a binary32 estimate of its 16-tap sum unless the estimate lies
+    within 1e-3 of a rounding boundary - only there the library's binary64 sum is computed (racecar_patch_exact.h, PX_BAND; the
+    estimate's error is bounded by 1.1e-4).  `rc_selftest_exact_estimate` computes BOTH for every pixel: over 4 096 poses on two
+    tracks (163 M pixels) the estimate alone would never have set a pixel differently, its largest error stays an order of
+    magnitude inside the band, and a fraction of a percent of the pixels take the binary64 path."""
+    import ctypes as C
+    import struct
+    import torch
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track
+    for name in ("austria", "columbia"):
+        t = load_track(name)
+        rng = np.random.default_rng(5)
+        n = 2048
+        x = t.origin[0] + rng.uniform(-0.5, t.width * 0.05 + 0.5, n)
+        y = t.origin[1] + rng.uniform(-0.5, t.height * 0.05 + 0.5, n)
+        cl = t.centerline[rng.integers(0, len(t.centerline), n // 2)]
+        x[:n // 2], y[:n // 2] = cl[:, 0] + rng.uniform(-0.5, 0.5, n // 2), cl[:, 1] + rng.uniform(-0.5, 0.5, n // 2)
+        poses = np.stack([x, y, rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+        env = BatchedRaceEnv(t, n, 1, obs_type="lidar_occupancy_reference")
+        env.reset()
+        want = env.set_pose(poses)["lidar_occupancy"].clone()
+        out = (C.c_uint64 * 4)()
+        L.check(env._lib.rc_selftest_exact_estimate(env._h, out))
+        torch.cuda.synchronize()
+        inside, band, wrong, err = out[0], out[1], out[2], struct.unpack("f", struct.pack("I", out[3] & 0xffffffff))[0]
+        assert torch.equal(env.views["lidar_occupancy"], want)            # the self-test's render is the render
+        env.close()
+        assert inside > 0.5 * n * 200 * 200, (name, inside)
+        assert wrong == 0, (name, wrong)
+        assert 0.0 < err < 1.1e-4, (name, err)
+        assert 0 < band < 0.01 * inside, (name, band, inside)
+
+
 def test_a_lab_library_built_against_other_headers_is_refused(tmp_path):
     """RcParams and RcLaunchInfo cross the lab boundary by pointer, so a lab library built against other headers would
     read them wrongly - wrong scans or a GPU fault, no error.  The lab says what it was built against (`rclab_abi`: struct sizes

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """obs_type lidar_occupancy_reference on EVERY compiled map (GPU box): the HIP kernels against the C oracle's exact render
 (oracle/racecar_oracle.c, oc_patch_exact_range) from `n` poses per map - half near the centre line, the rest anywhere on the grid
-and beyond it, an eighth on cell corners with axis-aligned and diagonal headings.  python tools/exact_all_tracks.py [n]"""
+and beyond it, an eighth on cell corners with axis-aligned and diagonal headings; and the binary32 estimate of the sampling pass
+against the binary64 sum on every pixel of those renders (rc_selftest_exact_estimate).  python tools/exact_all_tracks.py [n]"""
+import ctypes
 import os
+import struct
 import sys
 import time
 
@@ -11,11 +14,13 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import c_oracle, racecar_oracle as ro  # noqa: E402
+from racing_dreamer_amd import _lib as L  # noqa: E402
 from racing_dreamer_amd.batched_env import BatchedRaceEnv  # noqa: E402
 from racing_dreamer_amd.track_assets import available_tracks, load_track  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 total = bad_total = 0
+tot, worst = [0, 0, 0], 0.0
 t0 = time.time()
 for k, name in enumerate(sorted(available_tracks())):
     t = load_track(name)
@@ -45,10 +50,18 @@ for k, name in enumerate(sorted(available_tracks())):
     got = env.set_pose(poses)["lidar_occupancy"]
     torch.cuda.synchronize()
     got = got.cpu().numpy().reshape(n, 64, 64)
+    chk = (ctypes.c_uint64 * 4)()                                     # both sums for every pixel (rc_selftest_exact_estimate)
+    L.check(env._lib.rc_selftest_exact_estimate(env._h, chk))
+    err = struct.unpack("f", struct.pack("I", chk[3] & 0xffffffff))[0]
+    tot = [a + b for a, b in zip(tot, (chk[0], chk[1], chk[2]))]
+    worst = max(worst, err)
     env.close()
     bad = int((got != want).reshape(n, -1).any(1).sum())
     total += n
     bad_total += bad
-    print(f"{name:28s} {t.height:5d} x {t.width:<5d} {n} poses: {bad} patches differ; mean drivable share of a patch {want.mean():.3f}", flush=True)
-print(f"{total} patches on {k + 1} maps in {time.time() - t0:.0f} s: {bad_total} differ")
-sys.exit(1 if bad_total else 0)
+    print(f"{name:28s} {t.height:5d} x {t.width:<5d} {n} poses: {bad} patches differ; estimate: {chk[1] / max(chk[0], 1) * 100:.4f} % of the pixels in the band, "
+          f"{chk[2]} decided wrongly, largest error {err:.2e}", flush=True)
+print(f"{total} patches on {k + 1} maps in {time.time() - t0:.0f} s: {bad_total} differ; the binary32 estimate: {tot[0]} pixels inside the array, "
+      f"{tot[1]} ({tot[1] / max(tot[0], 1) * 100:.4f} %) sent to the binary64 sum by the band, {tot[2]} the estimate alone would have got wrong, "
+      f"largest |estimate - binary64 sum| {worst:.2e} (bound 1.1e-4, band 1e-3)")
+sys.exit(1 if bad_total or tot[2] else 0)

@@ -28,7 +28,7 @@ int main() {
     CK(hipMemcpy(s.data(), d_s, s.size() * 8, hipMemcpyDeviceToHost));
     double mx = 0; for (int i = 0; i < 220 * 220; ++i) mx = fmax(mx, fabs(s[i]));
     printf("prefilter: max |coefficient| %g  coefficient[110][110] %.17g\n", mx, s[110 * 220 + 110]);
-    hipLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(1), dim3(PX_ST), 0, 0, p);
+    hipLaunchKernelGGL(rc_patch_exact_sample_kernel<false>, dim3(1), dim3(PX_ST), 0, 0, p);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());
     std::vector<uint8_t> patch(4096);
     CK(hipMemcpy(patch.data(), d_patch, 4096, hipMemcpyDeviceToHost));

@@ -33,7 +33,7 @@ int main() {
             float ms;
             CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_prefilter_kernel, dim3(g), dim3(256), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
             CK(hipEventElapsedTime(&ms, a, b)); best[0] = ms < best[0] ? ms : best[0];
-            CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_sample_kernel, dim3(g), dim3(PX_ST), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+            CK(hipEventRecord(a)); hipLaunchKernelGGL(rc_patch_exact_sample_kernel<false>, dim3(g), dim3(PX_ST), 0, 0, p); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
             CK(hipEventElapsedTime(&ms, a, b)); best[1] = ms < best[1] ? ms : best[1];
         }
         printf("%5d cars: prefilter %8.1f us   sample %8.1f us\n", g, best[0] * 1e3, best[1] * 1e3);
