@@ -151,6 +151,54 @@ def test_reference_patches_dense_poses_equal_the_c_oracle(track_name):
     env.close()
 
 
+@pytest.mark.parametrize("pattern", ["checkerboard", "stripes", "noise"])
+def test_reference_patches_on_adversarial_drivable_patterns(pattern):
+    """The exact render where the spline coefficients are as large as a 0 / 1 image can make them (a checkerboard drives the
+    prefilter to its extremes; the tracks' smooth regions never do): the drivable bitmap of columbia replaced by a pattern, 512
+    poses, HIP == C oracle on every pixel - and the sampling pass's binary32 estimate, checked against the binary64 sum on every
+    pixel of these renders, never decides one wrongly and stays inside its error bound (racecar_patch_exact.h, PX_BAND)."""
+    import ctypes as C
+    import dataclasses
+    import struct
+    import torch
+    from oracle import c_oracle
+    from racing_dreamer_amd import _lib as L
+    from racing_dreamer_amd.batched_env import BatchedRaceEnv
+    from racing_dreamer_amd.track_assets import load_track, pack_words
+    t0 = load_track("columbia")
+    yy, xx = np.mgrid[0:t0.height, 0:t0.width]
+    rng = np.random.default_rng(3)
+    drv = {"checkerboard": (yy + xx) % 2 == 0, "stripes": xx % 2 == 0, "noise": rng.random((t0.height, t0.width)) < 0.5}[pattern]
+    drv[0, :] = drv[-1, :] = drv[:, 0] = drv[:, -1] = False             # (the env's spec: the outermost ring is not drivable)
+    t = dataclasses.replace(t0, drv_words=pack_words(drv, t0.pitch))
+    n = 512
+    poses = np.stack([t.origin[0] + rng.uniform(-0.5, t.width * 0.05 + 0.5, n), t.origin[1] + rng.uniform(-0.5, t.height * 0.05 + 0.5, n),
+                      rng.uniform(-np.pi, np.pi, n)], 1).astype(np.float32)
+    poses[:64, 2] = rng.choice([0.0, np.pi / 2, np.pi / 4, -3 * np.pi / 4], 64)
+    cfg = ro.OracleConfig(num_envs=n, cars_per_env=1, render_occupancy="reference")
+    ora = c_oracle.COracleEnv(t.occ, t.drivable, t.progress, t.centerline, t.origin, t.resolution, cfg, threads=8)
+    ora.set_frame(t)
+    ora.reset()
+    ora.arr["x"][:], ora.arr["y"][:], ora.arr["theta"][:] = poses[:, 0], poses[:, 1], poses[:, 2]
+    ora.arr["st"][:], ora.arr["ct"][:] = ro.sincos32(poses[:, 2])
+    ora.arr["fresh"][:] = 0
+    ora._observe()
+    want = ora.patch.reshape(n, 64, 64)
+    env = BatchedRaceEnv(t, n, 1, obs_type="lidar_occupancy_reference")
+    env.reset()
+    got = env.set_pose(poses)["lidar_occupancy"]
+    torch.cuda.synchronize()
+    got = got.cpu().numpy().reshape(n, 64, 64)
+    bad = np.nonzero((got != want).reshape(n, -1).any(1))[0]
+    assert bad.size == 0, (pattern, bad.size, bad[:5])
+    assert want.any() and len(np.unique(want)) >= 2
+    out = (C.c_uint64 * 4)()
+    L.check(env._lib.rc_selftest_exact_estimate(env._h, out))
+    env.close()
+    err = struct.unpack("f", struct.pack("I", out[3] & 0xffffffff))[0]
+    assert out[0] > 0 and out[2] == 0 and err < 1.1e-4, (pattern, list(out), err)
+
+
 def test_reference_patches_in_a_rollout_match_the_oracle():
     """... and inside the step: 48 envs, action_repeat 4, auto-reset (fresh episodes read zeros), all other outputs as ever."""
     _run_pair("columbia", num_envs=48, cars=1, steps=8, repeat=4, obs_type="lidar_occupancy_reference")
