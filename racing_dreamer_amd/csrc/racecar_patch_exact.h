@@ -24,10 +24,12 @@
 #define PX_KSIZE 15
 #define PX_BITS 22
 #define PX_T 25                               // the sample kernel renders the 200 x 200 window in 8 x 10 tiles of PX_T rows x PX_TW columns:
+#ifndef PX_TW
 #define PX_TW 20                              // 500 pixels = two passes of 256 threads at 98 % (square tiles of 40 / 25 / 20 / 10: EXPERIMENTS.md 000.4;
                                               // 25 x 25 is three passes at 81 %)
 #define PX_TILE_N 39                          // a tile's taps lie within sqrt(24^2 + 19^2) + 9 = 39.6 coefficients per axis
-#define PX_TILE_PITCH 39                      // doubles per staged column (odd: consecutive columns start in different LDS banks)
+#define PX_TILE_PITCH 39                      // values per staged column (odd: consecutive columns start in different LDS banks)
+#endif
 #define PX_Z (-0.2679491924311227)            // scipy ni_splines.c: the cubic spline's pole, sqrt(3) - 2 correctly rounded
 #define PX_ZN (-5.539710763905135e-126)       // pow(PX_Z, 219)
 #define PX_PI180 1.74532925199432957692e-2
