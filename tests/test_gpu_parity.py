@@ -1124,6 +1124,22 @@ def test_mixed_track_env_blocks_equal_their_oracles():
             compare_outputs({k2: v[a:b] for k2, v in dv.items()}, ov, b - a, 2, f"step {k}, block [{a}, {b}) on {nm}")
     assert sum(int(np.asarray(ov["done"]).sum()) for ov in ovs) >= 0
     env.close()
+    # ... and with the reference's own render (obs_type lidar_occupancy_reference): every handle of the group renders its block
+    names, sizes = ["columbia", "austria"], [14, 10]
+    env = MixedTrackEnv(names, sizes, cars_per_env=1, obs_type="lidar_occupancy_reference", auto_reset=True)
+    oras = [make_oracle(load_track(nm), num_envs=n, cars_per_env=1, auto_reset=True, render_occupancy="reference", first_env=a)
+            for nm, n, (a, b) in zip(names, sizes, env.blocks)]
+    dv = env.reset(mode="random", seed=4)
+    ovs = [o.reset(mode=spec.RESET_RANDOM, seed=4) for o in oras]
+    for k in range(3):
+        act = ro.random_actions(6, k, 24)
+        act[:, 0] = np.abs(act[:, 0])
+        dv = env.step(torch.from_numpy(act).cuda().view(24, 1, 2), repeat=2)
+        ovs = [o.step(act[a:b], repeat=2) for o, (a, b) in zip(oras, env.blocks)]
+        for (a, b), ov, nm in zip(env.blocks, ovs, names):
+            compare_outputs({k2: v[a:b] for k2, v in dv.items()}, ov, b - a, 1, f"reference render, step {k}, block [{a}, {b}) on {nm}")
+    assert dv["lidar_occupancy"].any()
+    env.close()
     # the same track in two blocks == one batch
     two = MixedTrackEnv(["columbia", "columbia"], [70, 58], auto_reset=True)
     one = BatchedRaceEnv("columbia", 128, 1, auto_reset=True)
